@@ -1,0 +1,87 @@
+// dge_internal.h — handle layouts and error plumbing shared by graph.hip and sgns.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/dge.h"
+
+void dge_set_error(const char* fmt, ...);
+
+#define DGE_FAIL(code, ...)            \
+    do {                               \
+        dge_set_error(__VA_ARGS__);    \
+        return (code);                 \
+    } while (0)
+
+#define DGE_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            dge_set_error("HIP error %s at %s:%d: %s", hipGetErrorName(e__), __FILE__, __LINE__, #expr); \
+            return DGE_ERR_DEVICE;                                                            \
+        }                                                                                     \
+    } while (0)
+
+int dge_require_device(int device);   // DGE_OK when `device` is a usable gfx950 device, sets it current
+
+template <typename T>
+static inline int dge_dev_alloc(T** p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    DGE_HIP(hipMalloc((void**)p, n * sizeof(T)));
+    return DGE_OK;
+}
+static inline void dge_dev_free(void* p) { if (p) (void)hipFree(p); }
+
+// One alias slot as the walk kernel reads it: 16 bytes, one dwordx4 load per step.
+// nbr_alias already resolves alias[i] to the neighbour it points at ("alias == -1" -> nbr itself).
+struct __attribute__((aligned(16))) dge_slot {
+    double prob;
+    int32_t nbr;
+    int32_t nbr_alias;
+};
+
+struct dge_graph {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // COO staging in insertion order (allEdges, J/LayeredGraph.java:142)
+    int64_t n_coo = 0, cap_coo = 0;
+    int32_t *d_coo_src = nullptr, *d_coo_dst = nullptr;
+    double* d_coo_w = nullptr;
+    int32_t max_id = -1;
+    // CSR
+    bool csr_built = false, alias_built = false;
+    int32_t V = 0;
+    int64_t E = 0;
+    int64_t* d_row_ptr = nullptr;
+    int32_t* d_nbr = nullptr;
+    double* d_w = nullptr;
+    double* d_outdeg = nullptr;
+    double* d_prob = nullptr;
+    int32_t* d_alias = nullptr;
+    dge_slot* d_slots = nullptr;
+    // sources (J/LayeredGraph.java:145-148)
+    int64_t S = 0;
+    int32_t* d_srcv = nullptr;
+    double src_weight_sum = 0.0;
+    double* d_src_w = nullptr;
+    double* d_src_prob = nullptr;
+    int32_t* d_src_alias = nullptr;
+    dge_slot* d_src_slots = nullptr;
+};
+
+struct dge_walks {
+    int device = 0;
+    int64_t n = 0;
+    int32_t L = 0;
+    int32_t* d = nullptr;
+};
+
+int dge_graph_ensure_csr(dge_graph* g);
+// launches the strided walk kernel on `stream`; rows [row0,row0+n) of out (row length L)
+int dge_launch_walks_strided(const dge_graph* g, hipStream_t stream, int32_t* d_out, int64_t n, int32_t L,
+                             int64_t seed, int64_t first_index, int32_t* d_deadend_count);

@@ -1,0 +1,777 @@
+// sgns.hip — vocabulary, unigram table and the skip-gram negative-sampling trainer of libdge.so (gfx950).
+//
+// Replaces `new Word2Vec.Builder()...build(); w2v.fit()` (J/DeepWalk.java:73-79).  The arithmetic of that call
+// lives in DL4J-NLP 0.7.2 / ND4J-native 0.7.2 (not under /root/reference); what is implemented is the word2vec
+// skip-gram negative-sampling update with DL4J's pair enumeration, as restated in oracle/dge_oracle.c
+// (SURVEY.md §3.3, row a9).
+//
+// HBM layout: syn0, syn1neg  float32 [V x stride], stride = round_up(dim, 64) floats (zero padded) so that a row
+// is 1..4 chunks of 256 B and a 16-lane group moves one chunk with one dwordx4 per lane.
+// Work decomposition: one 16-lane group ("worker") per walk; 4 workers per wave.  A worker owns D/16 floats of
+// every row it touches in registers, dot products are 16-lane xor-butterflies (DPP-sized), and the K negative
+// rows of a pair are in flight together.  Updates are plain stores (Hogwild, like the reference's 8 DL4J
+// workers); workers == 1 gives the in-order schedule the oracle follows.
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "dge_algos.h"
+#include "dge_internal.h"
+
+#define EXP_TABLE_SIZE 1000
+#define MAX_EXP 6
+#define NEG_BATCH 5
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+struct dge_model {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    dge_train_config cfg{};
+    int64_t V = 0;
+    int32_t D = 0, stride = 0, NV = 0;
+    int64_t T = 0;
+    int64_t total_words = 0;
+    float *d_syn0 = nullptr, *d_syn1neg = nullptr, *d_snap = nullptr;
+    int32_t* d_vocab_ids = nullptr;
+    int64_t* d_counts = nullptr;
+    int32_t* d_remap = nullptr;
+    int32_t* d_table = nullptr;
+    float* d_exp = nullptr;
+    // per-call work buffers
+    int64_t cap_rows = 0; int32_t cap_L = 0;
+    int32_t* d_sen = nullptr; int64_t* d_len = nullptr; int64_t* d_wb = nullptr;
+    void* d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
+    unsigned long long* d_counters = nullptr;   // [0]=pairs [1]=words
+    // host mirrors for the read-back API
+    std::vector<float> h_syn0, h_syn1neg;
+    std::vector<int32_t> h_vocab_ids, h_table;
+    std::vector<int64_t> h_counts;
+    // stats
+    std::vector<EventPair> pending;
+    double kernel_ms = 0, walk_ms = 0;
+    int64_t launches = 0;
+};
+
+// ------------------------------------------------------------------------------------------ vocabulary
+__global__ void k_count_tokens(const int32_t* __restrict__ walks, int64_t n, int32_t NV, unsigned long long* counts) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int32_t t = walks[i];
+        if (t >= 0 && t < NV) atomicAdd(&counts[t], 1ULL);
+    }
+}
+
+__global__ void k_iota_i32(int32_t* p, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (int32_t)i;
+}
+
+__global__ void k_count_kept(const int64_t* sorted_counts, int64_t n, int64_t min_count, unsigned long long* out) {
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        c += (sorted_counts[i] >= min_count && sorted_counts[i] > 0) ? 1ULL : 0ULL;
+    for (int o = 32; o > 0; o >>= 1) c += (unsigned long long)__shfl_xor((long long)c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+__global__ void k_scatter_remap(const int32_t* vocab_ids, int64_t V, int32_t* remap) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < V) remap[vocab_ids[r]] = (int32_t)r;
+}
+
+// word2vec.c InitUnigramTable without the serial loop.  The loop advances the word index i by at most one per
+// slot a, whenever a/T > cum[i]; with j(a) = #{i : cum[i] < a/T} this is i(a+1) = min(i(a)+1, j(a)), whose
+// closed form is i(a) = a + min(0, min_{b<a}(j(b) - b - 1)): a binary search, an exclusive prefix-min, a clamp.
+__global__ void k_table_chase(const double* __restrict__ cum, int64_t V, int64_t T, int32_t* g) {
+    int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= T) return;
+    double x = (double)a / (double)T;
+    int64_t lo = 0, hi = V;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (cum[mid] < x) lo = mid + 1; else hi = mid; }
+    g[a] = (int32_t)(lo - a - 1);
+}
+__global__ void k_table_fill(const int32_t* __restrict__ m, int64_t V, int64_t T, int32_t* table) {
+    int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= T) return;
+    int64_t i = a + (int64_t)min(0, m[a]);
+    table[a] = (int32_t)min(i, V - 1);
+}
+
+// word2vec.c InitNet: syn0[a][b] = ((lcg & 0xFFFF)/65536 - 0.5)/dim, one LCG stream over the whole table
+__global__ void k_init_syn0(float* syn0, int64_t V, int32_t D, int32_t stride, uint64_t seed) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= V) return;
+    uint64_t s = dge_w2v_jump(seed, (uint64_t)r * (uint64_t)D);
+    float* row = syn0 + r * stride;
+    for (int b = 0; b < D; b++) {
+        s = s * DGE_W2V_MULT + 11;
+        row[b] = (((float)(s & 0xFFFF) / (float)65536) - 0.5f) / (float)D;
+    }
+    for (int b = D; b < stride; b++) row[b] = 0.0f;
+}
+
+// vertex ids -> vocabulary rows, out-of-vocabulary tokens dropped and the walk left-packed (word2vec / DL4J
+// filter the sentence before windowing); len = tokens kept
+__global__ void k_remap_compact(const int32_t* __restrict__ walks, int64_t n_rows, int32_t L, const int32_t* __restrict__ remap,
+                                int32_t NV, int32_t* __restrict__ sen, int64_t* __restrict__ len_out) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int32_t* in = walks + r * L;
+    int32_t* out = sen + r * L;
+    int len = 0;
+    for (int j = 0; j < L; j++) {
+        int32_t t = in[j];
+        int32_t v = (t >= 0 && t < NV) ? remap[t] : -1;
+        if (v >= 0) out[len++] = v;
+    }
+    for (int j = len; j < L; j++) out[j] = -1;
+    len_out[r] = len;
+}
+
+// ------------------------------------------------------------------------------------------ trainer
+struct TrainParams {
+    const int32_t* sen; const int64_t* len; const int64_t* wb;
+    float* syn0; float* syn1neg; const int32_t* table; const float* exp_table;
+    int64_t n_rows; int32_t L, W, K, stride;
+    int64_t V, T;
+    uint64_t seed;
+    int64_t gidx_base;        // (epoch*total_walks + walk_index_base): RNG stream key of row 0
+    int64_t words_done_base;  // epoch*total_words + words_before
+    int64_t all_words;        // epochs*total_words
+    double words_scale;
+    float alpha0, min_alpha;
+    int64_t n_workers;
+    unsigned long long* counters;
+};
+
+template <int DCH> struct Row { float4 v[DCH]; };
+
+__device__ __forceinline__ float group16_sum(float p) {
+    p += __shfl_xor(p, 1);
+    p += __shfl_xor(p, 2);
+    p += __shfl_xor(p, 4);
+    p += __shfl_xor(p, 8);
+    return p;
+}
+
+template <int DCH>
+__device__ __forceinline__ void row_load(Row<DCH>& r, const float* base, int64_t row, int stride, int lane) {
+    const float4* p = reinterpret_cast<const float4*>(base + row * stride) + lane;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) r.v[c] = p[c * 16];
+}
+template <int DCH>
+__device__ __forceinline__ void row_store(const Row<DCH>& r, float* base, int64_t row, int stride, int lane) {
+    float4* p = reinterpret_cast<float4*>(base + row * stride) + lane;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) p[c * 16] = r.v[c];
+}
+template <int DCH>
+__device__ __forceinline__ float row_dot(const Row<DCH>& a, const Row<DCH>& b) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        acc = fmaf(a.v[c].x, b.v[c].x, acc);
+        acc = fmaf(a.v[c].y, b.v[c].y, acc);
+        acc = fmaf(a.v[c].z, b.v[c].z, acc);
+        acc = fmaf(a.v[c].w, b.v[c].w, acc);
+    }
+    return group16_sum(acc);
+}
+// y += g * x
+template <int DCH>
+__device__ __forceinline__ void row_axpy(Row<DCH>& y, float g, const Row<DCH>& x) {
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        y.v[c].x = fmaf(g, x.v[c].x, y.v[c].x);
+        y.v[c].y = fmaf(g, x.v[c].y, y.v[c].y);
+        y.v[c].z = fmaf(g, x.v[c].z, y.v[c].z);
+        y.v[c].w = fmaf(g, x.v[c].w, y.v[c].w);
+    }
+}
+
+__device__ __forceinline__ float sgns_g(float f, float label, float alpha, const float* s_exp) {
+    if (f > (float)MAX_EXP) return (label - 1.0f) * alpha;
+    if (f < -(float)MAX_EXP) return (label - 0.0f) * alpha;
+    int idx = (int)((f + (float)MAX_EXP) * (float)(EXP_TABLE_SIZE / MAX_EXP / 2));
+    idx = min(max(idx, 0), EXP_TABLE_SIZE - 1);
+    return (label - s_exp[idx]) * alpha;
+}
+
+__device__ __forceinline__ uint64_t shfl16_u64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = (uint32_t)__shfl((int)lo, src, 16);
+    hi = (uint32_t)__shfl((int)hi, src, 16);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// one (target row, label 0) update against l1; sequential form used when a pair drew the same row twice
+template <int DCH>
+__device__ __forceinline__ void neg_update_serial(const Row<DCH>& l1, Row<DCH>& neu, float* syn1neg, int32_t tg, int stride,
+                                                  int lane, float alpha, const float* s_exp) {
+    Row<DCH> r;
+    row_load(r, syn1neg, tg, stride, lane);
+    float f = row_dot(l1, r);
+    float g = sgns_g(f, 0.0f, alpha, s_exp);
+    row_axpy(neu, g, r);
+    row_axpy(r, g, l1);
+    row_store(r, syn1neg, tg, stride, lane);
+}
+
+template <int DCH>
+__global__ void __launch_bounds__(256)
+k_sgns_train(TrainParams p) {
+    __shared__ float s_exp[EXP_TABLE_SIZE];
+    for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 15;
+    const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (worker >= p.n_workers) return;
+
+    // lane j turns the pair's LCG state s into the state after j+1 draws: s*mA + cA
+    uint64_t mA = 1, cA = 0;
+    for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
+
+    const int L = p.L, W = p.W, K = p.K, stride = p.stride;
+    unsigned long long my_pairs = 0, my_words = 0;
+
+    for (int64_t w = worker; w < p.n_rows; w += p.n_workers) {
+        const int32_t* sen = p.sen + w * L;
+        const int len = (int)p.len[w];
+        if (len <= 0) continue;
+        my_words += (unsigned long long)len;
+        // learning rate from the exact number of in-vocabulary tokens that precede this walk
+        int64_t wbw = p.wb[w];
+        int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
+        float alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
+        if (alpha < p.min_alpha) alpha = p.min_alpha;
+        const int64_t gbase = (p.gidx_base + w) * (int64_t)L;
+
+        for (int i = 0; i < len; i++) {
+            const int32_t word = sen[i];
+            uint64_t s = dge_mix64(p.seed + (uint64_t)(gbase + i));
+            s = s * DGE_W2V_MULT + 11;
+            const int b = (int)(s % (uint64_t)W);
+            Row<DCH> h;                                   // syn1neg[word]: positive target of every pair of this centre
+            row_load(h, p.syn1neg, word, stride, lane);
+            bool h_dirty = false;
+            for (int a = b; a < W * 2 + 1 - b; a++) {
+                if (a == W) continue;
+                const int c = i - W + a;
+                if (c < 0 || c >= len) continue;
+                const int32_t last = sen[c];
+                Row<DCH> l1, neu;
+                row_load(l1, p.syn0, last, stride, lane);
+#pragma unroll
+                for (int q = 0; q < DCH; q++) neu.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                {   // d == 0: target = word, label 1
+                    float f = row_dot(l1, h);
+                    float g = sgns_g(f, 1.0f, alpha, s_exp);
+                    row_axpy(neu, g, h);
+                    row_axpy(h, g, l1);
+                    h_dirty = true;
+                }
+                for (int kd = 0; kd < K; kd += 16) {
+                    const int kc = min(16, K - kd);
+                    // lane j draws negative kd+j
+                    const uint64_t sl = s * mA + cA;
+                    int32_t t = -1;
+                    if (lane < kc) {
+                        t = p.table[(sl >> 16) % (uint64_t)p.T];
+                        if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                        if (t == word) t = -1;
+                    }
+                    s = shfl16_u64(sl, kc - 1);
+                    for (int base = 0; base < kc; base += NEG_BATCH) {
+                        int32_t tg[NEG_BATCH];
+                        bool dup = false;
+#pragma unroll
+                        for (int q = 0; q < NEG_BATCH; q++) {
+                            int32_t v = __shfl(t, (base + q) & 15, 16);
+                            tg[q] = (base + q < kc) ? v : -1;
+                        }
+#pragma unroll
+                        for (int q = 1; q < NEG_BATCH; q++)
+#pragma unroll
+                            for (int r = 0; r < q; r++) dup |= (tg[q] >= 0 && tg[q] == tg[r]);
+                        if (!dup) {
+                            Row<DCH> rr[NEG_BATCH];
+#pragma unroll
+                            for (int q = 0; q < NEG_BATCH; q++)
+                                if (tg[q] >= 0) row_load(rr[q], p.syn1neg, tg[q], stride, lane);
+#pragma unroll
+                            for (int q = 0; q < NEG_BATCH; q++)
+                                if (tg[q] >= 0) {
+                                    float f = row_dot(l1, rr[q]);
+                                    float g = sgns_g(f, 0.0f, alpha, s_exp);
+                                    row_axpy(neu, g, rr[q]);
+                                    row_axpy(rr[q], g, l1);
+                                    row_store(rr[q], p.syn1neg, tg[q], stride, lane);
+                                }
+                        } else {
+#pragma unroll 1
+                            for (int q = 0; q < NEG_BATCH; q++)
+                                if (tg[q] >= 0) neg_update_serial<DCH>(l1, neu, p.syn1neg, tg[q], stride, lane, alpha, s_exp);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < DCH; q++) {
+                    l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
+                }
+                row_store(l1, p.syn0, last, stride, lane);
+                my_pairs++;
+            }
+            if (h_dirty) row_store(h, p.syn1neg, word, stride, lane);
+        }
+    }
+    if (lane == 0) {
+        if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
+        if (my_words) atomicAdd(&p.counters[1], my_words);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ delta exchange
+__global__ void k_delta_export(const float* __restrict__ cur, const float* __restrict__ snap, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = cur[i] - snap[i];
+}
+__global__ void k_delta_import(float* __restrict__ cur, float* __restrict__ snap, const float* __restrict__ in, float scale, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = fmaf(scale, in[i], snap[i]);
+        cur[i] = v; snap[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+extern "C" int dge_count_tokens(const dge_walks* w, int64_t row0, int64_t n_rows, int32_t n_vertices, int64_t* d_counts) {
+    if (!w || !d_counts || row0 < 0 || n_rows < 0 || row0 + n_rows > w->n || n_vertices <= 0) DGE_FAIL(DGE_ERR_ARG, "dge_count_tokens: bad argument");
+    DGE_HIP(hipSetDevice(w->device));
+    int64_t n = n_rows * w->L;
+    if (n == 0) return DGE_OK;
+    unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_count_tokens, dim3(blocks), dim3(256), 0, 0, w->d + row0 * w->L, n, n_vertices, (unsigned long long*)d_counts);
+    DGE_HIP(hipGetLastError());
+    DGE_HIP(hipStreamSynchronize(0));
+    return DGE_OK;
+}
+
+static void model_release(dge_model* m) {
+    dge_dev_free(m->d_syn0); dge_dev_free(m->d_syn1neg); dge_dev_free(m->d_snap); dge_dev_free(m->d_vocab_ids);
+    dge_dev_free(m->d_counts); dge_dev_free(m->d_remap); dge_dev_free(m->d_table); dge_dev_free(m->d_exp);
+    dge_dev_free(m->d_sen); dge_dev_free(m->d_len); dge_dev_free(m->d_wb); dge_dev_free(m->d_scan_tmp); dge_dev_free(m->d_counters);
+    for (auto& e : m->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
+}
+
+extern "C" void dge_model_free(dge_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    model_release(m);
+    delete m;
+}
+
+extern "C" int dge_model_set_stream(dge_model* m, void* hip_stream) {
+    if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_set_stream: null model");
+    DGE_HIP(hipSetDevice(m->device));
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
+    m->stream = (hipStream_t)hip_stream;
+    m->own_stream = false;
+    return DGE_OK;
+}
+
+static bool dim_supported(int dch) { return dch == 1 || dch == 2 || dch == 3 || dch == 4 || dch == 6 || dch == 8; }
+
+extern "C" int dge_model_create(int device, const dge_train_config* cfg, const int64_t* d_counts, dge_model** out) {
+    if (!out || !cfg || !d_counts) DGE_FAIL(DGE_ERR_ARG, "dge_model_create: null argument");
+    *out = nullptr;
+    if (cfg->dim <= 0 || cfg->window <= 0 || cfg->negative < 0 || cfg->n_vertices <= 0 || cfg->epochs < 0 || cfg->workers < 0)
+        DGE_FAIL(DGE_ERR_ARG, "dge_model_create: dim/window/n_vertices must be positive, negative/epochs/workers non-negative");
+    int dch = (cfg->dim + 63) / 64;
+    if (!dim_supported(dch)) dch = dch <= 6 ? 6 : 8;
+    if (cfg->dim > 512) DGE_FAIL(DGE_ERR_ARG, "dge_model_create: dim %d > 512 is not supported", cfg->dim);
+    int rc = dge_require_device(device);
+    if (rc) return rc;
+    dge_model* m = new dge_model();
+    m->device = device;
+    m->cfg = *cfg;
+    if (m->cfg.table_size <= 0) m->cfg.table_size = 100000000LL;
+    if (m->cfg.table_size >= 0x7fffffffLL) { delete m; DGE_FAIL(DGE_ERR_ARG, "dge_model_create: table_size must be < 2^31"); }
+    m->D = cfg->dim; m->stride = dch * 64; m->NV = cfg->n_vertices; m->T = m->cfg.table_size;
+    hipError_t he = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) { delete m; DGE_FAIL(DGE_ERR_DEVICE, "hipStreamCreate failed"); }
+    m->own_stream = true;
+    hipStream_t st = m->stream;
+    const int32_t NV = m->NV;
+
+#define MC(expr) do { int rc__ = (expr); if (rc__) { model_release(m); delete m; return rc__; } } while (0)
+#define MH(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { dge_set_error("HIP error %s at %s:%d", hipGetErrorName(e__), __FILE__, __LINE__); model_release(m); delete m; return DGE_ERR_DEVICE; } } while (0)
+
+    // --- vocabulary: stable descending sort on count (ids ascending inside a tie), keep count >= min_count
+    int32_t *d_ids = nullptr, *d_ids_sorted = nullptr; int64_t* d_cnt_sorted = nullptr; unsigned long long* d_kept = nullptr;
+    MC(dge_dev_alloc(&d_ids, (size_t)NV)); MC(dge_dev_alloc(&d_ids_sorted, (size_t)NV)); MC(dge_dev_alloc(&d_cnt_sorted, (size_t)NV));
+    MC(dge_dev_alloc(&d_kept, 2));
+    hipLaunchKernelGGL(k_iota_i32, dim3(grid_for(NV, 256)), dim3(256), 0, st, d_ids, (int64_t)NV);
+    size_t tmp_bytes = 0;
+    MH(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, d_counts, d_cnt_sorted, d_ids, d_ids_sorted, NV, 0, 64, st));
+    void* d_tmp = nullptr;
+    MH(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+    MH(hipcub::DeviceRadixSort::SortPairsDescending(d_tmp, tmp_bytes, d_counts, d_cnt_sorted, d_ids, d_ids_sorted, NV, 0, 64, st));
+    MH(hipMemsetAsync(d_kept, 0, 2 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_count_kept, dim3(std::min<unsigned>(grid_for(NV, 256), 2048u)), dim3(256), 0, st, d_cnt_sorted, (int64_t)NV,
+                       (int64_t)cfg->min_count, d_kept);
+    unsigned long long kept = 0;
+    MH(hipMemcpyAsync(&kept, d_kept, sizeof(kept), hipMemcpyDeviceToHost, st));
+    MH(hipStreamSynchronize(st));
+    dge_dev_free(d_tmp); d_tmp = nullptr;
+    const int64_t V = (int64_t)kept;
+    m->V = V;
+    MC(dge_dev_alloc(&m->d_vocab_ids, (size_t)V)); MC(dge_dev_alloc(&m->d_counts, (size_t)V)); MC(dge_dev_alloc(&m->d_remap, (size_t)NV));
+    if (V) {
+        MH(hipMemcpyAsync(m->d_vocab_ids, d_ids_sorted, V * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        MH(hipMemcpyAsync(m->d_counts, d_cnt_sorted, V * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    }
+    MH(hipMemsetAsync(m->d_remap, 0xFF, (size_t)NV * sizeof(int32_t), st));
+    if (V) hipLaunchKernelGGL(k_scatter_remap, dim3(grid_for(V, 256)), dim3(256), 0, st, m->d_vocab_ids, V, m->d_remap);
+    m->h_counts.resize((size_t)V); m->h_vocab_ids.resize((size_t)V);
+    if (V) {
+        MH(hipMemcpyAsync(m->h_counts.data(), m->d_counts, V * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        MH(hipMemcpyAsync(m->h_vocab_ids.data(), m->d_vocab_ids, V * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
+    MH(hipStreamSynchronize(st));
+    dge_dev_free(d_ids); dge_dev_free(d_ids_sorted); dge_dev_free(d_cnt_sorted); dge_dev_free(d_kept);
+    int64_t tw = 0;
+    for (int64_t i = 0; i < V; i++) tw += m->h_counts[(size_t)i];
+    m->total_words = tw;
+
+    // --- unigram^0.75 cumulative (word2vec.c InitUnigramTable's running d1; a serial double sum by definition)
+    MC(dge_dev_alloc(&m->d_table, (size_t)m->T));
+    if (V > 0) {
+        std::vector<double> cum((size_t)V);
+        double twp = 0.0; const double power = 0.75;
+        for (int64_t i = 0; i < V; i++) twp += pow((double)m->h_counts[(size_t)i], power);
+        double d1 = 0.0;
+        for (int64_t i = 0; i < V; i++) { d1 = (i == 0) ? pow((double)m->h_counts[0], power) / twp : d1 + pow((double)m->h_counts[(size_t)i], power) / twp; cum[(size_t)i] = d1; }
+        double* d_cum = nullptr; int32_t *d_g = nullptr, *d_m = nullptr;
+        MC(dge_dev_alloc(&d_cum, (size_t)V)); MC(dge_dev_alloc(&d_g, (size_t)m->T)); MC(dge_dev_alloc(&d_m, (size_t)m->T));
+        MH(hipMemcpyAsync(d_cum, cum.data(), V * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_table_chase, dim3(grid_for(m->T, 256)), dim3(256), 0, st, d_cum, V, m->T, d_g);
+        tmp_bytes = 0;
+        MH(hipcub::DeviceScan::ExclusiveScan(nullptr, tmp_bytes, d_g, d_m, hipcub::Min(), (int32_t)0, m->T, st));
+        MH(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+        MH(hipcub::DeviceScan::ExclusiveScan(d_tmp, tmp_bytes, d_g, d_m, hipcub::Min(), (int32_t)0, m->T, st));
+        hipLaunchKernelGGL(k_table_fill, dim3(grid_for(m->T, 256)), dim3(256), 0, st, d_m, V, m->T, m->d_table);
+        MH(hipStreamSynchronize(st));
+        dge_dev_free(d_tmp); dge_dev_free(d_cum); dge_dev_free(d_g); dge_dev_free(d_m);
+    } else {
+        MH(hipMemsetAsync(m->d_table, 0, (size_t)m->T * sizeof(int32_t), st));
+    }
+
+    // --- sigmoid LUT (word2vec.c expTable) and weights
+    {
+        float e[EXP_TABLE_SIZE];
+        for (int i = 0; i < EXP_TABLE_SIZE; i++) {
+            float x = (float)exp((i / (float)EXP_TABLE_SIZE * 2 - 1) * MAX_EXP);
+            e[i] = x / (x + 1);
+        }
+        MC(dge_dev_alloc(&m->d_exp, EXP_TABLE_SIZE));
+        MH(hipMemcpyAsync(m->d_exp, e, sizeof(e), hipMemcpyHostToDevice, st));
+        MH(hipStreamSynchronize(st));
+    }
+    size_t tab = (size_t)V * (size_t)m->stride;
+    MC(dge_dev_alloc(&m->d_syn0, tab + 64)); MC(dge_dev_alloc(&m->d_syn1neg, tab + 64));
+    MH(hipMemsetAsync(m->d_syn1neg, 0, (tab + 64) * sizeof(float), st));
+    if (V) hipLaunchKernelGGL(k_init_syn0, dim3(grid_for(V, 256)), dim3(256), 0, st, m->d_syn0, V, m->D, m->stride, cfg->seed);
+    MC(dge_dev_alloc(&m->d_counters, 2));
+    MH(hipMemsetAsync(m->d_counters, 0, 2 * sizeof(unsigned long long), st));
+    MH(hipStreamSynchronize(st));
+    MH(hipGetLastError());
+#undef MC
+#undef MH
+    *out = m;
+    return DGE_OK;
+}
+
+static int ensure_work(dge_model* m, int64_t n_rows, int32_t L) {
+    if (n_rows <= m->cap_rows && L <= m->cap_L) return DGE_OK;
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    dge_dev_free(m->d_sen); dge_dev_free(m->d_len); dge_dev_free(m->d_wb); dge_dev_free(m->d_scan_tmp);
+    m->d_sen = nullptr; m->d_len = nullptr; m->d_wb = nullptr; m->d_scan_tmp = nullptr;
+    int64_t nr = std::max(n_rows, m->cap_rows); int32_t nl = std::max(L, m->cap_L);
+    int rc;
+    if ((rc = dge_dev_alloc(&m->d_sen, (size_t)(nr * nl)))) return rc;
+    if ((rc = dge_dev_alloc(&m->d_len, (size_t)nr))) return rc;
+    if ((rc = dge_dev_alloc(&m->d_wb, (size_t)nr))) return rc;
+    size_t bytes = 0;
+    DGE_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, m->d_len, m->d_wb, nr, m->stream));
+    DGE_HIP(hipMalloc(&m->d_scan_tmp, bytes ? bytes : 1));
+    m->scan_tmp_bytes = bytes;
+    m->cap_rows = nr; m->cap_L = nl;
+    return DGE_OK;
+}
+
+template <int DCH>
+static void launch_train(const TrainParams& p, unsigned blocks, unsigned threads, hipStream_t st) {
+    hipLaunchKernelGGL(k_sgns_train<DCH>, dim3(blocks), dim3(threads), 0, st, p);
+}
+
+static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32_t L, int64_t walk_index_base, int32_t epoch,
+                      int64_t words_before, double words_scale, int64_t total_walks) {
+    if (n_rows == 0 || m->V == 0) return DGE_OK;
+    int rc = ensure_work(m, n_rows, L);
+    if (rc) return rc;
+    hipStream_t st = m->stream;
+    hipLaunchKernelGGL(k_remap_compact, dim3(grid_for(n_rows, 256)), dim3(256), 0, st, d_rows, n_rows, L, m->d_remap, m->NV, m->d_sen, m->d_len);
+    size_t bytes = m->scan_tmp_bytes;
+    DGE_HIP(hipcub::DeviceScan::ExclusiveSum(m->d_scan_tmp, bytes, m->d_len, m->d_wb, n_rows, st));
+
+    TrainParams p;
+    p.sen = m->d_sen; p.len = m->d_len; p.wb = m->d_wb;
+    p.syn0 = m->d_syn0; p.syn1neg = m->d_syn1neg; p.table = m->d_table; p.exp_table = m->d_exp;
+    p.n_rows = n_rows; p.L = L; p.W = m->cfg.window; p.K = m->cfg.negative; p.stride = m->stride;
+    p.V = m->V; p.T = m->T; p.seed = m->cfg.seed;
+    p.gidx_base = (int64_t)epoch * total_walks + walk_index_base;
+    p.words_done_base = (int64_t)epoch * m->total_words + words_before;
+    p.all_words = (int64_t)std::max(m->cfg.epochs, 1) * m->total_words;
+    p.words_scale = words_scale;
+    p.alpha0 = m->cfg.alpha; p.min_alpha = m->cfg.min_alpha;
+    p.counters = m->d_counters;
+
+    int64_t workers;
+    if (m->cfg.workers == 0) {
+        hipDeviceProp_t prop;
+        DGE_HIP(hipGetDeviceProperties(&prop, m->device));
+        workers = (int64_t)prop.multiProcessorCount * 4 /*blocks per CU*/ * 16 /*workers per 256-thread block*/;
+        workers = std::min(workers, (n_rows + 15) / 16 * 16);
+    } else workers = m->cfg.workers;
+    p.n_workers = workers;
+    unsigned threads = workers == 1 ? 64u : 256u;
+    unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
+
+    EventPair ev; ev.kind = 0;
+    DGE_HIP(hipEventCreate(&ev.a)); DGE_HIP(hipEventCreate(&ev.b));
+    DGE_HIP(hipEventRecord(ev.a, st));
+    switch (m->stride / 64) {
+        case 1: launch_train<1>(p, blocks, threads, st); break;
+        case 2: launch_train<2>(p, blocks, threads, st); break;
+        case 3: launch_train<3>(p, blocks, threads, st); break;
+        case 4: launch_train<4>(p, blocks, threads, st); break;
+        case 6: launch_train<6>(p, blocks, threads, st); break;
+        default: launch_train<8>(p, blocks, threads, st); break;
+    }
+    DGE_HIP(hipEventRecord(ev.b, st));
+    m->pending.push_back(ev);
+    m->launches++;
+    DGE_HIP(hipGetLastError());
+    return DGE_OK;
+}
+
+extern "C" int dge_model_train(dge_model* m, const dge_walks* w, int64_t row0, int64_t n_rows, int64_t walk_index_base, int32_t epoch,
+                               int64_t words_before, double words_scale, int64_t total_walks) {
+    if (!m || !w || row0 < 0 || n_rows < 0 || row0 + n_rows > w->n || epoch < 0 || words_before < 0 || !(words_scale > 0))
+        DGE_FAIL(DGE_ERR_ARG, "dge_model_train: bad argument");
+    if (w->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_train: corpus and model live on different devices");
+    DGE_HIP(hipSetDevice(m->device));
+    if (total_walks <= 0) total_walks = w->n;
+    return train_rows(m, w->d + row0 * w->L, n_rows, w->L, walk_index_base, epoch, words_before, words_scale, total_walks);
+}
+
+extern "C" int dge_model_walk_and_train(dge_model* m, const dge_graph* g, dge_walks* w, int64_t row0, int64_t n_rows, int64_t walk_seed,
+                                        int64_t walk_index_base, int32_t epoch, int64_t words_before, double words_scale, int64_t total_walks) {
+    if (!m || !g || !w || row0 < 0 || n_rows < 0 || row0 + n_rows > w->n) DGE_FAIL(DGE_ERR_ARG, "dge_model_walk_and_train: bad argument");
+    if (!g->alias_built) DGE_FAIL(DGE_ERR_STATE, "dge_model_walk_and_train: alias tables not built");
+    if (w->device != m->device || g->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_walk_and_train: handles live on different devices");
+    DGE_HIP(hipSetDevice(m->device));
+    EventPair ev; ev.kind = 1;
+    DGE_HIP(hipEventCreate(&ev.a)); DGE_HIP(hipEventCreate(&ev.b));
+    DGE_HIP(hipEventRecord(ev.a, m->stream));
+    int rc = dge_launch_walks_strided(g, m->stream, w->d + row0 * w->L, n_rows, w->L, walk_seed, walk_index_base, nullptr);
+    if (rc) return rc;
+    DGE_HIP(hipEventRecord(ev.b, m->stream));
+    m->pending.push_back(ev);
+    if (total_walks <= 0) total_walks = w->n;
+    return train_rows(m, w->d + row0 * w->L, n_rows, w->L, walk_index_base, epoch, words_before, words_scale, total_walks);
+}
+
+extern "C" int dge_train_sgns_device(const dge_walks* w, const dge_train_config* cfg, dge_model** out) {
+    if (!w || !cfg || !out) DGE_FAIL(DGE_ERR_ARG, "dge_train_sgns_device: null argument");
+    *out = nullptr;
+    if (cfg->n_vertices <= 0) DGE_FAIL(DGE_ERR_ARG, "dge_train_sgns_device: n_vertices must be positive");
+    DGE_HIP(hipSetDevice(w->device));
+    int64_t* d_counts = nullptr;
+    int rc = dge_dev_alloc(&d_counts, (size_t)cfg->n_vertices);
+    if (rc) return rc;
+    DGE_HIP(hipMemset(d_counts, 0, (size_t)cfg->n_vertices * sizeof(int64_t)));
+    rc = dge_count_tokens(w, 0, w->n, cfg->n_vertices, d_counts);
+    dge_model* m = nullptr;
+    if (!rc) rc = dge_model_create(w->device, cfg, d_counts, &m);
+    dge_dev_free(d_counts);
+    if (rc) return rc;
+    for (int ep = 0; ep < cfg->epochs && !rc; ep++) rc = dge_model_train(m, w, 0, w->n, 0, ep, 0, 1.0, w->n);
+    if (!rc) { hipError_t e = hipStreamSynchronize(m->stream); if (e != hipSuccess) { dge_set_error("training failed: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; } }
+    if (rc) { dge_model_free(m); return rc; }
+    *out = m;
+    return DGE_OK;
+}
+
+extern "C" int dge_train_sgns(int device, const int32_t* walks, int64_t n_walks, int32_t max_len, const dge_train_config* cfg, dge_model** out) {
+    dge_walks* w = nullptr;
+    int rc = dge_walks_from_host(device, walks, n_walks, max_len, &w);
+    if (rc) return rc;
+    rc = dge_train_sgns_device(w, cfg, out);
+    dge_walks_free(w);
+    return rc;
+}
+
+static int sync_tables_to_host(dge_model* m, bool want_syn0, bool want_syn1) {
+    DGE_HIP(hipSetDevice(m->device));
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    size_t tab = (size_t)m->V * (size_t)m->stride;
+    std::vector<float> tmp(tab ? tab : 1);
+    for (int which = 0; which < 2; which++) {
+        if ((which == 0 && !want_syn0) || (which == 1 && !want_syn1)) continue;
+        if (tab) DGE_HIP(hipMemcpy(tmp.data(), which == 0 ? m->d_syn0 : m->d_syn1neg, tab * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<float>& dst = which == 0 ? m->h_syn0 : m->h_syn1neg;
+        dst.resize((size_t)m->V * (size_t)m->D);
+        for (int64_t r = 0; r < m->V; r++) memcpy(dst.data() + r * m->D, tmp.data() + r * m->stride, (size_t)m->D * sizeof(float));
+    }
+    return DGE_OK;
+}
+
+extern "C" int dge_model_vectors(dge_model* m, const float** syn0, const int32_t** vocab_ids, int64_t* V, int32_t* dim) {
+    if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_vectors: null model");
+    int rc = sync_tables_to_host(m, true, false);
+    if (rc) return rc;
+    if (syn0) *syn0 = m->h_syn0.data();
+    if (vocab_ids) *vocab_ids = m->h_vocab_ids.data();
+    if (V) *V = m->V;
+    if (dim) *dim = m->D;
+    return DGE_OK;
+}
+extern "C" int dge_model_syn1neg(dge_model* m, const float** syn1neg) {
+    if (!m || !syn1neg) DGE_FAIL(DGE_ERR_ARG, "dge_model_syn1neg: null argument");
+    int rc = sync_tables_to_host(m, false, true);
+    if (rc) return rc;
+    *syn1neg = m->h_syn1neg.data();
+    return DGE_OK;
+}
+extern "C" int dge_model_counts(dge_model* m, const int64_t** counts) {
+    if (!m || !counts) DGE_FAIL(DGE_ERR_ARG, "dge_model_counts: null argument");
+    *counts = m->h_counts.data();
+    return DGE_OK;
+}
+extern "C" int dge_model_table(dge_model* m, const int32_t** table, int64_t* table_size) {
+    if (!m || !table) DGE_FAIL(DGE_ERR_ARG, "dge_model_table: null argument");
+    DGE_HIP(hipSetDevice(m->device));
+    m->h_table.resize((size_t)m->T);
+    DGE_HIP(hipMemcpy(m->h_table.data(), m->d_table, (size_t)m->T * sizeof(int32_t), hipMemcpyDeviceToHost));
+    *table = m->h_table.data();
+    if (table_size) *table_size = m->T;
+    return DGE_OK;
+}
+
+static int drain_events(dge_model* m) {
+    if (m->pending.empty()) return DGE_OK;
+    DGE_HIP(hipSetDevice(m->device));
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    for (auto& e : m->pending) {
+        float ms = 0.f;
+        DGE_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+        if (e.kind == 0) m->kernel_ms += ms; else m->walk_ms += ms;
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    m->pending.clear();
+    return DGE_OK;
+}
+
+extern "C" int dge_model_stats(const dge_model* mc, dge_train_stats* out) {
+    dge_model* m = const_cast<dge_model*>(mc);
+    if (!m || !out) DGE_FAIL(DGE_ERR_ARG, "dge_model_stats: null argument");
+    int rc = drain_events(m);
+    if (rc) return rc;
+    unsigned long long c[2] = {0, 0};
+    DGE_HIP(hipMemcpy(c, m->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    out->pairs = (int64_t)c[0]; out->words = (int64_t)c[1];
+    out->kernel_ms = m->kernel_ms; out->walk_kernel_ms = m->walk_ms; out->launches = m->launches;
+    return DGE_OK;
+}
+
+extern "C" int dge_model_reset_stats(dge_model* m) {
+    if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_reset_stats: null model");
+    int rc = drain_events(m);
+    if (rc) return rc;
+    DGE_HIP(hipMemset(m->d_counters, 0, 2 * sizeof(unsigned long long)));
+    m->kernel_ms = 0; m->walk_ms = 0; m->launches = 0;
+    return DGE_OK;
+}
+
+extern "C" int dge_write_vec(dge_model* m, const char* const* names, const char* path, int header) {
+    if (!m || !path) DGE_FAIL(DGE_ERR_ARG, "dge_write_vec: null argument");
+    int rc = sync_tables_to_host(m, true, false);
+    if (rc) return rc;
+    FILE* f = fopen(path, "w");
+    if (!f) DGE_FAIL(DGE_ERR_IO, "dge_write_vec: cannot open %s", path);
+    if (header) fprintf(f, "%lld %d\n", (long long)m->V, m->D);
+    for (int64_t r = 0; r < m->V; r++) {
+        int32_t id = m->h_vocab_ids[(size_t)r];
+        if (names && names[id]) fputs(names[id], f); else fprintf(f, "%d", id);
+        const float* v = m->h_syn0.data() + r * m->D;
+        for (int j = 0; j < m->D; j++) fprintf(f, " %.9g", (double)v[j]);
+        fputc('\n', f);
+    }
+    if (fclose(f) != 0) DGE_FAIL(DGE_ERR_IO, "dge_write_vec: write to %s failed", path);
+    return DGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ multi-GPU exchange
+extern "C" int dge_model_sync_size(const dge_model* m, int64_t* n_floats) {
+    if (!m || !n_floats) DGE_FAIL(DGE_ERR_ARG, "dge_model_sync_size: null argument");
+    *n_floats = 2 * m->V * (int64_t)m->stride;
+    return DGE_OK;
+}
+
+extern "C" int dge_model_snapshot(dge_model* m) {
+    if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_snapshot: null model");
+    DGE_HIP(hipSetDevice(m->device));
+    size_t tab = (size_t)m->V * (size_t)m->stride;
+    if (!m->d_snap) { int rc = dge_dev_alloc(&m->d_snap, 2 * tab + 64); if (rc) return rc; }
+    DGE_HIP(hipMemcpyAsync(m->d_snap, m->d_syn0, tab * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+    DGE_HIP(hipMemcpyAsync(m->d_snap + tab, m->d_syn1neg, tab * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    return DGE_OK;
+}
+
+extern "C" int dge_model_export_delta(dge_model* m, float* d_buf) {
+    if (!m || !d_buf) DGE_FAIL(DGE_ERR_ARG, "dge_model_export_delta: null argument");
+    if (!m->d_snap) DGE_FAIL(DGE_ERR_STATE, "dge_model_export_delta: call dge_model_snapshot before training the shard");
+    DGE_HIP(hipSetDevice(m->device));
+    int64_t tab = m->V * (int64_t)m->stride;
+    if (tab) {
+        hipLaunchKernelGGL(k_delta_export, dim3(2048), dim3(256), 0, m->stream, m->d_syn0, m->d_snap, d_buf, tab);
+        hipLaunchKernelGGL(k_delta_export, dim3(2048), dim3(256), 0, m->stream, m->d_syn1neg, m->d_snap + tab, d_buf + tab, tab);
+    }
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    DGE_HIP(hipGetLastError());
+    return DGE_OK;
+}
+
+extern "C" int dge_model_import_delta(dge_model* m, const float* d_buf, float scale) {
+    if (!m || !d_buf) DGE_FAIL(DGE_ERR_ARG, "dge_model_import_delta: null argument");
+    if (!m->d_snap) DGE_FAIL(DGE_ERR_STATE, "dge_model_import_delta: no snapshot");
+    DGE_HIP(hipSetDevice(m->device));
+    int64_t tab = m->V * (int64_t)m->stride;
+    if (tab) {
+        hipLaunchKernelGGL(k_delta_import, dim3(2048), dim3(256), 0, m->stream, m->d_syn0, m->d_snap, d_buf, scale, tab);
+        hipLaunchKernelGGL(k_delta_import, dim3(2048), dim3(256), 0, m->stream, m->d_syn1neg, m->d_snap + tab, d_buf + tab, scale, tab);
+    }
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    DGE_HIP(hipGetLastError());
+    return DGE_OK;
+}

@@ -1,0 +1,267 @@
+"""Thin object view of the C ABI (include/dge.h).  All compute happens in libdge.so on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+from ._native import TrainConfig, TrainStats, check, lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _dev_ptr(t):
+    """device pointer of a torch tensor (or a raw int)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+class DeviceGraph:
+    """Edge store + alias tables in HBM (replaces the LayeredGraph store, J/LayeredGraph.java:142-226)."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p(0)
+        check(lib.dge_graph_create(C.byref(h), int(device)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.dge_graph_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_stream(self, stream_ptr):
+        check(lib.dge_graph_set_stream(self._h, C.c_void_p(int(stream_ptr))))
+
+    def add_edges(self, src, dst, w):
+        src = np.ascontiguousarray(src, np.int32); dst = np.ascontiguousarray(dst, np.int32)
+        w = np.ascontiguousarray(w, np.float64)
+        if not (len(src) == len(dst) == len(w)):
+            raise ValueError("src/dst/w lengths differ")
+        check(lib.dge_graph_add_edges(self._h, _ptr(src), _ptr(dst), _ptr(w), len(src)))
+
+    def add_edges_device(self, src_t, dst_t, w_t):
+        """src/dst int32, w float64 torch tensors on this device."""
+        n = int(src_t.numel())
+        check(lib.dge_graph_add_edges_device(self._h, _dev_ptr(src_t), _dev_ptr(dst_t), _dev_ptr(w_t), n))
+
+    def set_sources(self, v, stream_sum=False):
+        v = np.ascontiguousarray(v, np.int32)
+        check(lib.dge_graph_set_sources(self._h, _ptr(v), len(v), int(bool(stream_sum))))
+
+    def keep_top_k(self, k):
+        check(lib.dge_graph_keep_top_k(self._h, int(k)))
+
+    def build_alias(self, exact=True):
+        check(lib.dge_graph_build_alias(self._h, int(bool(exact))))
+
+    @property
+    def num_vertices(self):
+        n = C.c_int32(0); check(lib.dge_graph_num_vertices(self._h, C.byref(n))); return n.value
+
+    @property
+    def num_edges(self):
+        n = C.c_int64(0); check(lib.dge_graph_num_edges(self._h, C.byref(n))); return n.value
+
+    def get_alias(self, v, tables=True):
+        k = C.c_int32(0); od = C.c_double(0)
+        check(lib.dge_graph_get_alias(self._h, int(v), None, None, None, None, 0, C.byref(k), C.byref(od)))
+        n = max(k.value, 1)
+        prob = np.zeros(n, np.float64); alias = np.zeros(n, np.int32); nbr = np.zeros(n, np.int32); wt = np.zeros(n, np.float64)
+        check(lib.dge_graph_get_alias(self._h, int(v), _ptr(prob) if tables else None, _ptr(alias) if tables else None,
+                                      _ptr(nbr), _ptr(wt), n, C.byref(k), C.byref(od)))
+        kk = k.value
+        return dict(prob=prob[:kk], alias=alias[:kk], nbr=nbr[:kk], weight=wt[:kk], out_degree=od.value)
+
+    def get_source_alias(self):
+        k = C.c_int32(0); ws = C.c_double(0)
+        check(lib.dge_graph_get_source_alias(self._h, None, None, None, 0, C.byref(k), C.byref(ws)))
+        n = max(k.value, 1)
+        prob = np.zeros(n, np.float64); alias = np.zeros(n, np.int32); src = np.zeros(n, np.int32)
+        check(lib.dge_graph_get_source_alias(self._h, _ptr(prob), _ptr(alias), _ptr(src), n, C.byref(k), C.byref(ws)))
+        kk = k.value
+        return dict(prob=prob[:kk], alias=alias[:kk], src=src[:kk], weight_sum=ws.value)
+
+    def sample_next(self, v, x):
+        nxt = C.c_int32(-1)
+        check(lib.dge_graph_sample_next(self._h, int(v), float(x), C.byref(nxt)))
+        return nxt.value
+
+    def sample_walks(self, n_walks, max_len, seed, rng_mode=1, first_index=0, return_draws=False):
+        out = np.empty((int(n_walks), int(max_len)), np.int32)
+        draws = C.c_int64(0)
+        check(lib.dge_sample_walks(self._h, int(n_walks), int(max_len), int(seed), int(rng_mode), int(first_index),
+                                   _ptr(out), C.byref(draws)))
+        return (out, draws.value) if return_draws else out
+
+    def sample_walks_device(self, n_walks, max_len, seed, rng_mode=1, first_index=0):
+        h = C.c_void_p(0); draws = C.c_int64(0)
+        check(lib.dge_sample_walks_device(self._h, int(n_walks), int(max_len), int(seed), int(rng_mode), int(first_index),
+                                          C.byref(h), C.byref(draws)))
+        return WalkCorpus(h, self.device)
+
+    def sample_walks_into(self, corpus, row0, n_walks, seed, first_index):
+        check(lib.dge_sample_walks_into(self._h, corpus._h, int(row0), int(n_walks), int(seed), int(first_index)))
+
+
+class WalkCorpus:
+    """Walk corpus int32 [n x L] in HBM (replaces the .seq text corpus between J/CrossTimeGraph.java:132-141
+    and J/DeepWalk.java:49-56)."""
+
+    def __init__(self, handle, device):
+        self._h = handle
+        self.device = device
+
+    @classmethod
+    def from_host(cls, walks, device=0):
+        walks = np.ascontiguousarray(walks, np.int32)
+        n, L = walks.shape
+        h = C.c_void_p(0)
+        check(lib.dge_walks_from_host(int(device), _ptr(walks), n, L, C.byref(h)))
+        return cls(h, int(device))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.dge_walks_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def shape(self):
+        n = C.c_int64(0); L = C.c_int32(0)
+        check(lib.dge_walks_info(self._h, C.byref(n), C.byref(L), None))
+        return n.value, L.value
+
+    def to_host(self):
+        n, L = self.shape
+        out = np.empty((n, L), np.int32)
+        check(lib.dge_walks_to_host(self._h, _ptr(out), n * L))
+        return out
+
+    def add_position_prefix(self, region_count):
+        check(lib.dge_walks_add_position_prefix(self._h, int(region_count)))
+
+    def count_tokens(self, n_vertices, d_counts, row0=0, n_rows=None):
+        """d_counts: torch int64 tensor [n_vertices] on this device (accumulated into)."""
+        if n_rows is None:
+            n_rows = self.shape[0] - row0
+        check(lib.dge_count_tokens(self._h, int(row0), int(n_rows), int(n_vertices), _dev_ptr(d_counts)))
+
+
+def make_config(dim, window, n_vertices, negative=5, min_count=2, epochs=1, workers=0, alpha=0.025, min_alpha=1e-4,
+                seed=1, table_size=100_000_000):
+    return TrainConfig(int(dim), int(window), int(negative), int(min_count), int(epochs), int(workers), float(alpha),
+                       float(min_alpha), int(seed), int(table_size), int(n_vertices), 0)
+
+
+class SgnsModel:
+    """Vocabulary + syn0/syn1neg in HBM (replaces the DL4J Word2Vec object of J/DeepWalk.java:73-82)."""
+
+    def __init__(self, handle, device, cfg):
+        self._h = handle
+        self.device = device
+        self.cfg = cfg
+
+    @classmethod
+    def create(cls, cfg, d_counts, device=0):
+        h = C.c_void_p(0)
+        check(lib.dge_model_create(int(device), C.byref(cfg), _dev_ptr(d_counts), C.byref(h)))
+        return cls(h, int(device), cfg)
+
+    @classmethod
+    def fit(cls, walks, cfg, device=0):
+        """w2v.fit() one-shot: walks is a host int32 [n x L] array or a WalkCorpus."""
+        h = C.c_void_p(0)
+        if isinstance(walks, WalkCorpus):
+            check(lib.dge_train_sgns_device(walks._h, C.byref(cfg), C.byref(h)))
+            device = walks.device
+        else:
+            walks = np.ascontiguousarray(walks, np.int32)
+            n, L = walks.shape
+            check(lib.dge_train_sgns(int(device), _ptr(walks), n, L, C.byref(cfg), C.byref(h)))
+        return cls(h, int(device), cfg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.dge_model_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_stream(self, stream_ptr):
+        check(lib.dge_model_set_stream(self._h, C.c_void_p(int(stream_ptr))))
+
+    def train(self, corpus, row0=0, n_rows=None, walk_index_base=0, epoch=0, words_before=0, words_scale=1.0, total_walks=0):
+        if n_rows is None:
+            n_rows = corpus.shape[0] - row0
+        check(lib.dge_model_train(self._h, corpus._h, int(row0), int(n_rows), int(walk_index_base), int(epoch),
+                                  int(words_before), float(words_scale), int(total_walks)))
+
+    def walk_and_train(self, graph, corpus, row0, n_rows, walk_seed, walk_index_base, epoch=0, words_before=0,
+                       words_scale=1.0, total_walks=0):
+        check(lib.dge_model_walk_and_train(self._h, graph._h, corpus._h, int(row0), int(n_rows), int(walk_seed),
+                                           int(walk_index_base), int(epoch), int(words_before), float(words_scale),
+                                           int(total_walks)))
+
+    def vectors(self):
+        p = C.c_void_p(0); ids = C.c_void_p(0); V = C.c_int64(0); D = C.c_int32(0)
+        check(lib.dge_model_vectors(self._h, C.byref(p), C.byref(ids), C.byref(V), C.byref(D)))
+        if V.value == 0:
+            return np.zeros((0, D.value), np.float32), np.zeros(0, np.int32)
+        syn0 = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(V.value * D.value,)).copy().reshape(V.value, D.value)
+        vid = np.ctypeslib.as_array(C.cast(ids, C.POINTER(C.c_int32)), shape=(V.value,)).copy()
+        return syn0, vid
+
+    def syn1neg(self):
+        syn0, _ = self.vectors()
+        p = C.c_void_p(0)
+        check(lib.dge_model_syn1neg(self._h, C.byref(p)))
+        if syn0.size == 0:
+            return np.zeros_like(syn0)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(syn0.size,)).copy().reshape(syn0.shape)
+
+    def counts(self):
+        _, vid = self.vectors()
+        p = C.c_void_p(0)
+        check(lib.dge_model_counts(self._h, C.byref(p)))
+        if len(vid) == 0:
+            return np.zeros(0, np.int64)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int64)), shape=(len(vid),)).copy()
+
+    def table(self):
+        p = C.c_void_p(0); T = C.c_int64(0)
+        check(lib.dge_model_table(self._h, C.byref(p), C.byref(T)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(T.value,)).copy()
+
+    def stats(self):
+        s = TrainStats()
+        check(lib.dge_model_stats(self._h, C.byref(s)))
+        return dict(pairs=s.pairs, words=s.words, kernel_ms=s.kernel_ms, walk_kernel_ms=s.walk_kernel_ms, launches=s.launches)
+
+    def reset_stats(self):
+        check(lib.dge_model_reset_stats(self._h))
+
+    def write_vec(self, path, names=None, header=False):
+        arr = None
+        if names is not None:
+            arr = (C.c_char_p * len(names))(*[n.encode() if n is not None else None for n in names])
+        check(lib.dge_write_vec(self._h, arr, str(path).encode(), int(bool(header))))
+
+    # --- multi-GPU exchange (include/dge.h, last section)
+    def sync_size(self):
+        n = C.c_int64(0); check(lib.dge_model_sync_size(self._h, C.byref(n))); return n.value
+
+    def snapshot(self):
+        check(lib.dge_model_snapshot(self._h))
+
+    def export_delta(self, d_buf):
+        check(lib.dge_model_export_delta(self._h, _dev_ptr(d_buf)))
+
+    def import_delta(self, d_buf, scale):
+        check(lib.dge_model_import_delta(self._h, _dev_ptr(d_buf), float(scale)))

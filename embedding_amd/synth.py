@@ -1,0 +1,55 @@
+"""Synthetic time-sliced region-flow graphs: the stand-in for the taxi flow maps the reference
+builds its cross-time graph from (J/CrossTimeGraph.java:25-52), which are not shipped.
+
+Vertex id = h*R + r ("h-regionId" in the reference's vocabulary); an edge of slice h goes
+(h, src) -> ((h+1) % T, dst) with an integer trip count as weight (J/CrossTimeGraph.java:36-39); sources are the
+layer-0 vertices (:43-47).  T == 1 gives a static graph whose vertices are all sources (cfg2).
+"""
+import numpy as np
+
+SEED = 20171106
+
+
+def flow_graph_numpy(R, T, mean_degree, seed=SEED, sigma=1.0, weight_mean=20.0, dead_end_fraction=0.0):
+    """Host generator (tests, small configs).  Returns dict(src, dst, w, sources, n_vertices)."""
+    rng = np.random.default_rng(seed)
+    V = R * T
+    mu = np.log(mean_degree) - 0.5 * sigma * sigma
+    deg = np.minimum(np.maximum(rng.lognormal(mu, sigma, V).astype(np.int64), 1), R)
+    if dead_end_fraction > 0:
+        dead = rng.random(V) < dead_end_fraction
+        dead[:R] = False                      # keep every source alive
+        deg[dead] = 0
+    E = int(deg.sum())
+    src = np.repeat(np.arange(V, dtype=np.int64), deg)
+    layer = src // R
+    dst_region = rng.integers(0, R, E)
+    dst = (((layer + 1) % T) * R + dst_region) if T > 1 else dst_region
+    w = 1.0 + np.floor(rng.exponential(weight_mean, E))
+    sources = np.arange(R, dtype=np.int32)
+    return dict(src=src.astype(np.int32), dst=dst.astype(np.int32), w=w.astype(np.float64), sources=sources,
+                n_vertices=V, R=R, T=T)
+
+
+def flow_graph_torch(R, T, mean_degree, device, seed=SEED, sigma=1.0, weight_mean=20.0):
+    """Device generator (bench configs: 5 M .. 100 M edges never touch the host).  Returns torch tensors."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    V = R * T
+    mu = float(np.log(mean_degree) - 0.5 * sigma * sigma)
+    z = torch.randn(V, generator=g, device=device, dtype=torch.float32)
+    deg = torch.exp(mu + sigma * z).to(torch.int64).clamp_(1, R)
+    E = int(deg.sum().item())
+    src = torch.repeat_interleave(torch.arange(V, device=device, dtype=torch.int32), deg)
+    dst_region = torch.randint(0, R, (E,), generator=g, device=device, dtype=torch.int32)
+    if T > 1:
+        layer = torch.div(src, R, rounding_mode="floor")
+        dst = ((layer + 1) % T) * R + dst_region
+    else:
+        dst = dst_region
+    u = torch.rand(E, generator=g, device=device, dtype=torch.float64).clamp_(min=1e-12)
+    w = 1.0 + torch.floor(-weight_mean * torch.log(u))
+    sources = np.arange(R, dtype=np.int32)
+    return dict(src=src.contiguous(), dst=dst.to(torch.int32).contiguous(), w=w.contiguous(), sources=sources,
+                n_vertices=V, n_edges=E, R=R, T=T)

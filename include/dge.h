@@ -1,0 +1,191 @@
+/*
+ * dge.h — C ABI of libdge.so: the MI355X-native random-walk + SGNS engine.
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json:north_star.  The reference
+ * (thekingofkings/embedding) is plain Java with no FFI; the seam is introduced UNDER its public
+ * classes.  Each entry point cites the reference interface it replaces, with
+ * J/ = embedding/src/main/java/embedding/.  The JNI / ctypes bindings a maintainer adds on the
+ * reference side are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", opaque handles, plain pointers and sizes; every function returns a status
+ *     (DGE_OK == 0).  dge_last_error() returns a thread-local message for the last failure.
+ *   - No CPU compute path exists in this library: every call needs a visible gfx950 device and fails
+ *     with DGE_ERR_DEVICE otherwise.
+ *   - Vertex ids are the caller's insertion ordinals (J/LayeredGraph.java:160,166): name <-> id
+ *     interning ("h-regionId" strings) stays on the host-language side.
+ *   - "host" pointers are ordinary process memory; "d_" pointers are device memory on the handle's
+ *     device (e.g. a torch tensor's data_ptr()).
+ *   - Handles are not thread-safe; the reference's walk API is single-threaded
+ *     (J/CrossTimeGraph.java:134-140) and the trainer owns its workers (J/DeepWalk.java:75).
+ */
+#ifndef DGE_H
+#define DGE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGE_VERSION 100
+
+enum {
+    DGE_OK = 0,
+    DGE_ERR_ARG = 1,      /* null / negative / inconsistent argument */
+    DGE_ERR_RANGE = 2,    /* vertex id outside the graph */
+    DGE_ERR_TOPK = 3,     /* keep_top_k: a vertex has fewer than k edges (Java: IndexOutOfBoundsException) */
+    DGE_ERR_CAP = 4,      /* caller buffer too small */
+    DGE_ERR_STATE = 5,    /* call order violated (e.g. walks before alias tables) */
+    DGE_ERR_DEVICE = 6,   /* no usable gfx950 device / HIP failure */
+    DGE_ERR_IO = 7
+};
+
+typedef struct dge_graph dge_graph;   /* per-timeslice edge store + alias tables, resident in HBM   */
+typedef struct dge_walks dge_walks;   /* walk corpus int32 [n_walks x max_len], pad -1, resident in HBM */
+typedef struct dge_model dge_model;   /* vocabulary + syn0/syn1neg tables, resident in HBM           */
+
+const char* dge_last_error(void);
+int  dge_version(void);
+int  dge_device_count(int* n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Edge store — replaces LayeredGraph's HashMap/ArrayList store (J/LayeredGraph.java:142-148).
+ * ---------------------------------------------------------------------------------------------- */
+/* new LayeredGraph()  J/LayeredGraph.java:150-155.  device >= 0 (no CPU path). */
+int  dge_graph_create(dge_graph** out, int device);
+void dge_graph_free(dge_graph* g);
+/* run this handle's work on an existing hipStream_t (default: a stream the handle owns) */
+int  dge_graph_set_stream(dge_graph* g, void* hip_stream);
+/* bulk addEdge(fn, tn, weight)  J/LayeredGraph.java:157-174.  Appends in call order; duplicates are
+ * kept; per-vertex edge order = insertion order; outDegree = running sum (J/LayeredGraph.java:46-49). */
+int  dge_graph_add_edges(dge_graph* g, const int32_t* src, const int32_t* dst, const double* w, int64_t n);
+/* same, COO already in device memory (synthetic generators, device-side OD ingest) */
+int  dge_graph_add_edges_device(dge_graph* g, const int32_t* d_src, const int32_t* d_dst, const double* d_w, int64_t n);
+/* bulk addSourceVertex(vn)  J/LayeredGraph.java:180-189 (after all edges).  stream_sum = 0: sourceWeightSum
+ * is the running += of addSourceVertex; 1: DoubleStream.sum() as in J/SpatialGraph.java:56-57,82-83. */
+int  dge_graph_set_sources(dge_graph* g, const int32_t* v, int64_t n, int stream_sum);
+/* SpatialGraph.keepNearestKVertices(k)  J/SpatialGraph.java:29-35: stable sort by weight descending,
+ * keep the first k, outDegree recomputed.  DGE_ERR_TOPK if some vertex has fewer than k edges. */
+int  dge_graph_keep_top_k(dge_graph* g, int32_t k);
+/* initiateAliasTables()  J/LayeredGraph.java:195-226 (+ Vertex.initiateAliasTable :54-82).
+ * exact_reference_order = 1: the reference's own pairing order (bit-identical prob/alias arrays);
+ * 0: Vose O(k) pairing — same sampling distribution, different alias indices (scalable form). */
+int  dge_graph_build_alias(dge_graph* g, int exact_reference_order);
+int  dge_graph_num_vertices(const dge_graph* g, int32_t* n);
+int  dge_graph_num_edges(const dge_graph* g, int64_t* n);
+/* Vertex.{probTable,aliasTable,edgesOut,outDegree} read-back for one vertex (J/LayeredGraph.java:31-37);
+ * any output pointer may be null.  *k receives the degree even when cap is too small (DGE_ERR_CAP). */
+int  dge_graph_get_alias(const dge_graph* g, int32_t v, double* prob, int32_t* alias, int32_t* nbr,
+                         double* weight, int32_t cap, int32_t* k, double* out_degree);
+/* LayeredGraph.{probTable,aliasTable,sourceVertices,sourceWeightSum}  J/LayeredGraph.java:145-148 */
+int  dge_graph_get_source_alias(const dge_graph* g, double* prob, int32_t* alias, int32_t* src,
+                                int32_t cap, int32_t* k, double* weight_sum);
+/* Vertex.sampleNextVertex(double x)  J/LayeredGraph.java:123-132 (test overload); *next = -1 when the
+ * vertex has no out-edges.  Runs the device sampler for one explicit x. */
+int  dge_graph_sample_next(const dge_graph* g, int32_t v, double x, int32_t* next);
+
+/* ------------------------------------------------------------------------------------------------
+ * Walk sampler — replaces sampleVertexSequence() J/LayeredGraph.java:232-252 and the writer loops
+ * J/CrossTimeGraph.java:134-140, J/SpatialGraph.java:103-113.
+ *   rng_mode 0 ("java-sequential"): one java.util.Random(seed) stream consumed walk after walk, one
+ *            nextDouble() per decision — what the reference produces after
+ *            `LayeredGraph.rnd = new Random(seed)`.  first_index = draws already consumed.
+ *   rng_mode 1 ("strided"): walk i owns draws [i*max_len, (i+1)*max_len) of that same stream.
+ *            first_index = global index of the first walk (shards / batches).
+ *            Both modes give identical walks on graphs where no walk dead-ends.
+ * A dead end yields a shorter walk (pad -1), never an error (J/LayeredGraph.java:247-248).
+ * ---------------------------------------------------------------------------------------------- */
+int  dge_sample_walks(const dge_graph* g, int64_t n_walks, int32_t max_len, int64_t seed, int rng_mode,
+                      int64_t first_index, int32_t* out /* host [n_walks*max_len] */, int64_t* draws_consumed);
+int  dge_sample_walks_device(const dge_graph* g, int64_t n_walks, int32_t max_len, int64_t seed, int rng_mode,
+                             int64_t first_index, dge_walks** out, int64_t* draws_consumed);
+/* re-sample into an existing corpus: rows [row0, row0+n_walks) (strided mode only) */
+int  dge_sample_walks_into(const dge_graph* g, dge_walks* w, int64_t row0, int64_t n_walks, int64_t seed,
+                           int64_t first_index);
+int  dge_walks_from_host(int device, const int32_t* walks, int64_t n_walks, int32_t max_len, dge_walks** out);
+int  dge_walks_to_host(const dge_walks* w, int32_t* out, int64_t cap_elems);
+int  dge_walks_info(const dge_walks* w, int64_t* n_walks, int32_t* max_len, const int32_t** d_ptr);
+/* SpatialGraph's position prefix "j-name" (J/SpatialGraph.java:105-108): token j of each walk becomes
+ * j*region_count + id, i.e. lands in layer j of the cross-time id space. */
+int  dge_walks_add_position_prefix(dge_walks* w, int32_t region_count);
+void dge_walks_free(dge_walks* w);
+
+/* ------------------------------------------------------------------------------------------------
+ * SGNS trainer — replaces new Word2Vec.Builder()...build(); w2v.fit()  J/DeepWalk.java:73-79
+ * (DL4J-NLP 0.7.2 SkipGram + ND4J AggregateSkipGram; behaviour restated).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dge_train_config {
+    int32_t dim;             /* .layerSize(n)          J/DeepWalk.java:62-66,74 */
+    int32_t window;          /* .windowSize(n)         J/DeepWalk.java:74 (= LayeredGraph.numLayer) */
+    int32_t negative;        /* .negativeSample(5)     J/DeepWalk.java:75 */
+    int32_t min_count;       /* .minWordFrequency(2)   J/DeepWalk.java:73 */
+    int32_t epochs;          /* .iterations(1) x epochs(1)  J/DeepWalk.java:74 */
+    int32_t workers;         /* .workers(8) J/DeepWalk.java:75.  1 = one in-order worker (deterministic);
+                                0 = fill the device (Hogwild); n>1 = exactly n concurrent walk workers */
+    float   alpha;           /* DL4J default learningRate 0.025 */
+    float   min_alpha;       /* DL4J default minLearningRate 1e-4 */
+    uint64_t seed;
+    int64_t table_size;      /* unigram^0.75 table length; 0 -> 100000000 (word2vec.c) */
+    int32_t n_vertices;      /* vertex-id space of the corpus */
+    int32_t reserved;
+} dge_train_config;
+
+typedef struct dge_train_stats {
+    int64_t pairs;           /* (center, context) pairs trained = "edges" of BASELINE.json's metric */
+    int64_t words;           /* in-vocabulary tokens consumed */
+    double  kernel_ms;       /* HIP-event time of the SGNS kernel launches, summed */
+    double  walk_kernel_ms;  /* HIP-event time of the walk kernel launches issued through this model */
+    int64_t launches;        /* SGNS kernel launches */
+} dge_train_stats;
+
+/* vocabulary pass (DL4J VocabConstructor.buildJointVocabulary): d_counts[v] += occurrences of v.
+ * d_counts is device int64[n_vertices]; the caller may all-reduce it across ranks before
+ * dge_model_create. */
+int  dge_count_tokens(const dge_walks* w, int64_t row0, int64_t n_rows, int32_t n_vertices, int64_t* d_counts);
+/* build vocabulary (count >= min_count, ordered by count desc, id asc), unigram table, sigmoid LUT and
+ * initial weights (InMemoryLookupTable.resetWeights) */
+int  dge_model_create(int device, const dge_train_config* cfg, const int64_t* d_counts, dge_model** out);
+int  dge_model_set_stream(dge_model* m, void* hip_stream);
+/* one pass of the trainer over corpus rows [row0, row0+n_rows).
+ *   walk_index_base : global index of row0 within the epoch (RNG streams are keyed on it)
+ *   epoch           : 0-based epoch number
+ *   words_before    : in-vocab tokens trained before row0 in this epoch (learning-rate schedule)
+ *   words_scale     : 1.0, or the number of ranks when ranks advance through the epoch in parallel */
+int  dge_model_train(dge_model* m, const dge_walks* w, int64_t row0, int64_t n_rows, int64_t walk_index_base,
+                     int32_t epoch, int64_t words_before, double words_scale, int64_t total_walks_per_epoch);
+/* one-shot forms of w2v.fit(): vocabulary + all epochs */
+int  dge_train_sgns(int device, const int32_t* walks /* host */, int64_t n_walks, int32_t max_len,
+                    const dge_train_config* cfg, dge_model** out);
+int  dge_train_sgns_device(const dge_walks* w, const dge_train_config* cfg, dge_model** out);
+/* fused step used by bench.py: sample rows [row0,row0+n) of the corpus again from the graph (strided RNG)
+ * and train on them, without leaving the device */
+int  dge_model_walk_and_train(dge_model* m, const dge_graph* g, dge_walks* w, int64_t row0, int64_t n_rows,
+                              int64_t walk_seed, int64_t walk_index_base, int32_t epoch, int64_t words_before,
+                              double words_scale, int64_t total_walks_per_epoch);
+/* results (w2v.lookupTable): host copies [V x dim], borrowed until the next call on m / dge_model_free */
+int  dge_model_vectors(dge_model* m, const float** syn0, const int32_t** vocab_ids, int64_t* V, int32_t* dim);
+int  dge_model_syn1neg(dge_model* m, const float** syn1neg);
+int  dge_model_counts(dge_model* m, const int64_t** counts);
+int  dge_model_table(dge_model* m, const int32_t** table, int64_t* table_size);
+int  dge_model_stats(const dge_model* m, dge_train_stats* out);
+int  dge_model_reset_stats(dge_model* m);
+/* WordVectorSerializer.writeWordVectors(w2v, path)  J/DeepWalk.java:82: "name v1 .. vD\n" per vocabulary
+ * row, no header (header != 0 writes the LINE-style "V D" first line of miscs/taxi_all.txt:1).
+ * names[v] is the string of vertex id v; null -> the decimal id. */
+int  dge_write_vec(dge_model* m, const char* const* names, const char* path, int header);
+void dge_model_free(dge_model* m);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU exchange at epoch boundaries (new; the reference is single-host).  Each rank trains its
+ * walk shard from a common snapshot; delta = current - snapshot is summed across ranks (RCCL
+ * all-reduce on the caller's communicator, e.g. torch.distributed) and applied with a scale.
+ * ---------------------------------------------------------------------------------------------- */
+int  dge_model_sync_size(const dge_model* m, int64_t* n_floats);          /* 2 * V * row_stride */
+int  dge_model_snapshot(dge_model* m);                                     /* snapshot = current (start of a shard) */
+int  dge_model_export_delta(dge_model* m, float* d_buf);                  /* d_buf = current - snapshot */
+int  dge_model_import_delta(dge_model* m, const float* d_buf, float scale); /* current = snapshot + scale*d_buf; re-snapshot */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,46 @@
+"""Shared builders for the parity tests: the same seeded inputs go to the oracle and to libdge."""
+import numpy as np
+
+
+def layered_graph(R=40, T=4, deg=6, seed=0, shuffle=True, duplicates=True, dead_ends=0.0):
+    """Small cross-time graph in INSERTION order that is not sorted by source (as J/CrossTimeGraph.java:33-41
+    would produce it, then shuffled) with duplicate (src,dst) pairs kept (J/LayeredGraph.java:157-174)."""
+    rng = np.random.default_rng(seed)
+    src, dst, w = [], [], []
+    for h in range(T):
+        for s in range(R):
+            if dead_ends > 0 and h > 0 and rng.random() < dead_ends:
+                continue
+            k = int(rng.integers(1, deg + 1))
+            for d in rng.integers(0, R, k):
+                src.append(h * R + s); dst.append(((h + 1) % T) * R + int(d)); w.append(float(rng.integers(1, 60)))
+            if duplicates and rng.random() < 0.3:
+                src.append(h * R + s); dst.append(dst[-1]); w.append(float(rng.integers(1, 60)))
+    src = np.array(src, np.int32); dst = np.array(dst, np.int32); w = np.array(w, np.float64)
+    if shuffle:
+        p = rng.permutation(len(src))
+        src, dst, w = src[p], dst[p], w[p]
+    present = np.zeros(R * T, bool); present[src] = True; present[dst] = True
+    sources = np.array([v for v in range(R) if present[v]], np.int32)
+    return src, dst, w, sources
+
+
+def build_both(O, E, src, dst, w, sources, exact=True, stream_sum=False, top_k=None):
+    og = O.Graph(); og.add_edges(src, dst, w)
+    dg = E.DeviceGraph(0); dg.add_edges(src, dst, w)
+    if top_k is not None:
+        og.keep_top_k(top_k); dg.keep_top_k(top_k)
+    og.set_sources(sources, stream_sum); dg.set_sources(sources, stream_sum)
+    og.build_alias(exact); dg.build_alias(exact)
+    return og, dg
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.int64 if a.dtype == np.float64 else np.int32)
+
+
+def cosine_rows(a, b):
+    num = (a.astype(np.float64) * b.astype(np.float64)).sum(1)
+    den = np.linalg.norm(a.astype(np.float64), axis=1) * np.linalg.norm(b.astype(np.float64), axis=1)
+    return num / np.maximum(den, 1e-300)
