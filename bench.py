@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — SGNS training edges/sec on the synthetic time-sliced flow graph (BASELINE.json metric).
+
+One process per GPU.  A "step" is one pass of the hot path over one batch of walks: the walk kernel re-samples the
+batch from the alias tables in HBM, the batch is remapped to vocabulary rows, and the SGNS kernel trains every
+(centre, context) pair of it with 1 positive + K negative updates.  Everything the step reads is resident in HBM
+before the timed region starts.  With N > 1 ranks every rank trains its own walk shard (no data-path collective)
+and the embedding deltas are all-reduced over RCCL after each step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[2]/[3]: R*T = 1 000 008 layered vertices, ~100 M edges, 24 hourly slices, D=128, K=5
+    "cfg3": dict(R=41667, T=24, mean_degree=100, dim=128, negative=5, L=24, walks_per_vertex=10,
+                 name="synthetic 1M-node / 100M-edge flow graph, 24 timeslices, dim=128, K=5, L=W=24"),
+    # BASELINE.json configs[1]: 100k-node / 5M-edge static graph, D=64, K=5
+    "cfg2": dict(R=100000, T=1, mean_degree=50, dim=64, negative=5, L=8, walks_per_vertex=10,
+                 name="synthetic 100k-node / 5M-edge static flow graph, dim=64, K=5, L=W=8"),
+    # small smoke-sized workload for quick checks
+    "tiny": dict(R=2000, T=8, mean_degree=20, dim=128, negative=5, L=8, walks_per_vertex=10,
+                 name="tiny 16k-node graph (debug)"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch-walks", type=int, default=0, help="walks per step per GPU (default: epoch/10)")
+    ap.add_argument("--workers", type=int, default=0, help="SGNS walk workers (0 = fill the device)")
+    ap.add_argument("--policy", type=int, default=0, help="dge_train_config.update_policy (0 auto = float atomics)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    N = world
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if N > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device(dev))
+
+    import embedding_amd as E
+    from embedding_amd import synth
+
+    wl = WORKLOADS[args.workload]
+    R, T, L, D, K = wl["R"], wl["T"], wl["L"], wl["dim"], wl["negative"]
+    NV = R * T
+    t0 = time.time()
+
+    # ---- setup (untimed): replicate the edge store on every GPU, build alias tables
+    G = synth.flow_graph_torch(R, T, wl["mean_degree"], dev)
+    g = E.DeviceGraph(local_rank)
+    g.add_edges_device(G["src"], G["dst"], G["w"])
+    n_edges = G["n_edges"]
+    sources = G["sources"] if T > 1 else np.arange(R, dtype=np.int32)
+    del G
+    torch.cuda.empty_cache()
+    g.set_sources(sources)
+    g.build_alias(exact=False)       # Vose pairing: same distribution as the reference order, O(k) for hubs
+
+    # ---- setup: this rank's shard of the epoch corpus, global vocabulary
+    epoch_walks = wl["walks_per_vertex"] * NV
+    shard = epoch_walks // N
+    shard0 = rank * shard
+    WALK_SEED = 20171106
+    corpus = g.sample_walks_device(shard, L, seed=WALK_SEED, rng_mode=1, first_index=shard0)
+    counts = torch.zeros(NV, dtype=torch.int64, device=dev)
+    corpus.count_tokens(NV, counts)
+    if N > 1:
+        dist.all_reduce(counts)
+    # epochs only sets the learning-rate horizon (alpha decays over epochs*total_words); the bench steps stay near alpha0
+    cfg = E.make_config(D, L, NV, negative=K, min_count=2, epochs=1000, workers=args.workers, seed=1, update_policy=args.policy)
+    model = E.SgnsModel.create(cfg, counts, local_rank)
+    total_words = int(counts.sum().item())
+    B = args.batch_walks or max(1, epoch_walks // 10)
+    B = min(B, shard)
+    delta = None
+    if N > 1:
+        delta = torch.empty(model.sync_size(), dtype=torch.float32, device=dev)
+        model.snapshot()
+    setup_s = time.time() - t0
+
+    def step(i):
+        row0 = (i * B) % max(shard - B + 1, 1)
+        model.walk_and_train(g, corpus, row0, B, walk_seed=WALK_SEED, walk_index_base=shard0 + row0, epoch=0,
+                             words_before=0, words_scale=float(N), total_walks=epoch_walks)
+        if N > 1:
+            model.export_delta(delta)
+            dist.all_reduce(delta)
+            model.import_delta(delta, 1.0 / N)
+
+    def sync():
+        model.stats()                 # drains the library's stream
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    model.reset_stats()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t1
+    st = model.stats()
+
+    pairs = torch.tensor([float(st["pairs"])], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if N > 1:
+        dist.all_reduce(pairs)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_pairs = float(pairs.item())
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        value = total_pairs / elapsed
+        bytes_per_pair = 8 * D * (K + 2)                      # one syn0 row + K+1 syn1neg rows, read+written
+        launches = max(st["launches"], 1)
+        ms_per_launch = st["kernel_ms"] / launches
+        pairs_per_launch = st["pairs"] / launches
+        achieved = pairs_per_launch * bytes_per_pair / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        out = {
+            "metric": "SGNS training edges/sec",
+            "value": value,
+            "unit": "edges/s",
+            "n_gpus": N,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "vertices": NV, "edges": int(n_edges), "timeslices": T, "dim": D,
+                       "negatives": K, "walk_len": L, "window": L, "walks_per_step_per_gpu": B,
+                       "pairs_per_step_per_gpu": st["pairs"] / args.steps, "vocabulary": int((counts >= 2).sum().item()),
+                       "sgns_workers": args.workers, "update_policy": args.policy, "parallelism": "walk-shard x%d, RCCL all-reduce of deltas per step" % N if N > 1 else "1 GPU",
+                       "setup_s": round(setup_s, 1)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "kernel": "k_sgns_train", "ms_per_launch": ms_per_launch,
+                         "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
+                         "walk_kernel_ms_per_launch": st["walk_kernel_ms"] / launches},
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            sample = g.sample_walks(min(shard, 400_000), L, seed=WALK_SEED, rng_mode=1, first_index=shard0)   # = first rows of the corpus
+            out["cpu_baseline"] = cpu_baseline(sample, NV, D, L, K, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(walks, NV, D, L, K, seconds):
+    """The CPU restatement (oracle, 'port') timed with Hogwild threads on this box's host cores, on a bounded sample
+    of the same walks.  A reported baseline, not the target; not the Java reference (no JDK here)."""
+    from oracle import oracle as O
+    O.build()
+    cores = len(os.sched_getaffinity(0))
+    probe = walks[:20_000]
+    m = O.train_sgns(probe, NV, D, L, negative=K, threads=cores, table_size=10_000_000)
+    rate = m.pairs / max(m.seconds, 1e-9)
+    n = int(min(len(walks), max(20_000, seconds * rate / (m.pairs / len(probe)))))
+    m = O.train_sgns(walks[:n], NV, D, L, negative=K, threads=cores, table_size=10_000_000)
+    return {"value": m.pairs / max(m.seconds, 1e-9), "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": "%d walks (%d pairs) of the same corpus, oracle/dge_oracle.c Hogwild with %d OpenMP threads, %.1f s"
+                      % (n, m.pairs, cores, m.seconds)}
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,7 @@ class TrainConfig(C.Structure):
     _fields_ = [
         ("dim", C.c_int32), ("window", C.c_int32), ("negative", C.c_int32), ("min_count", C.c_int32),
         ("epochs", C.c_int32), ("workers", C.c_int32), ("alpha", C.c_float), ("min_alpha", C.c_float),
-        ("seed", C.c_uint64), ("table_size", C.c_int64), ("n_vertices", C.c_int32), ("reserved", C.c_int32),
+        ("seed", C.c_uint64), ("table_size", C.c_int64), ("n_vertices", C.c_int32), ("update_policy", C.c_int32),
     ]
 
 
@@ -78,11 +78,31 @@ SIGNATURES = {
 }
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel ships its own libamdhip64.so (SONAME libamdhip64.so.7,
+    loaded by file name), libdge.so needs libamdhip64.so.7: if both copies get loaded, the second one finds no
+    device.  When torch is installed, load ITS runtime first so libdge.so binds to it by SONAME; torch tensors
+    (torch.distributed / RCCL plumbing) and libdge then share streams and memory."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        p = os.path.join(libdir, name)
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "embedding_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (rt, at) in SIGNATURES.items():
         f = getattr(lib, name)      # AttributeError if the library does not export a declared symbol

@@ -6,7 +6,7 @@
 // (SURVEY.md §3.3, row a9).
 //
 // HBM layout: syn0, syn1neg  float32 [V x stride], stride = round_up(dim, 64) floats (zero padded) so that a row
-// is 1..4 chunks of 256 B and a 16-lane group moves one chunk with one dwordx4 per lane.
+// is 1..8 chunks of 256 B; a 16-lane group moves a chunk as four 64-B segments (lane j owns elements 64c+16m+j).
 // Work decomposition: one 16-lane group ("worker") per walk; 4 workers per wave.  A worker owns D/16 floats of
 // every row it touches in registers, dot products are 16-lane xor-butterflies (DPP-sized), and the K negative
 // rows of a pair are in flight together.  Updates are plain stores (Hogwild, like the reference's 8 DL4J
@@ -148,6 +148,21 @@ struct TrainParams {
 };
 
 template <int DCH> struct Row { float4 v[DCH]; };
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+// Cache policy of the table traffic.  The eight XCDs have private L2s that are not coherent with each other, and a
+// plain store parks its line dirty in the writer's L2: with plain loads/stores every XCD would train its own stale
+// copy of a row and the last write-back would win (measured: >90 % of the updates lost on a 10 MB table).  So the
+// Hogwild schedules move rows with agent-scope (sc1) loads and either write-through (sc1) stores or memory-side
+// float atomics; the in-order schedule (one worker, one CU) keeps plain accesses.
+//   POL 0  plain loads / plain stores            (workers == 1: bit-exact with the oracle)
+//   POL 1  sc1 loads / sc1 write-through stores  (Hogwild, row granularity: last writer of a row wins)
+//   POL 2  sc1 loads / float atomic adds         (Hogwild, element granularity: no update is lost)
+template <int POL> struct Policy {
+    static constexpr int LOAD_AUX = POL == 0 ? 0 : 16;    // aux bit 4 = sc1 on gfx950
+    static constexpr int STORE_AUX = POL == 0 ? 0 : 16;
+    static constexpr bool ATOMIC = POL == 2;
+};
 
 __device__ __forceinline__ float group16_sum(float p) {
     p += __shfl_xor(p, 1);
@@ -157,17 +172,56 @@ __device__ __forceinline__ float group16_sum(float p) {
     return p;
 }
 
-template <int DCH>
-__device__ __forceinline__ void row_load(Row<DCH>& r, const float* base, int64_t row, int stride, int lane) {
-    const float4* p = reinterpret_cast<const float4*>(base + row * stride) + lane;
-#pragma unroll
-    for (int c = 0; c < DCH; c++) r.v[c] = p[c * 16];
+// one table seen through a buffer descriptor: byte offset of (row, lane) = row*stride*4 + lane*16 (< 4 GiB)
+struct TableView {
+    __amdgpu_buffer_rsrc_t rsrc;
+    float* base;
+    uint32_t row_bytes;
+};
+__device__ __forceinline__ TableView make_view(float* base, int64_t rows, int stride) {
+    TableView t;
+    t.base = base;
+    t.row_bytes = (uint32_t)stride * 4u;
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(uint32_t)(rows * stride * 4), 0x00020000);
+    return t;
 }
-template <int DCH>
-__device__ __forceinline__ void row_store(const Row<DCH>& r, float* base, int64_t row, int stride, int lane) {
-    float4* p = reinterpret_cast<float4*>(base + row * stride) + lane;
+
+// Lane j of a 16-lane group owns elements {64c + 16m + j : m = 0..3} of chunk c (kept as v[c].{x,y,z,w}): every
+// memory instruction of a group then touches 64 CONTIGUOUS bytes of the row, which is the shape the memory-side
+// float atomics want (one 64-B request per group instead of four) and costs the loads nothing (HBM-bound).
+template <int DCH, int AUX>
+__device__ __forceinline__ void row_load(Row<DCH>& r, const TableView& t, int32_t row, int lane) {
+    const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 4u;
 #pragma unroll
-    for (int c = 0; c < DCH; c++) p[c * 16] = r.v[c];
+    for (int c = 0; c < DCH; c++) {
+        r.v[c].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, (int)(off + c * 256u), 0, AUX));
+        r.v[c].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, (int)(off + c * 256u + 64u), 0, AUX));
+        r.v[c].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, (int)(off + c * 256u + 128u), 0, AUX));
+        r.v[c].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, (int)(off + c * 256u + 192u), 0, AUX));
+    }
+}
+template <int DCH, int AUX>
+__device__ __forceinline__ void row_store(const Row<DCH>& r, const TableView& t, int32_t row, int lane) {
+    const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 4u;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].x), t.rsrc, (int)(off + c * 256u), 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].y), t.rsrc, (int)(off + c * 256u + 64u), 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].z), t.rsrc, (int)(off + c * 256u + 128u), 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].w), t.rsrc, (int)(off + c * 256u + 192u), 0, AUX);
+    }
+}
+// row += g * x, element-wise float atomics at the memory side (64 contiguous bytes per group and instruction)
+template <int DCH>
+__device__ __forceinline__ void row_atomic_axpy(const TableView& t, int32_t row, int lane, float g, const Row<DCH>& x) {
+    float* p = t.base + (size_t)row * (t.row_bytes / 4) + lane;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        atomicAdd(p + c * 64 + 0, g * x.v[c].x);
+        atomicAdd(p + c * 64 + 16, g * x.v[c].y);
+        atomicAdd(p + c * 64 + 32, g * x.v[c].z);
+        atomicAdd(p + c * 64 + 48, g * x.v[c].w);
+    }
 }
 template <int DCH>
 __device__ __forceinline__ float row_dot(const Row<DCH>& a, const Row<DCH>& b) {
@@ -192,6 +246,11 @@ __device__ __forceinline__ void row_axpy(Row<DCH>& y, float g, const Row<DCH>& x
         y.v[c].w = fmaf(g, x.v[c].w, y.v[c].w);
     }
 }
+template <int DCH>
+__device__ __forceinline__ void row_zero(Row<DCH>& y) {
+#pragma unroll
+    for (int c = 0; c < DCH; c++) y.v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
 
 __device__ __forceinline__ float sgns_g(float f, float label, float alpha, const float* s_exp) {
     if (f > (float)MAX_EXP) return (label - 1.0f) * alpha;
@@ -209,21 +268,22 @@ __device__ __forceinline__ uint64_t shfl16_u64(uint64_t v, int src) {
 }
 
 // one (target row, label 0) update against l1; sequential form used when a pair drew the same row twice
-template <int DCH>
-__device__ __forceinline__ void neg_update_serial(const Row<DCH>& l1, Row<DCH>& neu, float* syn1neg, int32_t tg, int stride,
+template <int DCH, int POL>
+__device__ __forceinline__ void neg_update_serial(const Row<DCH>& l1, Row<DCH>& neu, const TableView& syn1neg, int32_t tg,
                                                   int lane, float alpha, const float* s_exp) {
     Row<DCH> r;
-    row_load(r, syn1neg, tg, stride, lane);
+    row_load<DCH, Policy<POL>::LOAD_AUX>(r, syn1neg, tg, lane);
     float f = row_dot(l1, r);
     float g = sgns_g(f, 0.0f, alpha, s_exp);
     row_axpy(neu, g, r);
     row_axpy(r, g, l1);
-    row_store(r, syn1neg, tg, stride, lane);
+    row_store<DCH, Policy<POL>::STORE_AUX>(r, syn1neg, tg, lane);
 }
 
-template <int DCH>
+template <int DCH, int POL>
 __global__ void __launch_bounds__(256)
 k_sgns_train(TrainParams p) {
+    using P = Policy<POL>;
     __shared__ float s_exp[EXP_TABLE_SIZE];
     for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
     __syncthreads();
@@ -232,11 +292,14 @@ k_sgns_train(TrainParams p) {
     const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (worker >= p.n_workers) return;
 
+    const TableView syn0 = make_view(p.syn0, p.V, p.stride);
+    const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride);
+
     // lane j turns the pair's LCG state s into the state after j+1 draws: s*mA + cA
     uint64_t mA = 1, cA = 0;
     for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
 
-    const int L = p.L, W = p.W, K = p.K, stride = p.stride;
+    const int L = p.L, W = p.W, K = p.K;
     unsigned long long my_pairs = 0, my_words = 0;
 
     for (int64_t w = worker; w < p.n_rows; w += p.n_workers) {
@@ -256,8 +319,9 @@ k_sgns_train(TrainParams p) {
             uint64_t s = dge_mix64(p.seed + (uint64_t)(gbase + i));
             s = s * DGE_W2V_MULT + 11;
             const int b = (int)(s % (uint64_t)W);
-            Row<DCH> h;                                   // syn1neg[word]: positive target of every pair of this centre
-            row_load(h, p.syn1neg, word, stride, lane);
+            Row<DCH> h, dh;                               // syn1neg[word]: positive target of every pair of this centre
+            row_load<DCH, P::LOAD_AUX>(h, syn1neg, word, lane);
+            if (P::ATOMIC) row_zero(dh);
             bool h_dirty = false;
             for (int a = b; a < W * 2 + 1 - b; a++) {
                 if (a == W) continue;
@@ -265,14 +329,14 @@ k_sgns_train(TrainParams p) {
                 if (c < 0 || c >= len) continue;
                 const int32_t last = sen[c];
                 Row<DCH> l1, neu;
-                row_load(l1, p.syn0, last, stride, lane);
-#pragma unroll
-                for (int q = 0; q < DCH; q++) neu.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                row_load<DCH, P::LOAD_AUX>(l1, syn0, last, lane);
+                row_zero(neu);
                 {   // d == 0: target = word, label 1
                     float f = row_dot(l1, h);
                     float g = sgns_g(f, 1.0f, alpha, s_exp);
                     row_axpy(neu, g, h);
                     row_axpy(h, g, l1);
+                    if (P::ATOMIC) row_axpy(dh, g, l1);
                     h_dirty = true;
                 }
                 for (int kd = 0; kd < K; kd += 16) {
@@ -294,39 +358,53 @@ k_sgns_train(TrainParams p) {
                             int32_t v = __shfl(t, (base + q) & 15, 16);
                             tg[q] = (base + q < kc) ? v : -1;
                         }
+                        if (!P::ATOMIC) {
 #pragma unroll
-                        for (int q = 1; q < NEG_BATCH; q++)
+                            for (int q = 1; q < NEG_BATCH; q++)
 #pragma unroll
-                            for (int r = 0; r < q; r++) dup |= (tg[q] >= 0 && tg[q] == tg[r]);
+                                for (int r = 0; r < q; r++) dup |= (tg[q] >= 0 && tg[q] == tg[r]);
+                        }
                         if (!dup) {
+                            // all rows of the batch in flight together: loads are unconditional (a skipped slot
+                            // reads the centre's own row, always valid), only the arithmetic and the store are guarded
                             Row<DCH> rr[NEG_BATCH];
 #pragma unroll
-                            for (int q = 0; q < NEG_BATCH; q++)
-                                if (tg[q] >= 0) row_load(rr[q], p.syn1neg, tg[q], stride, lane);
+                            for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX>(rr[q], syn1neg, tg[q] >= 0 ? tg[q] : word, lane);
 #pragma unroll
                             for (int q = 0; q < NEG_BATCH; q++)
                                 if (tg[q] >= 0) {
                                     float f = row_dot(l1, rr[q]);
                                     float g = sgns_g(f, 0.0f, alpha, s_exp);
                                     row_axpy(neu, g, rr[q]);
-                                    row_axpy(rr[q], g, l1);
-                                    row_store(rr[q], p.syn1neg, tg[q], stride, lane);
+                                    if (P::ATOMIC) {
+                                        row_atomic_axpy(syn1neg, tg[q], lane, g, l1);
+                                    } else {
+                                        row_axpy(rr[q], g, l1);
+                                        row_store<DCH, P::STORE_AUX>(rr[q], syn1neg, tg[q], lane);
+                                    }
                                 }
                         } else {
 #pragma unroll 1
                             for (int q = 0; q < NEG_BATCH; q++)
-                                if (tg[q] >= 0) neg_update_serial<DCH>(l1, neu, p.syn1neg, tg[q], stride, lane, alpha, s_exp);
+                                if (tg[q] >= 0) neg_update_serial<DCH, POL>(l1, neu, syn1neg, tg[q], lane, alpha, s_exp);
                         }
                     }
                 }
+                if (P::ATOMIC) {
+                    row_atomic_axpy(syn0, last, lane, 1.0f, neu);
+                } else {
 #pragma unroll
-                for (int q = 0; q < DCH; q++) {
-                    l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
+                    for (int q = 0; q < DCH; q++) {
+                        l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
+                    }
+                    row_store<DCH, P::STORE_AUX>(l1, syn0, last, lane);
                 }
-                row_store(l1, p.syn0, last, stride, lane);
                 my_pairs++;
             }
-            if (h_dirty) row_store(h, p.syn1neg, word, stride, lane);
+            if (h_dirty) {
+                if (P::ATOMIC) row_atomic_axpy(syn1neg, word, lane, 1.0f, dh);
+                else row_store<DCH, P::STORE_AUX>(h, syn1neg, word, lane);
+            }
         }
     }
     if (lane == 0) {
@@ -478,7 +556,8 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     {
         float e[EXP_TABLE_SIZE];
         for (int i = 0; i < EXP_TABLE_SIZE; i++) {
-            float x = (float)exp((i / (float)EXP_TABLE_SIZE * 2 - 1) * MAX_EXP);
+            // C semantics of word2vec.c: the argument is a float expression, exp() itself is the DOUBLE function
+            float x = (float)exp((double)((i / (float)EXP_TABLE_SIZE * 2 - 1) * MAX_EXP));
             e[i] = x / (x + 1);
         }
         MC(dge_dev_alloc(&m->d_exp, EXP_TABLE_SIZE));
@@ -486,6 +565,10 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         MH(hipStreamSynchronize(st));
     }
     size_t tab = (size_t)V * (size_t)m->stride;
+    if (tab * sizeof(float) >= (size_t)0xFFFFFFFFull) {
+        model_release(m); delete m;
+        DGE_FAIL(DGE_ERR_ARG, "dge_model_create: a table of %lld rows x %d floats exceeds the 4 GiB buffer window of this build", (long long)V, m->stride);
+    }
     MC(dge_dev_alloc(&m->d_syn0, tab + 64)); MC(dge_dev_alloc(&m->d_syn1neg, tab + 64));
     MH(hipMemsetAsync(m->d_syn1neg, 0, (tab + 64) * sizeof(float), st));
     if (V) hipLaunchKernelGGL(k_init_syn0, dim3(grid_for(V, 256)), dim3(256), 0, st, m->d_syn0, V, m->D, m->stride, cfg->seed);
@@ -518,8 +601,12 @@ static int ensure_work(dge_model* m, int64_t n_rows, int32_t L) {
 }
 
 template <int DCH>
-static void launch_train(const TrainParams& p, unsigned blocks, unsigned threads, hipStream_t st) {
-    hipLaunchKernelGGL(k_sgns_train<DCH>, dim3(blocks), dim3(threads), 0, st, p);
+static void launch_train(const TrainParams& p, int pol, unsigned blocks, unsigned threads, hipStream_t st) {
+    switch (pol) {
+        case 0: hipLaunchKernelGGL((k_sgns_train<DCH, 0>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1>), dim3(blocks), dim3(threads), 0, st, p); break;
+        default: hipLaunchKernelGGL((k_sgns_train<DCH, 2>), dim3(blocks), dim3(threads), 0, st, p); break;
+    }
 }
 
 static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32_t L, int64_t walk_index_base, int32_t epoch,
@@ -552,6 +639,8 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
     } else workers = m->cfg.workers;
     p.n_workers = workers;
+    // update policy (see Policy<> and dge_train_config.update_policy)
+    int pol = workers == 1 ? 0 : (m->cfg.update_policy == 1 ? 1 : (m->cfg.update_policy == 3 ? 0 : 2));
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
 
@@ -559,12 +648,12 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     DGE_HIP(hipEventCreate(&ev.a)); DGE_HIP(hipEventCreate(&ev.b));
     DGE_HIP(hipEventRecord(ev.a, st));
     switch (m->stride / 64) {
-        case 1: launch_train<1>(p, blocks, threads, st); break;
-        case 2: launch_train<2>(p, blocks, threads, st); break;
-        case 3: launch_train<3>(p, blocks, threads, st); break;
-        case 4: launch_train<4>(p, blocks, threads, st); break;
-        case 6: launch_train<6>(p, blocks, threads, st); break;
-        default: launch_train<8>(p, blocks, threads, st); break;
+        case 1: launch_train<1>(p, pol, blocks, threads, st); break;
+        case 2: launch_train<2>(p, pol, blocks, threads, st); break;
+        case 3: launch_train<3>(p, pol, blocks, threads, st); break;
+        case 4: launch_train<4>(p, pol, blocks, threads, st); break;
+        case 6: launch_train<6>(p, pol, blocks, threads, st); break;
+        default: launch_train<8>(p, pol, blocks, threads, st); break;
     }
     DGE_HIP(hipEventRecord(ev.b, st));
     m->pending.push_back(ev);

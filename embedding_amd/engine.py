@@ -155,9 +155,9 @@ class WalkCorpus:
 
 
 def make_config(dim, window, n_vertices, negative=5, min_count=2, epochs=1, workers=0, alpha=0.025, min_alpha=1e-4,
-                seed=1, table_size=100_000_000):
+                seed=1, table_size=100_000_000, update_policy=0):
     return TrainConfig(int(dim), int(window), int(negative), int(min_count), int(epochs), int(workers), float(alpha),
-                       float(min_alpha), int(seed), int(table_size), int(n_vertices), 0)
+                       float(min_alpha), int(seed), int(table_size), int(n_vertices), int(update_policy))
 
 
 class SgnsModel:

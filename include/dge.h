@@ -127,7 +127,11 @@ typedef struct dge_train_config {
     uint64_t seed;
     int64_t table_size;      /* unigram^0.75 table length; 0 -> 100000000 (word2vec.c) */
     int32_t n_vertices;      /* vertex-id space of the corpus */
-    int32_t reserved;
+    int32_t update_policy;   /* how concurrent workers update the tables (MI355X has 8 non-coherent L2s):
+                                0 = auto (atomic), 1 = agent-scope row read-modify-write (write-through; the last
+                                writer of a row wins, classic Hogwild), 2 = memory-side float atomics (no update is
+                                lost), 3 = plain cached accesses (debug only: XCDs train private stale copies).
+                                Ignored when workers == 1 (in-order, plain). */
 } dge_train_config;
 
 typedef struct dge_train_stats {

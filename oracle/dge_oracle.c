@@ -425,7 +425,7 @@ static int vc_cmp(const void* a, const void* b) {     /* count desc, vertex id a
 }
 
 /* dot products.  arith 0: word2vec.c loop.  arith 1: the HIP kernel's lane order — lane j of a
- * 16-lane group owns elements {64c+4j..64c+4j+3}, accumulates with fmaf in increasing index order,
+ * 16-lane group owns elements {64c+16m+j : m=0..3}, accumulates with fmaf in increasing index order,
  * then the 16 partials are combined by an xor-butterfly (1,2,4,8). */
 static inline float dot_seq(const float* a, const float* b, int D) {
     float f = 0;
@@ -438,7 +438,7 @@ static inline float dot_lane16(const float* a, const float* b, int D) {
         float acc = 0.0f;
         for (int c = 0; c * 64 < D; c++)
             for (int e = 0; e < 4; e++) {
-                int idx = c * 64 + 4 * j + e;
+                int idx = c * 64 + 16 * e + j;
                 if (idx < D) acc = fmaf(a[idx], b[idx], acc);
             }
         p[j] = acc;

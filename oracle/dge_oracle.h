@@ -66,7 +66,7 @@ typedef struct orc_train_config {
     uint64_t seed;
     int64_t table_size;      /* unigram^0.75 table length (word2vec.c: 1e8) */
     int32_t arith;           /* 0 = word2vec.c order (sequential dot, unfused mul+add)
-                                1 = HIP lane order (16-lane partials, fmaf, xor tree)   */
+                                1 = HIP lane order (lane j owns elements 64c+16m+j; fmaf; xor tree)   */
     int32_t n_vertices;      /* vertex-id space of the walks (ids in [0,n_vertices)) */
     int64_t walk_index_base; /* global index of walks[0] (multi-rank sharding) */
     int64_t total_walks;     /* global number of walks per epoch (0 = n_walks) */
