@@ -105,23 +105,25 @@ def test_zero_learning_rate_is_identity_and_empty_corpus(dge, oracle):
 
 
 def test_hogwild_matches_in_order_statistically(dge, oracle):
-    """workers=0 fills the device (racy like the reference's 8 DL4J workers): same pair count, vectors close to the
-    in-order run in direction (not element-wise: Hogwild is not deterministic even reference-vs-reference)."""
+    """workers=0 fills the device (racy like the reference's 8 DL4J workers): same pair count, and — because updates
+    are memory-side float atomics and reads are agent-scope — vectors that stay closer to the in-order result than the
+    CPU's own 8-thread Hogwild does (not element-wise: Hogwild is not deterministic even reference-vs-reference)."""
     walks, NV = _walks(oracle, dge, R=400, T=6, n=30000)
     om, dm = _fit_both(oracle, dge, walks, NV, arith=1, workers=0, dim=32)
+    o8 = oracle.train_sgns(walks, NV, 32, 6, table_size=20011, arith=1, threads=8)
     syn0, vid = dm.vectors()
     assert dm.stats()["pairs"] == om.pairs
     assert np.isfinite(syn0).all()
-    cos = cosine_rows(syn0, om.syn0)
-    assert np.median(cos) > 0.9, np.median(cos)
-    # the objective moved the same way: positive pairs score higher than at initialisation
-    s1 = dm.syn1neg()
-    def score(a0, a1):
-        w0 = walks[:2000, 0]; w1 = walks[:2000, 1]
-        remap = -np.ones(NV, np.int64); remap[vid] = np.arange(len(vid))
-        ok = (remap[w0] >= 0) & (remap[w1] >= 0)
-        return float((a0[remap[w1[ok]]] * a1[remap[w0[ok]]]).sum(1).mean())
-    assert score(syn0, s1) > 0.05 and abs(score(syn0, s1) - score(om.syn0, om.syn1neg)) < 0.5 * abs(score(om.syn0, om.syn1neg))
+    cos_gpu = float(np.median(cosine_rows(syn0, om.syn0)))
+    cos_cpu8 = float(np.median(cosine_rows(o8.syn0, om.syn0)))
+    assert cos_gpu > 0.95 and cos_gpu > cos_cpu8, (cos_gpu, cos_cpu8)
+    # an explicit worker count is honoured, and few workers track the in-order run almost exactly
+    _, d64 = _fit_both(oracle, dge, walks, NV, arith=1, workers=64, dim=32)
+    assert float(np.median(cosine_rows(d64.vectors()[0], om.syn0))) > 0.999
+    # the row read-modify-write policy (last writer wins) is also usable at low concurrency
+    c = dge.make_config(32, 6, NV, workers=64, table_size=20011, update_policy=1)
+    d1 = dge.SgnsModel.fit(walks, c, 0)
+    assert float(np.median(cosine_rows(d1.vectors()[0], om.syn0))) > 0.99
 
 
 def test_sharded_training_and_delta_exchange(dge, oracle):
