@@ -62,6 +62,7 @@ def main():
 
     import embedding_amd as E
     from embedding_amd import synth
+    from embedding_amd.distributed import allreduce_counts, exchange_deltas, shard_plan
 
     wl = WORKLOADS[args.workload]
     R, T, L, D, K = wl["R"], wl["T"], wl["L"], wl["dim"], wl["negative"]
@@ -81,14 +82,12 @@ def main():
 
     # ---- setup: this rank's shard of the epoch corpus, global vocabulary
     epoch_walks = wl["walks_per_vertex"] * NV
-    shard = epoch_walks // N
-    shard0 = rank * shard
+    shard0, shard = shard_plan(epoch_walks, N, rank)
     WALK_SEED = 20171106
     corpus = g.sample_walks_device(shard, L, seed=WALK_SEED, rng_mode=1, first_index=shard0)
     counts = torch.zeros(NV, dtype=torch.int64, device=dev)
     corpus.count_tokens(NV, counts)
-    if N > 1:
-        dist.all_reduce(counts)
+    allreduce_counts(counts)
     # epochs only sets the learning-rate horizon (alpha decays over epochs*total_words); the bench steps stay near alpha0
     cfg = E.make_config(D, L, NV, negative=K, min_count=2, epochs=1000, workers=args.workers, seed=1, update_policy=args.policy)
     model = E.SgnsModel.create(cfg, counts, local_rank)
@@ -106,9 +105,7 @@ def main():
         model.walk_and_train(g, corpus, row0, B, walk_seed=WALK_SEED, walk_index_base=shard0 + row0, epoch=0,
                              words_before=0, words_scale=float(N), total_walks=epoch_walks)
         if N > 1:
-            model.export_delta(delta)
-            dist.all_reduce(delta)
-            model.import_delta(delta, 1.0 / N)
+            exchange_deltas(model, delta, N)
 
     def sync():
         model.stats()                 # drains the library's stream

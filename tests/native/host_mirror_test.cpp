@@ -1,0 +1,91 @@
+// Port of T/LayeredGraphTest.java:12-44 to the C++ host mirror (embedding_amd/host/embedding_host.hpp), plus the
+// writer-loop / DeepWalk plumbing (.seq -> .vec).  Needs a GPU: built and run by tests/test_gpu_host_mirror.py.
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "../../embedding_amd/host/embedding_host.hpp"
+using namespace embedding;
+
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    std::string tmp = argc > 1 ? argv[1] : "/tmp";
+    {   // testAliasTable
+        LayeredGraph g;
+        g.addEdge("start", "d1", 2);
+        g.addEdge("start", "d2", 10);
+        g.addEdge("start", "d3", 8);
+        g.addSourceVertex("start");
+        g.initiateAliasTables();
+        LayeredGraph::Vertex org = g.vertex("start");
+        CHECK(org.aliasTable[0] == 1); CHECK(org.aliasTable[1] == 2); CHECK(org.aliasTable[2] == -1);
+        CHECK(org.probTable[0] == 0.3); CHECK(org.probTable[1] == 0.8); CHECK(org.probTable[2] == 1.0);
+        CHECK(org.outDegree == 20.0);
+        CHECK(org.sampleNextVertex(0.05) == 1); CHECK(org.sampleNextVertex(0.3) == 2); CHECK(org.sampleNextVertex(0.4) == 2);
+        CHECK(org.sampleNextVertex(0.65) == 3); CHECK(org.sampleNextVertex(0.9) == 3);
+        CHECK(g.vertex("d1").id == 1 && g.vertex("d3").id == 3);      // ids are insertion ordinals
+    }
+    {   // java.util.Random mirror: seed 42 -> 0.7275636800328681 ; seed 0 -> 0.730967787376657
+        Random r(42); CHECK(r.nextDouble() == 0.7275636800328681);
+        Random z(0);  CHECK(z.nextDouble() == 0.730967787376657);
+    }
+    // cross-time graph: 3 slices x 6 regions, every flow positive
+    CrossTimeGraph::numLayer = 3; CrossTimeGraph::numSamples = 2000;
+    std::vector<Flow> flows; std::vector<int> regions;
+    for (int r = 0; r < 6; r++) regions.push_back(100 + r);
+    for (int h = 0; h < 3; h++)
+        for (int s = 0; s < 6; s++)
+            for (int d = 0; d < 6; d++) flows.push_back({h, 100 + s, 100 + d, (double)(1 + (s * 7 + d * 3 + h) % 5)});
+    std::string seq = tmp + "/taxi-crosstime.seq", vec = tmp + "/taxi-deepwalk.vec";
+    {
+        CrossTimeGraph g;
+        CrossTimeGraph::constructGraph(g, flows, regions);
+        LayeredGraph::rnd = Random(2017);
+        CrossTimeGraph::outputSampleSequence(g, seq);
+        CHECK(LayeredGraph::rnd.draws() == 2000 * 3);                 // one draw per node, no dead ends
+        // single-call API consumes the same stream as the bulk call
+        LayeredGraph::rnd = Random(2017);
+        std::ifstream in(seq); std::string line;
+        for (int i = 0; i < 50; i++) {
+            std::getline(in, line);
+            std::vector<std::string> w = g.sampleVertexSequence();
+            std::string joined;
+            for (size_t j = 0; j < w.size(); j++) joined += (j ? " " : "") + w[j];
+            CHECK(joined == line);
+            CHECK(w.size() == 3 && w[0].substr(0, 2) == "0-" && w[1].substr(0, 2) == "1-" && w[2].substr(0, 2) == "2-");
+        }
+    }
+    {   // spatial graph: position prefix + top-10 prune
+        SpatialGraph::numLayer = 3; SpatialGraph::numSamples = 500;
+        std::vector<std::string> names; std::vector<double> wt;
+        int n = 12;
+        for (int i = 0; i < n; i++) names.push_back(std::to_string(100 + i));
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) wt.push_back(std::exp(-100.0 * std::fabs(i - j) * 0.004));
+        SpatialGraph g;
+        SpatialGraph::constructGraph(g, names, wt);
+        CHECK(g.vertex("105").edgesOutTo.size() == 10);
+        LayeredGraph::rnd = Random(7);
+        SpatialGraph::outputSampleSequence(g, tmp + "/taxi-spatial.seq");
+        std::ifstream in(tmp + "/taxi-spatial.seq"); std::string line; std::getline(in, line);
+        CHECK(line.substr(0, 2) == "0-" && line.find(" 1-") != std::string::npos && line.find(" 2-") != std::string::npos);
+    }
+    {   // DeepWalk.learnEmbedding on both corpora (the "usespatial" directory case, J/DeepWalk.java:47-50)
+        LayeredGraph::numLayer = 3;
+        dge_train_stats st = DeepWalk::learnEmbedding({seq, tmp + "/taxi-spatial.seq"}, vec, 20);
+        CHECK(st.pairs > 0);
+        std::ifstream in(vec); std::string line; int lines = 0;
+        while (std::getline(in, line)) {
+            std::istringstream ss(line); std::string name; ss >> name; double x; int cnt = 0;
+            while (ss >> x) cnt++;
+            CHECK(cnt == 20 && name.find('-') != std::string::npos);  // "h-id v1 .. v20", no header
+            lines++;
+        }
+        CHECK(lines == 18);                                           // 3 layers x 6 regions, all above min frequency
+    }
+    std::printf("HOST MIRROR OK\n");
+    return 0;
+}

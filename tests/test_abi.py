@@ -1,0 +1,54 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dge.h declares; without a GPU every entry that
+needs the device fails loudly (there is no CPU path in the product)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    h = open(os.path.join(ROOT, "include", "dge.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(dge_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_library_exports_every_declared_symbol(dge):
+    names = _declared()
+    assert len(names) >= 40
+    raw = C.CDLL(dge.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "libdge.so does not export %s" % n
+    from embedding_amd._native import SIGNATURES
+    assert sorted(SIGNATURES) == names, set(names) ^ set(SIGNATURES)     # the ctypes view binds exactly the header
+
+
+def test_struct_layouts(dge):
+    assert C.sizeof(dge.TrainConfig) == 56 and C.sizeof(dge.TrainStats) == 40
+    assert dge.lib.dge_version() == 100
+
+
+def test_no_device_means_loud_failure(dge):
+    n = C.c_int(0)
+    dge.lib.dge_device_count(C.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is visible: the no-device behaviour cannot be observed here")
+    with pytest.raises(dge.DgeError) as ei:
+        dge.DeviceGraph(0)
+    assert ei.value.code == 6 and "no CPU path" in str(ei.value)
+    with pytest.raises(dge.DgeError):
+        dge.WalkCorpus.from_host(np.zeros((2, 3), np.int32), 0)
+    with pytest.raises(dge.DgeError):
+        dge.SgnsModel.fit(np.zeros((2, 3), np.int32), dge.make_config(8, 3, 4), 0)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under embedding_amd/ may reference it."""
+    for d, _, files in os.walk(os.path.join(ROOT, "embedding_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
+                txt = open(os.path.join(d, f), errors="replace").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "dge_oracle" not in txt.replace("oracle/dge_oracle.c", ""), f

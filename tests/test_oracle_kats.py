@@ -1,0 +1,244 @@
+"""CPU: the oracle against every known-answer the reference holds for this path, plus an independent pure-Python
+restatement of the parts no reference test covers (RNG streams, pair enumeration, unigram table).
+
+Pinned by the reference: T/LayeredGraphTest.java:12-44 (tests/golden/layered_graph_test.json) and the public
+java.util.Random spec (tests/golden/java_random_kats.json).  SGNS: parity unpinned — see oracle/dge_oracle.h.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from helpers import cosine_rows, layered_graph
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+M64 = (1 << 64) - 1
+
+
+# ------------------------------------------------------------------------------------------- java.util.Random
+def test_java_random_known_answers(oracle):
+    for case in json.load(open(os.path.join(GOLD, "java_random_kats.json")))["cases"]:
+        r = oracle.JavaRandom(case["seed"])
+        if "next_int" in case:
+            assert r.next_int() == case["next_int"]
+        else:
+            assert r.next_double() == case["next_double"]
+
+
+def test_java_random_jump_equals_stepping(oracle):
+    a = oracle.JavaRandom(12345)
+    seq = [a.next_double() for _ in range(50)]
+    for k in (0, 1, 7, 49):
+        b = oracle.JavaRandom(12345)
+        b.jump(2 * k)                         # one nextDouble = two LCG steps (next(26), next(27))
+        assert b.next_double() == seq[k]
+    # spec restated in Python: s' = (s*0x5DEECE66D + 0xB) mod 2^48
+    s = (987 ^ 0x5DEECE66D) & ((1 << 48) - 1)
+    def nxt(bits):
+        nonlocal s
+        s = (s * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+        return s >> (48 - bits)
+    r = oracle.JavaRandom(987)
+    for _ in range(20):
+        assert r.next_double() == ((nxt(26) << 27) + nxt(27)) * 2.0 ** -53
+
+
+# ------------------------------------------------------------------------------------------- LayeredGraphTest
+def test_layered_graph_test_golden_vector(oracle):
+    """T/LayeredGraphTest.java:12-44, every assertion."""
+    G = json.load(open(os.path.join(GOLD, "layered_graph_test.json")))
+    e = np.array(G["edges"])
+    g = oracle.Graph()
+    g.add_edges(e[:, 0].astype(np.int32), e[:, 1].astype(np.int32), e[:, 2])
+    g.set_sources([0])
+    g.build_alias(exact=True)
+    a = g.get_alias(0)
+    assert a["alias"].tolist() == G["alias_table"]
+    assert a["prob"].tolist() == G["prob_table"]            # exact doubles, as assertEquals(double,double)
+    assert a["out_degree"] == G["out_degree"]
+    for x, want in G["draws"]:
+        assert g.sample_next(0, x) == want
+
+
+def test_reference_pairing_order_properties(oracle):
+    """The reference pairing (J/LayeredGraph.java:65-81) keeps the sampling distribution: P(edge i) = w_i / sum."""
+    rng = np.random.default_rng(0)
+    for k in (1, 2, 7, 40):
+        w = rng.integers(1, 50, k).astype(float)
+        g = oracle.Graph(); g.add_edges(np.zeros(k, np.int32), np.arange(1, k + 1, dtype=np.int32), w); g.set_sources([0])
+        for exact in (True, False):
+            g.build_alias(exact)
+            a = g.get_alias(0)
+            p = np.zeros(k)
+            for i in range(k):
+                p[i] += min(a["prob"][i], 1.0) / k
+                if a["alias"][i] >= 0:
+                    p[a["alias"][i]] += (1 - a["prob"][i]) / k
+                else:
+                    p[i] += max(0.0, 1 - a["prob"][i]) / k     # "no alias": stay in the slot
+            assert np.allclose(p, w / w.sum(), atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------- walks
+def test_walk_streams(oracle):
+    src, dst, w, sources = layered_graph(R=30, T=5, deg=5, seed=1)
+    g = oracle.Graph(); g.add_edges(src, dst, w); g.set_sources(sources); g.build_alias(True)
+    a, draws = g.sample_walks(500, 5, seed=7, rng_mode=0, return_draws=True)
+    b = g.sample_walks(500, 5, seed=7, rng_mode=1)
+    assert draws == 2500 and np.array_equal(a, b)                 # no dead ends: sequential == strided
+    assert (a // 30 == np.arange(5)[None, :]).all()              # step j reads slice j (J/CrossTimeGraph.java:36-39)
+    # first walk by hand: one draw for the source (J/LayeredGraph.java:234-242), one per step (:104-116)
+    r = oracle.JavaRandom(7)
+    sa = g.get_source_alias()
+    x = r.next_double(); k = len(sa["src"]); i = int(x * k); y = x * k - i
+    v = sa["src"][i] if y < sa["prob"][i] else sa["src"][sa["alias"][i]]
+    assert v == a[0, 0]
+    for j in range(1, 5):
+        al = g.get_alias(int(v)); k = len(al["nbr"]); x = r.next_double(); i = int(x * k); y = x * k - i
+        v = al["nbr"][i] if y < al["prob"][i] else al["nbr"][al["alias"][i]]
+        assert v == a[0, j]
+
+
+def test_dead_ends_shorten_walks_and_draw_counts(oracle):
+    src, dst, w, sources = layered_graph(R=30, T=5, deg=4, seed=3, dead_ends=0.3)
+    g = oracle.Graph(); g.add_edges(src, dst, w); g.set_sources(sources); g.build_alias(True)
+    a, draws = g.sample_walks(800, 5, seed=9, rng_mode=0, return_draws=True)
+    assert (a == -1).any() and draws == int((a >= 0).sum()) < 4000
+    lens = (a >= 0).sum(1)
+    for row, n in zip(a, lens):                                   # -1 only as right padding
+        assert (row[:n] >= 0).all() and (row[n:] == -1).all()
+    last = a[np.arange(len(a)), lens - 1]
+    short = lens < 5
+    assert all(len(g.get_alias(int(v))["nbr"]) == 0 for v in last[short][:50])   # stopped exactly at a sink
+
+
+def test_transition_frequencies_follow_weights(oracle):
+    rng = np.random.default_rng(2)
+    k = 12
+    w = rng.integers(1, 100, k).astype(float)
+    g = oracle.Graph(); g.add_edges(np.zeros(k, np.int32), np.arange(1, k + 1, dtype=np.int32), w); g.set_sources([0]); g.build_alias(True)
+    n = 200_000
+    walks = g.sample_walks(n, 2, seed=1, rng_mode=1)
+    obs = np.bincount(walks[:, 1], minlength=k + 1)[1:]
+    e = w / w.sum() * n
+    chi2 = float(((obs - e) ** 2 / e).sum())
+    assert chi2 < (k - 1) + 5 * math.sqrt(2 * (k - 1))
+
+
+def test_keep_top_k_is_stable_and_recomputes_degree(oracle):
+    g = oracle.Graph()
+    w = np.array([0.5, 1.0, 0.5, 0.25, 1.0, 0.5])
+    g.add_edges(np.zeros(6, np.int32), np.arange(6, dtype=np.int32), w)
+    for v in range(1, 6):
+        g.add_edges(np.full(6, v, np.int32), np.arange(6, dtype=np.int32), w)
+    g.keep_top_k(4)
+    a = g.get_alias(0)
+    assert a["nbr"].tolist() == [1, 4, 0, 2]                      # ties keep insertion order (List.sort is stable)
+    assert a["out_degree"] == 3.0
+    with pytest.raises(RuntimeError):
+        g.keep_top_k(5)                                           # subList(0,k) on a shorter list throws
+
+
+# ------------------------------------------------------------------------------------------- SGNS restatement
+def mix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M64
+    return x ^ (x >> 31)
+
+
+def test_vocabulary_table_init_and_pair_enumeration(oracle):
+    """Independent Python restatement of everything around the arithmetic: vocabulary order, unigram table
+    (word2vec.c InitUnigramTable), InitNet, per-(walk,centre) RNG streams and DL4J's window loop."""
+    src, dst, w, sources = layered_graph(R=10, T=4, deg=3, seed=5)
+    g = oracle.Graph(); g.add_edges(src, dst, w); g.set_sources(sources); g.build_alias(True)
+    walks = g.sample_walks(60, 4, seed=3, rng_mode=1)
+    NV, D, W, K, T, seed = 40, 6, 4, 2, 97, 11
+    m = oracle.train_sgns(walks, NV, D, W, negative=K, min_count=2, epochs=0, table_size=T, seed=seed)
+    cnt = np.bincount(walks[walks >= 0], minlength=NV)
+    order = sorted([v for v in range(NV) if cnt[v] >= 2], key=lambda v: (-cnt[v], v))
+    assert m.vocab_ids.tolist() == order and m.counts.tolist() == [int(cnt[v]) for v in order]
+    # unigram table
+    p = np.array([c ** 0.75 for c in m.counts]); p = p / p.sum()
+    tab, i, d1 = [], 0, p[0]
+    for a in range(T):
+        tab.append(i)
+        if a / T > d1:
+            i += 1; d1 += p[i] if i < len(p) else 0.0
+        if i >= len(p):
+            i = len(p) - 1
+    assert abs(np.array(tab) - m.table(T)).max() <= 1           # python float sum order may differ by one slot at a boundary
+    # InitNet
+    s = seed
+    for r in range(2):
+        for b in range(D):
+            s = (s * 25214903917 + 11) & M64
+            want = np.float32((np.float32(np.float32(s & 0xFFFF) / np.float32(65536)) - np.float32(0.5)) / np.float32(D))
+            assert m.syn0[r, b] == want
+    assert not m.syn1neg.any()
+    # pair count from the window draws (1 epoch)
+    m1 = oracle.train_sgns(walks, NV, D, W, negative=K, min_count=2, epochs=1, table_size=T, seed=seed)
+    remap = {v: r for r, v in enumerate(order)}
+    pairs = 0
+    for wi, row in enumerate(walks):
+        sen = [remap[t] for t in row if t >= 0 and t in remap]
+        for i in range(len(sen)):
+            st = mix64((seed + wi * 4 + i) & M64)
+            st = (st * 25214903917 + 11) & M64
+            b = st % W
+            for a in range(b, 2 * W + 1 - b):
+                c = i - W + a
+                if a != W and 0 <= c < len(sen):
+                    pairs += 1
+    assert pairs == m1.pairs and m1.total_words == sum(len([t for t in row if t >= 0 and t in remap]) for row in walks)
+
+
+def test_sigmoid_table_and_lane_order_agreement(oracle):
+    e = oracle.exp_table()
+    assert e[0] == np.float32(math.exp(-6.0)) / (np.float32(math.exp(-6.0)) + np.float32(1))
+    assert abs(e[500] - 0.5) < 1e-6 and (np.diff(e) > 0).all()
+    src, dst, w, sources = layered_graph(R=40, T=6, deg=5, seed=0)
+    g = oracle.Graph(); g.add_edges(src, dst, w); g.set_sources(sources); g.build_alias(True)
+    walks = g.sample_walks(1500, 6, seed=11, rng_mode=1)
+    a = oracle.train_sgns(walks, 240, 20, 6, table_size=20011, arith=0)
+    b = oracle.train_sgns(walks, 240, 20, 6, table_size=20011, arith=1)
+    assert cosine_rows(a.syn0, b.syn0).min() > 1 - 1e-4            # word2vec.c order vs HIP lane order: same vectors
+    # training moves positive pairs up and the loss proxy down relative to the initial weights
+    init = oracle.train_sgns(walks, 240, 20, 6, table_size=20011, epochs=0)
+    assert np.abs(a.syn0 - init.syn0).max() > 1e-3 and a.syn1neg.any()
+
+
+def test_hogwild_threads_keep_pair_count(oracle):
+    src, dst, w, sources = layered_graph(R=40, T=6, deg=5, seed=0)
+    g = oracle.Graph(); g.add_edges(src, dst, w); g.set_sources(sources); g.build_alias(True)
+    walks = g.sample_walks(3000, 6, seed=11, rng_mode=1)
+    a = oracle.train_sgns(walks, 240, 16, 6, table_size=5003, threads=1)
+    b = oracle.train_sgns(walks, 240, 16, 6, table_size=5003, threads=4)
+    assert a.pairs == b.pairs and np.isfinite(b.syn0).all()
+
+
+def test_oracle_regression_fixture(oracle):
+    """tests/golden/oracle_small.npz (made by make_golden.py from this oracle): guards against accidental change."""
+    G = np.load(os.path.join(GOLD, "oracle_small.npz"))
+    g = oracle.Graph(); g.add_edges(G["src"], G["dst"], G["w"]); g.set_sources(G["sources"]); g.build_alias(True)
+    assert np.array_equal(g.sample_walks(64, 4, seed=2017, rng_mode=0), G["walks_seq"])
+    assert np.array_equal(g.sample_walks(64, 4, seed=2017, rng_mode=1, first_index=5), G["walks_str"])
+    a3 = g.get_alias(3)
+    assert np.array_equal(a3["alias"], G["alias3"]) and np.array_equal(a3["prob"], G["prob3"])
+    for arith in (0, 1):
+        m = oracle.train_sgns(G["walks_seq"], 48, 8, 4, negative=3, min_count=2, table_size=257, arith=arith)
+        assert np.array_equal(m.vocab_ids, G["vocab"]) and np.array_equal(m.counts, G["counts"])
+        assert np.array_equal(m.table(257), G["table"]) and m.pairs == int(G["pairs"][0])
+        assert np.array_equal(m.syn0.view(np.int32), G["syn0_arith%d" % arith].view(np.int32))
+        assert np.array_equal(m.syn1neg.view(np.int32), G["syn1_arith%d" % arith].view(np.int32))
+
+
+def test_vec_format_fixture():
+    """miscs/taxi_all.txt (LINE-style .vec: header 'V D', then 'id v1..vD'): the reader contract of
+    P/embeddingEvaluation_tract.py:113-117 — skip_header=1, first column is the region id."""
+    rows = np.genfromtxt(os.path.join(GOLD, "taxi_all_head.vec"), skip_header=1)
+    head = open(os.path.join(GOLD, "taxi_all_head.vec")).readline().split()
+    assert head == ["77", "8"] and rows.shape == (3, 9) and rows[:, 0].tolist() == [1.0, 2.0, 3.0]
+    assert np.allclose(np.linalg.norm(rows[:, 1:5], axis=1), 1.0, atol=1e-4)      # two unit 4-vectors per row
