@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
             CHECK(cnt == 20 && name.find('-') != std::string::npos);  // "h-id v1 .. v20", no header
             lines++;
         }
-        CHECK(lines == 18);                                           // 3 layers x 6 regions, all above min frequency
+        CHECK(lines == 36);                                           // shared "h-id" vocabulary: 3 layers x 12 spatial regions (the 6 flow regions are a subset)
     }
     std::printf("HOST MIRROR OK\n");
     return 0;
