@@ -46,6 +46,7 @@ struct dge_model {
     int32_t* d_sen = nullptr; int64_t* d_len = nullptr; int64_t* d_wb = nullptr;
     void* d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
     unsigned long long* d_counters = nullptr;   // [0]=pairs [1]=words
+    int* d_locks = nullptr;                     // commit-lock word per syn1neg row
     // host mirrors for the read-back API
     std::vector<float> h_syn0, h_syn1neg;
     std::vector<int32_t> h_vocab_ids, h_table;
@@ -145,6 +146,7 @@ struct TrainParams {
     float alpha0, min_alpha;
     int64_t n_workers;
     unsigned long long* counters;
+    int* locks;               // one commit-lock word per syn1neg row (all zero between launches)
 };
 
 template <int DCH> struct Row { float4 v[DCH]; };
@@ -158,11 +160,25 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 //   POL 0  plain loads / plain stores            (workers == 1: bit-exact with the oracle)
 //   POL 1  sc1 loads / sc1 write-through stores  (Hogwild, row granularity: last writer of a row wins)
 //   POL 2  sc1 loads / float atomic adds         (Hogwild, element granularity: no update is lost)
+//   POL 4  syn0: as POL 2.  syn1neg: every row update is a read-modify-write under that row's commit lock
+//          (one 4-byte atomic exchange to take it, one write-through store to drop it) with write-through row
+//          stores: no update is lost and a 512-B row costs 2 atomic requests instead of 8.
 template <int POL> struct Policy {
     static constexpr int LOAD_AUX = POL == 0 ? 0 : 16;    // aux bit 4 = sc1 on gfx950
     static constexpr int STORE_AUX = POL == 0 ? 0 : 16;
-    static constexpr bool ATOMIC = POL == 2;
+    static constexpr bool ATOMIC = POL == 2;              // syn1neg updates are float atomics
+    static constexpr bool LOCKED = POL == 4;              // syn1neg updates are locked row RMW
+    static constexpr bool SYN0_ATOMIC = POL == 2 || POL == 4;
 };
+
+// try-lock of one row: true when this lane took it.  The caller makes the row's load address depend on the result,
+// so the load cannot be issued before the exchange has returned.
+__device__ __forceinline__ bool row_trylock(int* locks, int32_t row) { return atomicExch(&locks[row], 1) == 0; }
+// the row's write-through stores are drained (vmcnt(0), which the workgroup-scope release fence emits) before the
+// lock word is cleared with an agent-scope store
+__device__ __forceinline__ void row_unlock(int* locks, int32_t row) {
+    __hip_atomic_store(&locks[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ float group16_sum(float p) {
     p += __shfl_xor(p, 1);
@@ -280,15 +296,48 @@ __device__ __forceinline__ void neg_update_serial(const Row<DCH>& l1, Row<DCH>& 
     row_store<DCH, Policy<POL>::STORE_AUX>(r, syn1neg, tg, lane);
 }
 
+__device__ __forceinline__ int32_t walk_tok(bool in_regs, const int32_t* sen, int idx, int32_t tk0, int32_t tk1, int32_t tk2, int32_t tk3) {
+    if (!in_regs) return sen[idx];
+    const int r = idx >> 4;
+    const int32_t v = r == 0 ? tk0 : (r == 1 ? tk1 : (r == 2 ? tk2 : tk3));
+    return __shfl(v, idx & 15, 16);
+}
+
+// LOCKED policy: add the delta row d[] (LDS) to `row` under its lock, blocking.  Used when a second centre closes
+// while the first still waits for its lock, and at the very end of a worker.
 template <int DCH, int POL>
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ void flush_blocking(const TableView& syn1neg, int* locks, int32_t row, const float* d, int lane) {
+    for (;;) {
+        const bool won = lane == 0 ? row_trylock(locks, row) : false;
+        const bool got = __shfl((int)won, 0, 16) != 0;
+        if (got) {
+            Row<DCH> cur;
+            row_load<DCH, Policy<POL>::LOAD_AUX>(cur, syn1neg, got ? row : 0, lane);
+#pragma unroll
+            for (int q = 0; q < DCH; q++) {
+                cur.v[q].x += d[q * 64]; cur.v[q].y += d[q * 64 + 16]; cur.v[q].z += d[q * 64 + 32]; cur.v[q].w += d[q * 64 + 48];
+            }
+            row_store<DCH, Policy<POL>::STORE_AUX>(cur, syn1neg, row, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (won) row_unlock(locks, row);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+template <int DCH, int POL>
+__global__ void __launch_bounds__(256, (DCH <= 2) ? (POL == 4 ? 3 : 4) : 1)
 k_sgns_train(TrainParams p) {
     using P = Policy<POL>;
     __shared__ float s_exp[EXP_TABLE_SIZE];
+    // LOCKED: per worker two delta rows for the centre's syn1neg row (current centre / centre waiting for its lock)
+    __shared__ float s_dh[P::LOCKED ? 16 * 2 * DCH * 64 : 1];
     for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 15;
+    const int wk = threadIdx.x >> 4;
     const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (worker >= p.n_workers) return;
 
@@ -300,113 +349,231 @@ k_sgns_train(TrainParams p) {
     for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
 
     const int L = p.L, W = p.W, K = p.K;
+    const bool toks_in_regs = L <= 64;
     unsigned long long my_pairs = 0, my_words = 0;
 
-    for (int64_t w = worker; w < p.n_rows; w += p.n_workers) {
-        const int32_t* sen = p.sen + w * L;
-        const int len = (int)p.len[w];
-        if (len <= 0) continue;
-        my_words += (unsigned long long)len;
-        // learning rate from the exact number of in-vocabulary tokens that precede this walk
-        int64_t wbw = p.wb[w];
-        int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
-        float alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
-        if (alpha < p.min_alpha) alpha = p.min_alpha;
-        const int64_t gbase = (p.gidx_base + w) * (int64_t)L;
+    // ---- per-worker state: walk w, centre i, next context c (contexts are c..c_hi without i)
+    int64_t w = worker - p.n_workers;
+    int len = 0, i = 0, c = 1, c_hi = 0;
+    int32_t tk0 = -1, tk1 = -1, tk2 = -1, tk3 = -1;       // the walk's tokens: lane j holds tokens j, j+16, j+32, j+48
+    const int32_t* sen = p.sen;
+    int32_t word = 0;
+    float alpha = 0.f;
+    uint64_t s = 0;
+    int64_t gbase = 0;
+    Row<DCH> h, dh;                                       // syn1neg[word] and (ATOMIC) its accumulated update
+    bool h_dirty = false;
+    int32_t pend_row = -1;                                // LOCKED: centre row whose delta (LDS) still waits for its lock
+    int cur_buf = 0;
+    float* const my_dh = s_dh + (P::LOCKED ? (size_t)wk * 2 * DCH * 64 : 0);
 
-        for (int i = 0; i < len; i++) {
-            const int32_t word = sen[i];
-            uint64_t s = dge_mix64(p.seed + (uint64_t)(gbase + i));
+#define DGE_TOK(idx) walk_tok(toks_in_regs, sen, (idx), tk0, tk1, tk2, tk3)
+    // close the open centre: publish what it accumulated on syn1neg[word]
+#define DGE_CLOSE_CENTRE()                                                                                         \
+    do {                                                                                                           \
+        if (h_dirty) {                                                                                             \
+            h_dirty = false;                                                                                       \
+            if (P::ATOMIC) row_atomic_axpy(syn1neg, word, lane, 1.0f, dh);                                         \
+            else if (P::LOCKED) {                                                                                  \
+                if (pend_row >= 0) flush_blocking<DCH, POL>(syn1neg, p.locks, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane); \
+                pend_row = word;                                                                                   \
+                cur_buf ^= 1; /* the closed centre's delta keeps its buffer; the next centre starts a fresh one */ \
+            } else row_store<DCH, P::STORE_AUX>(h, syn1neg, word, lane);                                           \
+        }                                                                                                          \
+    } while (0)
+
+    for (;;) {
+        // ------------------------------------------------------------------ advance to the next (centre, context) pair
+        bool new_centre = false, alive = true;
+        while (c > c_hi) {
+            DGE_CLOSE_CENTRE();
+            i++;
+            while (i >= len) {                             // next walk of this worker (empty walks are skipped)
+                w += p.n_workers;
+                if (w >= p.n_rows) { alive = false; break; }
+                len = (int)p.len[w];
+                i = 0;
+                if (len > 0) {
+                    my_words += (unsigned long long)len;
+                    sen = p.sen + w * L;
+                    if (toks_in_regs) {
+                        tk0 = lane < L ? sen[lane] : -1;
+                        tk1 = lane + 16 < L ? sen[lane + 16] : -1;
+                        tk2 = lane + 32 < L ? sen[lane + 32] : -1;
+                        tk3 = lane + 48 < L ? sen[lane + 48] : -1;
+                    }
+                    // learning rate from the exact number of in-vocabulary tokens that precede this walk
+                    const int64_t wbw = p.wb[w];
+                    const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
+                    alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
+                    if (alpha < p.min_alpha) alpha = p.min_alpha;
+                    gbase = (p.gidx_base + w) * (int64_t)L;
+                }
+            }
+            if (!alive) break;
+            // open centre i: DL4J's window draw, radius W - b
+            word = DGE_TOK(i);
+            s = dge_mix64(p.seed + (uint64_t)(gbase + i));
             s = s * DGE_W2V_MULT + 11;
-            const int b = (int)(s % (uint64_t)W);
-            Row<DCH> h, dh;                               // syn1neg[word]: positive target of every pair of this centre
+            const int radius = W - (int)(s % (uint64_t)W);
+            c = max(0, i - radius);
+            c_hi = min(len - 1, i + radius);
+            if (c_hi == i) c_hi--;
+            if (c == i) c++;
+            new_centre = true;
+        }
+        if (!alive) break;
+        const int32_t last = DGE_TOK(c);
+
+        // ------------------------------------------------------------------ one pair: l1 = syn0[last], target rows in syn1neg
+        Row<DCH> l1, neu;
+        row_load<DCH, P::LOAD_AUX>(l1, syn0, last, lane);
+        if (new_centre) {
             row_load<DCH, P::LOAD_AUX>(h, syn1neg, word, lane);
             if (P::ATOMIC) row_zero(dh);
-            bool h_dirty = false;
-            for (int a = b; a < W * 2 + 1 - b; a++) {
-                if (a == W) continue;
-                const int c = i - W + a;
-                if (c < 0 || c >= len) continue;
-                const int32_t last = sen[c];
-                Row<DCH> l1, neu;
-                row_load<DCH, P::LOAD_AUX>(l1, syn0, last, lane);
-                row_zero(neu);
-                {   // d == 0: target = word, label 1
-                    float f = row_dot(l1, h);
-                    float g = sgns_g(f, 1.0f, alpha, s_exp);
-                    row_axpy(neu, g, h);
-                    row_axpy(h, g, l1);
-                    if (P::ATOMIC) row_axpy(dh, g, l1);
-                    h_dirty = true;
-                }
-                for (int kd = 0; kd < K; kd += 16) {
-                    const int kc = min(16, K - kd);
-                    // lane j draws negative kd+j
-                    const uint64_t sl = s * mA + cA;
-                    int32_t t = -1;
-                    if (lane < kc) {
-                        t = p.table[(sl >> 16) % (uint64_t)p.T];
-                        if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
-                        if (t == word) t = -1;
-                    }
-                    s = shfl16_u64(sl, kc - 1);
-                    for (int base = 0; base < kc; base += NEG_BATCH) {
-                        int32_t tg[NEG_BATCH];
-                        bool dup = false;
+            if (P::LOCKED) {
+                float* d = my_dh + cur_buf * DCH * 64 + lane;
 #pragma unroll
-                        for (int q = 0; q < NEG_BATCH; q++) {
-                            int32_t v = __shfl(t, (base + q) & 15, 16);
-                            tg[q] = (base + q < kc) ? v : -1;
-                        }
-                        if (!P::ATOMIC) {
-#pragma unroll
-                            for (int q = 1; q < NEG_BATCH; q++)
-#pragma unroll
-                                for (int r = 0; r < q; r++) dup |= (tg[q] >= 0 && tg[q] == tg[r]);
-                        }
-                        if (!dup) {
-                            // all rows of the batch in flight together: loads are unconditional (a skipped slot
-                            // reads the centre's own row, always valid), only the arithmetic and the store are guarded
-                            Row<DCH> rr[NEG_BATCH];
-#pragma unroll
-                            for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX>(rr[q], syn1neg, tg[q] >= 0 ? tg[q] : word, lane);
-#pragma unroll
-                            for (int q = 0; q < NEG_BATCH; q++)
-                                if (tg[q] >= 0) {
-                                    float f = row_dot(l1, rr[q]);
-                                    float g = sgns_g(f, 0.0f, alpha, s_exp);
-                                    row_axpy(neu, g, rr[q]);
-                                    if (P::ATOMIC) {
-                                        row_atomic_axpy(syn1neg, tg[q], lane, g, l1);
-                                    } else {
-                                        row_axpy(rr[q], g, l1);
-                                        row_store<DCH, P::STORE_AUX>(rr[q], syn1neg, tg[q], lane);
-                                    }
-                                }
-                        } else {
-#pragma unroll 1
-                            for (int q = 0; q < NEG_BATCH; q++)
-                                if (tg[q] >= 0) neg_update_serial<DCH, POL>(l1, neu, syn1neg, tg[q], lane, alpha, s_exp);
-                        }
-                    }
-                }
-                if (P::ATOMIC) {
-                    row_atomic_axpy(syn0, last, lane, 1.0f, neu);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < DCH; q++) {
-                        l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
-                    }
-                    row_store<DCH, P::STORE_AUX>(l1, syn0, last, lane);
-                }
-                my_pairs++;
-            }
-            if (h_dirty) {
-                if (P::ATOMIC) row_atomic_axpy(syn1neg, word, lane, 1.0f, dh);
-                else row_store<DCH, P::STORE_AUX>(h, syn1neg, word, lane);
+                for (int q = 0; q < DCH; q++) { d[q * 64] = 0.f; d[q * 64 + 16] = 0.f; d[q * 64 + 32] = 0.f; d[q * 64 + 48] = 0.f; }
             }
         }
+        row_zero(neu);
+        if (!P::LOCKED) {   // d == 0: target = word, label 1 (word2vec order: positive first)
+            float f = row_dot(l1, h);
+            float g = sgns_g(f, 1.0f, alpha, s_exp);
+            row_axpy(neu, g, h);
+            row_axpy(h, g, l1);
+            if (P::ATOMIC) row_axpy(dh, g, l1);
+            h_dirty = true;
+        }
+        for (int kd = 0; kd < K; kd += 15) {
+            const int kc = min(15, K - kd);
+            // lane j draws negative kd+j (lanes 0..14; lane 15 carries the pending centre flush of the LOCKED policy)
+            const uint64_t sl = s * mA + cA;
+            int32_t t = -1;
+            if (lane < kc) {
+                t = p.table[(sl >> 16) % (uint64_t)p.T];
+                if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                if (t == word) t = -1;
+            }
+            s = shfl16_u64(sl, kc - 1);
+            if (P::LOCKED && lane == 15) t = pend_row;
+            for (int base = 0; base < kc; base += NEG_BATCH) {
+                int32_t tg[NEG_BATCH];
+#pragma unroll
+                for (int q = 0; q < NEG_BATCH; q++) {
+                    int32_t v = __shfl(t, (base + q) & 15, 16);
+                    tg[q] = (base + q < kc) ? v : -1;
+                }
+                if (P::LOCKED) {
+                    // rounds of { try-lock every pending row of the batch (lane base+q takes slot q, lane 15 the pending
+                    // centre flush) -> rows won are loaded, updated, written through, unlocked }.  Nothing is held while
+                    // waiting, so there is no hold-and-wait cycle; a row drawn twice is won in two different rounds.
+                    unsigned pending = 0;
+#pragma unroll
+                    for (int q = 0; q < NEG_BATCH; q++) pending |= (tg[q] >= 0 ? 1u : 0u) << q;
+                    bool flush_pending = base == 0 && pend_row >= 0;
+                    while (pending) {
+                        const int myq = lane - base;
+                        const bool want = (myq >= 0 && myq < NEG_BATCH && ((pending >> myq) & 1u)) || (lane == 15 && flush_pending);
+                        const bool won = want ? row_trylock(p.locks, t) : false;
+                        const unsigned long long bal = __ballot(won);
+                        const unsigned gotl = (unsigned)(bal >> ((threadIdx.x & 48))) & 0xFFFFu;     // this group's 16 lanes
+                        const unsigned got = (gotl >> base) & ((1u << NEG_BATCH) - 1u) & pending;
+                        const bool gotf = flush_pending && ((gotl >> 15) & 1u);
+                        Row<DCH> rr[NEG_BATCH], fr;
+#pragma unroll
+                        for (int q = 0; q < NEG_BATCH; q++)
+                            row_load<DCH, P::LOAD_AUX>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : word, lane);
+                        if (flush_pending) row_load<DCH, P::LOAD_AUX>(fr, syn1neg, gotf ? pend_row : word, lane);
+#pragma unroll
+                        for (int q = 0; q < NEG_BATCH; q++)
+                            if ((got >> q) & 1u) {
+                                float f = row_dot(l1, rr[q]);
+                                float g = sgns_g(f, 0.0f, alpha, s_exp);
+                                row_axpy(neu, g, rr[q]);
+                                row_axpy(rr[q], g, l1);
+                                row_store<DCH, P::STORE_AUX>(rr[q], syn1neg, tg[q], lane);
+                            }
+                        if (gotf) {
+                            const float* d = my_dh + (cur_buf ^ 1) * DCH * 64 + lane;
+#pragma unroll
+                            for (int q = 0; q < DCH; q++) {
+                                fr.v[q].x += d[q * 64]; fr.v[q].y += d[q * 64 + 16]; fr.v[q].z += d[q * 64 + 32]; fr.v[q].w += d[q * 64 + 48];
+                            }
+                            row_store<DCH, P::STORE_AUX>(fr, syn1neg, pend_row, lane);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // drain the row stores
+                        if (won) row_unlock(p.locks, t);
+                        pending &= ~got;
+                        if (gotf) { flush_pending = false; pend_row = -1; if (lane == 15) t = -1; }
+                        if (pending) __builtin_amdgcn_s_sleep(2);
+                    }
+                    continue;
+                }
+                bool dup = false;
+                if (!P::ATOMIC) {
+#pragma unroll
+                    for (int q = 1; q < NEG_BATCH; q++)
+#pragma unroll
+                        for (int r = 0; r < q; r++) dup |= (tg[q] >= 0 && tg[q] == tg[r]);
+                }
+                if (!dup) {
+                    // all rows of the batch in flight together: loads are unconditional (a skipped slot reads the
+                    // centre's own row, always valid), only the arithmetic and the store are guarded
+                    Row<DCH> rr[NEG_BATCH];
+#pragma unroll
+                    for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX>(rr[q], syn1neg, tg[q] >= 0 ? tg[q] : word, lane);
+#pragma unroll
+                    for (int q = 0; q < NEG_BATCH; q++)
+                        if (tg[q] >= 0) {
+                            float f = row_dot(l1, rr[q]);
+                            float g = sgns_g(f, 0.0f, alpha, s_exp);
+                            row_axpy(neu, g, rr[q]);
+                            if (P::ATOMIC) {
+                                row_atomic_axpy(syn1neg, tg[q], lane, g, l1);
+                            } else {
+                                row_axpy(rr[q], g, l1);
+                                row_store<DCH, P::STORE_AUX>(rr[q], syn1neg, tg[q], lane);
+                            }
+                        }
+                } else {
+#pragma unroll 1
+                    for (int q = 0; q < NEG_BATCH; q++)
+                        if (tg[q] >= 0) neg_update_serial<DCH, POL>(l1, neu, syn1neg, tg[q], lane, alpha, s_exp);
+                }
+            }
+        }
+        if (P::LOCKED) {    // positive target last: its row lives in registers, its delta in LDS
+            float f = row_dot(l1, h);
+            float g = sgns_g(f, 1.0f, alpha, s_exp);
+            row_axpy(neu, g, h);
+            row_axpy(h, g, l1);
+            float* d = my_dh + cur_buf * DCH * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < DCH; q++) {
+                d[q * 64] = fmaf(g, l1.v[q].x, d[q * 64]); d[q * 64 + 16] = fmaf(g, l1.v[q].y, d[q * 64 + 16]);
+                d[q * 64 + 32] = fmaf(g, l1.v[q].z, d[q * 64 + 32]); d[q * 64 + 48] = fmaf(g, l1.v[q].w, d[q * 64 + 48]);
+            }
+            h_dirty = true;
+        }
+        if (P::SYN0_ATOMIC) {
+            row_atomic_axpy(syn0, last, lane, 1.0f, neu);
+        } else {
+#pragma unroll
+            for (int q = 0; q < DCH; q++) {
+                l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
+            }
+            row_store<DCH, P::STORE_AUX>(l1, syn0, last, lane);
+        }
+        my_pairs++;
+        c++;
+        if (c == i) c++;
     }
+    DGE_CLOSE_CENTRE();
+    if (P::LOCKED && pend_row >= 0) flush_blocking<DCH, POL>(syn1neg, p.locks, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane);
+#undef DGE_TOK
+#undef DGE_CLOSE_CENTRE
     if (lane == 0) {
         if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
         if (my_words) atomicAdd(&p.counters[1], my_words);
@@ -442,7 +609,7 @@ extern "C" int dge_count_tokens(const dge_walks* w, int64_t row0, int64_t n_rows
 static void model_release(dge_model* m) {
     dge_dev_free(m->d_syn0); dge_dev_free(m->d_syn1neg); dge_dev_free(m->d_snap); dge_dev_free(m->d_vocab_ids);
     dge_dev_free(m->d_counts); dge_dev_free(m->d_remap); dge_dev_free(m->d_table); dge_dev_free(m->d_exp);
-    dge_dev_free(m->d_sen); dge_dev_free(m->d_len); dge_dev_free(m->d_wb); dge_dev_free(m->d_scan_tmp); dge_dev_free(m->d_counters);
+    dge_dev_free(m->d_sen); dge_dev_free(m->d_len); dge_dev_free(m->d_wb); dge_dev_free(m->d_scan_tmp); dge_dev_free(m->d_counters); dge_dev_free(m->d_locks);
     for (auto& e : m->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
 }
@@ -572,6 +739,8 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     MC(dge_dev_alloc(&m->d_syn0, tab + 64)); MC(dge_dev_alloc(&m->d_syn1neg, tab + 64));
     MH(hipMemsetAsync(m->d_syn1neg, 0, (tab + 64) * sizeof(float), st));
     if (V) hipLaunchKernelGGL(k_init_syn0, dim3(grid_for(V, 256)), dim3(256), 0, st, m->d_syn0, V, m->D, m->stride, cfg->seed);
+    MC(dge_dev_alloc(&m->d_locks, (size_t)V + 1));
+    MH(hipMemsetAsync(m->d_locks, 0, ((size_t)V + 1) * sizeof(int), st));
     MC(dge_dev_alloc(&m->d_counters, 2));
     MH(hipMemsetAsync(m->d_counters, 0, 2 * sizeof(unsigned long long), st));
     MH(hipStreamSynchronize(st));
@@ -605,6 +774,7 @@ static void launch_train(const TrainParams& p, int pol, unsigned blocks, unsigne
     switch (pol) {
         case 0: hipLaunchKernelGGL((k_sgns_train<DCH, 0>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 4: hipLaunchKernelGGL((k_sgns_train<DCH, 4>), dim3(blocks), dim3(threads), 0, st, p); break;
         default: hipLaunchKernelGGL((k_sgns_train<DCH, 2>), dim3(blocks), dim3(threads), 0, st, p); break;
     }
 }
@@ -630,6 +800,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.words_scale = words_scale;
     p.alpha0 = m->cfg.alpha; p.min_alpha = m->cfg.min_alpha;
     p.counters = m->d_counters;
+    p.locks = m->d_locks;
 
     int64_t workers;
     if (m->cfg.workers == 0) {
@@ -638,13 +809,14 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
         hipDeviceProp_t prop;
         DGE_HIP(hipGetDeviceProperties(&prop, m->device));
-        workers = (int64_t)prop.multiProcessorCount * 4 * 16;
+        const int blocks_per_cu = m->cfg.update_policy == 4 ? 3 : 4;   // what the kernel's VGPR budget keeps resident
+        workers = (int64_t)prop.multiProcessorCount * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
     } else workers = m->cfg.workers;
     p.n_workers = workers;
     // update policy (see Policy<> and dge_train_config.update_policy)
-    int pol = workers == 1 ? 0 : (m->cfg.update_policy == 1 ? 1 : (m->cfg.update_policy == 3 ? 0 : 2));
+    int pol = workers == 1 ? 0 : (m->cfg.update_policy == 1 ? 1 : (m->cfg.update_policy == 3 ? 0 : (m->cfg.update_policy == 4 ? 4 : 2)));
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
 
