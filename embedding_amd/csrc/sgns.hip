@@ -13,6 +13,7 @@
 // workers); workers == 1 gives the in-order schedule the oracle follows.
 #include <hipcub/hipcub.hpp>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -151,6 +152,7 @@ struct TrainParams {
 
 template <int DCH> struct Row { float4 v[DCH]; };
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 // Cache policy of the table traffic.  The eight XCDs have private L2s that are not coherent with each other, and a
 // plain store parks its line dirty in the writer's L2: with plain loads/stores every XCD would train its own stale
@@ -160,15 +162,11 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 //   POL 0  plain loads / plain stores            (workers == 1: bit-exact with the oracle)
 //   POL 1  sc1 loads / sc1 write-through stores  (Hogwild, row granularity: last writer of a row wins)
 //   POL 2  sc1 loads / float atomic adds         (Hogwild, element granularity: no update is lost)
-//   POL 4  syn0: as POL 2.  syn1neg: every row update is a read-modify-write under that row's commit lock
-//          (one 4-byte atomic exchange to take it, one write-through store to drop it) with write-through row
-//          stores: no update is lost and a 512-B row costs 2 atomic requests instead of 8.
+//   (policy 5, every row update under a per-row commit lock, has its own kernel: k_sgns_train_locked)
 template <int POL> struct Policy {
     static constexpr int LOAD_AUX = POL == 0 ? 0 : 16;    // aux bit 4 = sc1 on gfx950
     static constexpr int STORE_AUX = POL == 0 ? 0 : 16;
-    static constexpr bool ATOMIC = POL == 2;              // syn1neg updates are float atomics
-    static constexpr bool LOCKED = POL == 4;              // syn1neg updates are locked row RMW
-    static constexpr bool SYN0_ATOMIC = POL == 2 || POL == 4;
+    static constexpr bool ATOMIC = POL == 2;              // updates are float atomics
 };
 
 // try-lock of one row: true when this lane took it.  The caller makes the row's load address depend on the result,
@@ -303,41 +301,15 @@ __device__ __forceinline__ int32_t walk_tok(bool in_regs, const int32_t* sen, in
     return __shfl(v, idx & 15, 16);
 }
 
-// LOCKED policy: add the delta row d[] (LDS) to `row` under its lock, blocking.  Used when a second centre closes
-// while the first still waits for its lock, and at the very end of a worker.
 template <int DCH, int POL>
-__device__ __forceinline__ void flush_blocking(const TableView& syn1neg, int* locks, int32_t row, const float* d, int lane) {
-    for (;;) {
-        const bool won = lane == 0 ? row_trylock(locks, row) : false;
-        const bool got = __shfl((int)won, 0, 16) != 0;
-        if (got) {
-            Row<DCH> cur;
-            row_load<DCH, Policy<POL>::LOAD_AUX>(cur, syn1neg, got ? row : 0, lane);
-#pragma unroll
-            for (int q = 0; q < DCH; q++) {
-                cur.v[q].x += d[q * 64]; cur.v[q].y += d[q * 64 + 16]; cur.v[q].z += d[q * 64 + 32]; cur.v[q].w += d[q * 64 + 48];
-            }
-            row_store<DCH, Policy<POL>::STORE_AUX>(cur, syn1neg, row, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (won) row_unlock(locks, row);
-            return;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
-template <int DCH, int POL>
-__global__ void __launch_bounds__(256, (DCH <= 2) ? (POL == 4 ? 3 : 4) : 1)
+__global__ void __launch_bounds__(256, (DCH <= 2) ? 4 : 1)
 k_sgns_train(TrainParams p) {
     using P = Policy<POL>;
     __shared__ float s_exp[EXP_TABLE_SIZE];
-    // LOCKED: per worker two delta rows for the centre's syn1neg row (current centre / centre waiting for its lock)
-    __shared__ float s_dh[P::LOCKED ? 16 * 2 * DCH * 64 : 1];
     for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 15;
-    const int wk = threadIdx.x >> 4;
     const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (worker >= p.n_workers) return;
 
@@ -363,9 +335,6 @@ k_sgns_train(TrainParams p) {
     int64_t gbase = 0;
     Row<DCH> h, dh;                                       // syn1neg[word] and (ATOMIC) its accumulated update
     bool h_dirty = false;
-    int32_t pend_row = -1;                                // LOCKED: centre row whose delta (LDS) still waits for its lock
-    int cur_buf = 0;
-    float* const my_dh = s_dh + (P::LOCKED ? (size_t)wk * 2 * DCH * 64 : 0);
 
 #define DGE_TOK(idx) walk_tok(toks_in_regs, sen, (idx), tk0, tk1, tk2, tk3)
     // close the open centre: publish what it accumulated on syn1neg[word]
@@ -374,11 +343,7 @@ k_sgns_train(TrainParams p) {
         if (h_dirty) {                                                                                             \
             h_dirty = false;                                                                                       \
             if (P::ATOMIC) row_atomic_axpy(syn1neg, word, lane, 1.0f, dh);                                         \
-            else if (P::LOCKED) {                                                                                  \
-                if (pend_row >= 0) flush_blocking<DCH, POL>(syn1neg, p.locks, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane); \
-                pend_row = word;                                                                                   \
-                cur_buf ^= 1; /* the closed centre's delta keeps its buffer; the next centre starts a fresh one */ \
-            } else row_store<DCH, P::STORE_AUX>(h, syn1neg, word, lane);                                           \
+            else row_store<DCH, P::STORE_AUX>(h, syn1neg, word, lane);                                           \
         }                                                                                                          \
     } while (0)
 
@@ -431,14 +396,9 @@ k_sgns_train(TrainParams p) {
         if (new_centre) {
             row_load<DCH, P::LOAD_AUX>(h, syn1neg, word, lane);
             if (P::ATOMIC) row_zero(dh);
-            if (P::LOCKED) {
-                float* d = my_dh + cur_buf * DCH * 64 + lane;
-#pragma unroll
-                for (int q = 0; q < DCH; q++) { d[q * 64] = 0.f; d[q * 64 + 16] = 0.f; d[q * 64 + 32] = 0.f; d[q * 64 + 48] = 0.f; }
-            }
         }
         row_zero(neu);
-        if (!P::LOCKED) {   // d == 0: target = word, label 1 (word2vec order: positive first)
+        {   // d == 0: target = word, label 1 (word2vec order: positive first)
             float f = row_dot(l1, h);
             float g = sgns_g(f, 1.0f, alpha, s_exp);
             row_axpy(neu, g, h);
@@ -446,9 +406,9 @@ k_sgns_train(TrainParams p) {
             if (P::ATOMIC) row_axpy(dh, g, l1);
             h_dirty = true;
         }
-        for (int kd = 0; kd < K; kd += 15) {
-            const int kc = min(15, K - kd);
-            // lane j draws negative kd+j (lanes 0..14; lane 15 carries the pending centre flush of the LOCKED policy)
+        for (int kd = 0; kd < K; kd += 16) {
+            const int kc = min(16, K - kd);
+            // lane j draws negative kd+j
             const uint64_t sl = s * mA + cA;
             int32_t t = -1;
             if (lane < kc) {
@@ -457,59 +417,12 @@ k_sgns_train(TrainParams p) {
                 if (t == word) t = -1;
             }
             s = shfl16_u64(sl, kc - 1);
-            if (P::LOCKED && lane == 15) t = pend_row;
             for (int base = 0; base < kc; base += NEG_BATCH) {
                 int32_t tg[NEG_BATCH];
 #pragma unroll
                 for (int q = 0; q < NEG_BATCH; q++) {
                     int32_t v = __shfl(t, (base + q) & 15, 16);
                     tg[q] = (base + q < kc) ? v : -1;
-                }
-                if (P::LOCKED) {
-                    // rounds of { try-lock every pending row of the batch (lane base+q takes slot q, lane 15 the pending
-                    // centre flush) -> rows won are loaded, updated, written through, unlocked }.  Nothing is held while
-                    // waiting, so there is no hold-and-wait cycle; a row drawn twice is won in two different rounds.
-                    unsigned pending = 0;
-#pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) pending |= (tg[q] >= 0 ? 1u : 0u) << q;
-                    bool flush_pending = base == 0 && pend_row >= 0;
-                    while (pending) {
-                        const int myq = lane - base;
-                        const bool want = (myq >= 0 && myq < NEG_BATCH && ((pending >> myq) & 1u)) || (lane == 15 && flush_pending);
-                        const bool won = want ? row_trylock(p.locks, t) : false;
-                        const unsigned long long bal = __ballot(won);
-                        const unsigned gotl = (unsigned)(bal >> ((threadIdx.x & 48))) & 0xFFFFu;     // this group's 16 lanes
-                        const unsigned got = (gotl >> base) & ((1u << NEG_BATCH) - 1u) & pending;
-                        const bool gotf = flush_pending && ((gotl >> 15) & 1u);
-                        Row<DCH> rr[NEG_BATCH], fr;
-#pragma unroll
-                        for (int q = 0; q < NEG_BATCH; q++)
-                            row_load<DCH, P::LOAD_AUX>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : word, lane);
-                        if (flush_pending) row_load<DCH, P::LOAD_AUX>(fr, syn1neg, gotf ? pend_row : word, lane);
-#pragma unroll
-                        for (int q = 0; q < NEG_BATCH; q++)
-                            if ((got >> q) & 1u) {
-                                float f = row_dot(l1, rr[q]);
-                                float g = sgns_g(f, 0.0f, alpha, s_exp);
-                                row_axpy(neu, g, rr[q]);
-                                row_axpy(rr[q], g, l1);
-                                row_store<DCH, P::STORE_AUX>(rr[q], syn1neg, tg[q], lane);
-                            }
-                        if (gotf) {
-                            const float* d = my_dh + (cur_buf ^ 1) * DCH * 64 + lane;
-#pragma unroll
-                            for (int q = 0; q < DCH; q++) {
-                                fr.v[q].x += d[q * 64]; fr.v[q].y += d[q * 64 + 16]; fr.v[q].z += d[q * 64 + 32]; fr.v[q].w += d[q * 64 + 48];
-                            }
-                            row_store<DCH, P::STORE_AUX>(fr, syn1neg, pend_row, lane);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // drain the row stores
-                        if (won) row_unlock(p.locks, t);
-                        pending &= ~got;
-                        if (gotf) { flush_pending = false; pend_row = -1; if (lane == 15) t = -1; }
-                        if (pending) __builtin_amdgcn_s_sleep(2);
-                    }
-                    continue;
                 }
                 bool dup = false;
                 if (!P::ATOMIC) {
@@ -544,20 +457,7 @@ k_sgns_train(TrainParams p) {
                 }
             }
         }
-        if (P::LOCKED) {    // positive target last: its row lives in registers, its delta in LDS
-            float f = row_dot(l1, h);
-            float g = sgns_g(f, 1.0f, alpha, s_exp);
-            row_axpy(neu, g, h);
-            row_axpy(h, g, l1);
-            float* d = my_dh + cur_buf * DCH * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < DCH; q++) {
-                d[q * 64] = fmaf(g, l1.v[q].x, d[q * 64]); d[q * 64 + 16] = fmaf(g, l1.v[q].y, d[q * 64 + 16]);
-                d[q * 64 + 32] = fmaf(g, l1.v[q].z, d[q * 64 + 32]); d[q * 64 + 48] = fmaf(g, l1.v[q].w, d[q * 64 + 48]);
-            }
-            h_dirty = true;
-        }
-        if (P::SYN0_ATOMIC) {
+        if (P::ATOMIC) {
             row_atomic_axpy(syn0, last, lane, 1.0f, neu);
         } else {
 #pragma unroll
@@ -571,9 +471,281 @@ k_sgns_train(TrainParams p) {
         if (c == i) c++;
     }
     DGE_CLOSE_CENTRE();
-    if (P::LOCKED && pend_row >= 0) flush_blocking<DCH, POL>(syn1neg, p.locks, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane);
 #undef DGE_TOK
 #undef DGE_CLOSE_CENTRE
+    if (lane == 0) {
+        if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
+        if (my_words) atomicAdd(&p.counters[1], my_words);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ all-locked Hogwild trainer
+// POL 5: every row update of BOTH tables is a read-modify-write under that row's commit lock, rows move as 16 bytes
+// per lane (lane j owns elements 64c+4j..64c+4j+3: one dwordx4 per chunk, a whole 256-B chunk per group and
+// instruction).  Measured on cfg3 (ablations in DESIGN.md §5.1): the write-through stores of the 4-byte-per-lane layout
+// that the float atomics need cost more than everything else in the pair; with 16-byte stores and 2 small atomic
+// requests per row (take / drop the lock) the pair is bounded by its HBM traffic again.
+// Lock order: the pair's syn0 row first (together with the first batch of syn1neg try-locks; if it is not won,
+// everything won in that round is dropped again and the round is repeated), then syn1neg rows in try-lock rounds that
+// never wait while holding a syn1neg lock: no hold-and-wait cycle exists.
+template <int DCH, int AUX>
+__device__ __forceinline__ void rowA_load(Row<DCH>& r, const TableView& t, int32_t row, int lane) {
+    const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 16u;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        // NOTE (hipcc 7.2): bit-casting the ELEMENTS of the loaded <4 x i32> lets the optimiser narrow the load to one
+        // dword (wrong data in y/z/w); casting the whole vector keeps the dwordx4.
+        const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(t.rsrc, (int)(off + c * 256u), 0, AUX));
+        r.v[c] = make_float4(f.x, f.y, f.z, f.w);
+    }
+}
+template <int DCH, int AUX>
+__device__ __forceinline__ void rowA_store(const Row<DCH>& r, const TableView& t, int32_t row, int lane) {
+    const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 16u;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        v4f f;
+        f.x = r.v[c].x; f.y = r.v[c].y; f.z = r.v[c].z; f.w = r.v[c].w;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), t.rsrc, (int)(off + c * 256u), 0, AUX);
+    }
+}
+
+template <int DCH>
+__device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* locks, int32_t row, const float* d, int lane) {
+    for (;;) {
+        const bool won = lane == 0 ? row_trylock(locks, row) : false;
+        const bool got = __shfl((int)won, 0, 16) != 0;
+        if (got) {
+            Row<DCH> cur;
+            rowA_load<DCH, 16>(cur, syn1neg, got ? row : 0, lane);
+#pragma unroll
+            for (int q = 0; q < DCH; q++) {
+                cur.v[q].x += d[q * 64]; cur.v[q].y += d[q * 64 + 16]; cur.v[q].z += d[q * 64 + 32]; cur.v[q].w += d[q * 64 + 48];
+            }
+            rowA_store<DCH, 16>(cur, syn1neg, row, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (won) row_unlock(locks, row);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+#define LK_NEG_LANES 13      /* lanes 0..12 draw negatives, lane 13 = pending centre flush, lane 14 = the pair's syn0 row */
+template <int DCH>
+__global__ void __launch_bounds__(256, DCH <= 2 ? 3 : 1)
+k_sgns_train_locked(TrainParams p) {
+    __shared__ float s_exp[EXP_TABLE_SIZE];
+    __shared__ float s_dh[16 * 2 * DCH * 64];
+    for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 15;
+    const int wk = threadIdx.x >> 4;
+    const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (worker >= p.n_workers) return;
+
+    const TableView syn0 = make_view(p.syn0, p.V, p.stride);
+    const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride);
+    int* const locks1 = p.locks;
+    int* const locks0 = p.locks + p.V + 1;
+
+    uint64_t mA = 1, cA = 0;
+    for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
+
+    const int L = p.L, W = p.W, K = p.K;
+    const bool toks_in_regs = L <= 64;
+    unsigned long long my_pairs = 0, my_words = 0;
+
+    int64_t w = worker - p.n_workers;
+    int len = 0, i = 0, c = 1, c_hi = 0;
+    int32_t tk0 = -1, tk1 = -1, tk2 = -1, tk3 = -1;
+    const int32_t* sen = p.sen;
+    int32_t word = 0;
+    float alpha = 0.f;
+    uint64_t s = 0;
+    int64_t gbase = 0;
+    Row<DCH> h;
+    bool h_dirty = false;
+    int32_t pend_row = -1;
+    int cur_buf = 0;
+    float* const my_dh = s_dh + (size_t)wk * 2 * DCH * 64;
+    bool retry_pair = false;      // the pair's syn0 row was busy: same pair again on the next trip through the loop
+    int32_t t_first = -1;         // this lane's slot of the pair's first chunk (kept across a retry: the draw is not repeated)
+    int32_t last = 0;
+
+#define LK_TOK(idx) walk_tok(toks_in_regs, sen, (idx), tk0, tk1, tk2, tk3)
+#define LK_CLOSE_CENTRE()                                                                                              \
+    do {                                                                                                               \
+        if (h_dirty) {                                                                                                 \
+            h_dirty = false;                                                                                           \
+            if (pend_row >= 0) flushA_blocking<DCH>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane); \
+            pend_row = word;                                                                                           \
+            cur_buf ^= 1;                                                                                              \
+        }                                                                                                              \
+    } while (0)
+
+    for (;;) {
+        bool new_centre = false, alive = true;
+        while (!retry_pair && c > c_hi) {
+            LK_CLOSE_CENTRE();
+            i++;
+            while (i >= len) {
+                w += p.n_workers;
+                if (w >= p.n_rows) { alive = false; break; }
+                len = (int)p.len[w];
+                i = 0;
+                if (len > 0) {
+                    my_words += (unsigned long long)len;
+                    sen = p.sen + w * L;
+                    if (toks_in_regs) {
+                        tk0 = lane < L ? sen[lane] : -1;
+                        tk1 = lane + 16 < L ? sen[lane + 16] : -1;
+                        tk2 = lane + 32 < L ? sen[lane + 32] : -1;
+                        tk3 = lane + 48 < L ? sen[lane + 48] : -1;
+                    }
+                    const int64_t wbw = p.wb[w];
+                    const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
+                    alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
+                    if (alpha < p.min_alpha) alpha = p.min_alpha;
+                    gbase = (p.gidx_base + w) * (int64_t)L;
+                }
+            }
+            if (!alive) break;
+            word = LK_TOK(i);
+            s = dge_mix64(p.seed + (uint64_t)(gbase + i));
+            s = s * DGE_W2V_MULT + 11;
+            const int radius = W - (int)(s % (uint64_t)W);
+            c = max(0, i - radius);
+            c_hi = min(len - 1, i + radius);
+            if (c_hi == i) c_hi--;
+            if (c == i) c++;
+            new_centre = true;
+        }
+        if (!alive) break;
+        if (!retry_pair) last = LK_TOK(c);
+
+        Row<DCH> l1, neu;
+        if (new_centre) {
+            rowA_load<DCH, 16>(h, syn1neg, word, lane);       // unlocked read: stale by at most the updates in flight
+            float* d = my_dh + cur_buf * DCH * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < DCH; q++) { d[q * 64] = 0.f; d[q * 64 + 16] = 0.f; d[q * 64 + 32] = 0.f; d[q * 64 + 48] = 0.f; }
+        }
+        row_zero(neu);
+        bool have_l1 = false, abort_pair = false;
+        int kd = 0;
+        do {    // chunks of up to 13 negatives (at least one pass so that the syn0 row is locked and loaded even when K == 0)
+            const int kc = min(LK_NEG_LANES, K - kd);
+            int32_t t = -1;
+            if (retry_pair && kd == 0) {
+                t = t_first;
+            } else {
+                const uint64_t sl = s * mA + cA;
+                if (lane < kc) {
+                    t = p.table[(sl >> 16) % (uint64_t)p.T];
+                    if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                    if (t == word) t = -1;
+                }
+                if (kc > 0) s = shfl16_u64(sl, kc - 1);
+                if (kd == 0) t_first = t;
+            }
+            if (lane == 13) t = pend_row;
+            if (lane == 14) t = last;
+            int base = 0;
+            do {
+                int32_t tg[NEG_BATCH];
+#pragma unroll
+                for (int q = 0; q < NEG_BATCH; q++) {
+                    int32_t v = __shfl(t, (base + q) & 15, 16);
+                    tg[q] = (base + q < kc) ? v : -1;
+                }
+                unsigned pending = 0;
+#pragma unroll
+                for (int q = 0; q < NEG_BATCH; q++) pending |= (tg[q] >= 0 ? 1u : 0u) << q;
+                bool flush_pending = base == 0 && pend_row >= 0;
+                while (pending || !have_l1) {
+                    const int myq = lane - base;
+                    const bool want = (myq >= 0 && myq < NEG_BATCH && lane < kc && ((pending >> myq) & 1u)) ||
+                                      (lane == 13 && flush_pending) || (lane == 14 && !have_l1);
+                    const bool won = want ? row_trylock(lane == 14 ? locks0 : locks1, t) : false;
+                    const unsigned long long bal = __ballot(won);
+                    const unsigned gotl = (unsigned)(bal >> (threadIdx.x & 48)) & 0xFFFFu;
+                    if (!have_l1 && !((gotl >> 14) & 1u)) {
+                        // the pair's syn0 row is busy (possibly held by another group of THIS wave, which can only drop it
+                        // once this group stops looping): drop whatever this round won and leave the pair for the next
+                        // trip through the outer loop — no waiting while holding, no spinning under divergence
+                        if (won) row_unlock(lane == 14 ? locks0 : locks1, t);
+                        abort_pair = true;
+                        break;
+                    }
+                    const bool got_l1 = !have_l1;
+                    const unsigned got = (gotl >> base) & ((1u << NEG_BATCH) - 1u) & pending;
+                    const bool gotf = flush_pending && ((gotl >> 13) & 1u);
+                    Row<DCH> rr[NEG_BATCH], fr;
+                    if (got_l1) rowA_load<DCH, 16>(l1, syn0, (gotl >> 14) & 1u ? last : 0, lane);
+#pragma unroll
+                    for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : word, lane);
+                    if (flush_pending) rowA_load<DCH, 16>(fr, syn1neg, gotf ? pend_row : word, lane);
+                    have_l1 = true;
+#pragma unroll
+                    for (int q = 0; q < NEG_BATCH; q++)
+                        if ((got >> q) & 1u) {
+                            float f = row_dot(l1, rr[q]);
+                            float g = sgns_g(f, 0.0f, alpha, s_exp);
+                            row_axpy(neu, g, rr[q]);
+                            row_axpy(rr[q], g, l1);
+                            rowA_store<DCH, 16>(rr[q], syn1neg, tg[q], lane);
+                        }
+                    if (gotf) {
+                        const float* d = my_dh + (cur_buf ^ 1) * DCH * 64 + lane;
+#pragma unroll
+                        for (int q = 0; q < DCH; q++) {
+                            fr.v[q].x += d[q * 64]; fr.v[q].y += d[q * 64 + 16]; fr.v[q].z += d[q * 64 + 32]; fr.v[q].w += d[q * 64 + 48];
+                        }
+                        rowA_store<DCH, 16>(fr, syn1neg, pend_row, lane);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // drain the row stores
+                    if (won && lane != 14) row_unlock(locks1, t);
+                    pending &= ~got;
+                    if (gotf) { flush_pending = false; pend_row = -1; if (lane == 13) t = -1; }
+                    if (pending) __builtin_amdgcn_s_sleep(2);
+                }
+                base += NEG_BATCH;
+            } while (base < kc && !abort_pair);
+            kd += LK_NEG_LANES;
+        } while (kd < K && !abort_pair);
+        if (abort_pair) { retry_pair = true; __builtin_amdgcn_s_sleep(4); continue; }
+        retry_pair = false;
+
+        {   // positive target: the centre's row lives in registers, its delta in LDS
+            float f = row_dot(l1, h);
+            float g = sgns_g(f, 1.0f, alpha, s_exp);
+            row_axpy(neu, g, h);
+            row_axpy(h, g, l1);
+            float* d = my_dh + cur_buf * DCH * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < DCH; q++) {
+                d[q * 64] = fmaf(g, l1.v[q].x, d[q * 64]); d[q * 64 + 16] = fmaf(g, l1.v[q].y, d[q * 64 + 16]);
+                d[q * 64 + 32] = fmaf(g, l1.v[q].z, d[q * 64 + 32]); d[q * 64 + 48] = fmaf(g, l1.v[q].w, d[q * 64 + 48]);
+            }
+            h_dirty = true;
+        }
+#pragma unroll
+        for (int q = 0; q < DCH; q++) {
+            l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
+        }
+        rowA_store<DCH, 16>(l1, syn0, last, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 14) row_unlock(locks0, last);
+        my_pairs++;
+        c++;
+        if (c == i) c++;
+    }
+    LK_CLOSE_CENTRE();
+    if (pend_row >= 0) flushA_blocking<DCH>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane);
+#undef LK_TOK
+#undef LK_CLOSE_CENTRE
     if (lane == 0) {
         if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
         if (my_words) atomicAdd(&p.counters[1], my_words);
@@ -739,8 +911,8 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     MC(dge_dev_alloc(&m->d_syn0, tab + 64)); MC(dge_dev_alloc(&m->d_syn1neg, tab + 64));
     MH(hipMemsetAsync(m->d_syn1neg, 0, (tab + 64) * sizeof(float), st));
     if (V) hipLaunchKernelGGL(k_init_syn0, dim3(grid_for(V, 256)), dim3(256), 0, st, m->d_syn0, V, m->D, m->stride, cfg->seed);
-    MC(dge_dev_alloc(&m->d_locks, (size_t)V + 1));
-    MH(hipMemsetAsync(m->d_locks, 0, ((size_t)V + 1) * sizeof(int), st));
+    MC(dge_dev_alloc(&m->d_locks, 2 * ((size_t)V + 1)));      // [0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows
+    MH(hipMemsetAsync(m->d_locks, 0, 2 * ((size_t)V + 1) * sizeof(int), st));
     MC(dge_dev_alloc(&m->d_counters, 2));
     MH(hipMemsetAsync(m->d_counters, 0, 2 * sizeof(unsigned long long), st));
     MH(hipStreamSynchronize(st));
@@ -774,7 +946,7 @@ static void launch_train(const TrainParams& p, int pol, unsigned blocks, unsigne
     switch (pol) {
         case 0: hipLaunchKernelGGL((k_sgns_train<DCH, 0>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 4: hipLaunchKernelGGL((k_sgns_train<DCH, 4>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH>), dim3(blocks), dim3(threads), 0, st, p); break;
         default: hipLaunchKernelGGL((k_sgns_train<DCH, 2>), dim3(blocks), dim3(threads), 0, st, p); break;
     }
 }
@@ -809,14 +981,18 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
         hipDeviceProp_t prop;
         DGE_HIP(hipGetDeviceProperties(&prop, m->device));
-        const int blocks_per_cu = m->cfg.update_policy == 4 ? 3 : 4;   // what the kernel's VGPR budget keeps resident
+        const int blocks_per_cu = (m->cfg.update_policy == 5 || (m->cfg.update_policy == 0 && m->V >= 262144)) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)prop.multiProcessorCount * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
     } else workers = m->cfg.workers;
     p.n_workers = workers;
     // update policy (see Policy<> and dge_train_config.update_policy)
-    int pol = workers == 1 ? 0 : (m->cfg.update_policy == 1 ? 1 : (m->cfg.update_policy == 3 ? 0 : (m->cfg.update_policy == 4 ? 4 : 2)));
+    // update policy (see Policy<>, k_sgns_train_locked and dge_train_config.update_policy)
+    int pol = m->cfg.update_policy;
+    if (pol == 0) pol = workers == 1 ? 100 : (m->V >= 262144 ? 5 : 2);   // auto
+    if (pol == 100 || (workers == 1 && pol != 5 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
+    if (pol == 3) pol = 0;
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
 

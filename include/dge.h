@@ -127,11 +127,14 @@ typedef struct dge_train_config {
     uint64_t seed;
     int64_t table_size;      /* unigram^0.75 table length; 0 -> 100000000 (word2vec.c) */
     int32_t n_vertices;      /* vertex-id space of the corpus */
-    int32_t update_policy;   /* how concurrent workers update the tables (MI355X has 8 non-coherent L2s):
-                                0 = auto (atomic), 1 = agent-scope row read-modify-write (write-through; the last
-                                writer of a row wins, classic Hogwild), 2 = memory-side float atomics (no update is
-                                lost), 3 = plain cached accesses (debug only: XCDs train private stale copies).
-                                Ignored when workers == 1 (in-order, plain). */
+    int32_t update_policy;   /* how concurrent workers update the tables (MI355X has 8 L2s that are not coherent):
+                                0 = auto: 5 when the vocabulary has >= 262144 rows, else 2;
+                                1 = agent-scope row read-modify-write, write-through (last writer of a row wins);
+                                2 = agent-scope loads + memory-side float atomics (no update is lost);
+                                3 = plain cached accesses (debug only: every XCD trains a private stale copy);
+                                5 = every row update under that row's commit lock, 16-byte write-through rows
+                                    (no update is lost; fastest when collisions are sparse).
+                                workers == 1 with policy 0/3 is the in-order schedule with plain accesses. */
 } dge_train_config;
 
 typedef struct dge_train_stats {
