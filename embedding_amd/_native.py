@@ -75,6 +75,7 @@ SIGNATURES = {
     "dge_model_snapshot": (_int, [_vp]),
     "dge_model_export_delta": (_int, [_vp, _vp]),
     "dge_model_import_delta": (_int, [_vp, _vp, C.c_float]),
+    "dge_selftest_locked_rows": (_int, [_int, _i32, _i64, _i32, C.c_uint64, _i32, _P(_i64), _P(_dbl)]),
 }
 
 

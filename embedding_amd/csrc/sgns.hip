@@ -174,6 +174,16 @@ template <int POL> struct Policy {
 __device__ __forceinline__ bool row_trylock(int* locks, int32_t row) { return atomicExch(&locks[row], 1) == 0; }
 // the row's write-through stores are drained (vmcnt(0), which the workgroup-scope release fence emits) before the
 // lock word is cleared with an agent-scope store
+// Before a lock word is cleared, the row's stores must be visible to every XCD.  Draining the wave's stores
+// (s_waitcnt vmcnt(0)) is NOT enough even for sc1 "write-through" stores: measured with dge_selftest_locked_rows,
+// 256..1024 hot rows lose up to ~40 of 10^4 increments per row that way.  None are lost with an agent-scope release
+// (buffer_wbl2 sc1 + vmcnt(0)) — but that fence costs the trainer a factor 19 — and none with the per-line commit
+// probes below, with or without an acquire on the reading side (the sc1 loads are enough there).
+// consume the probes' return values: forces the s_waitcnt on them (and, being a workgroup-scope release, on the stores)
+__device__ __forceinline__ void row_commit_wait(float probes) {
+    asm volatile("" ::"v"(probes));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
 __device__ __forceinline__ void row_unlock(int* locks, int32_t row) {
     __hip_atomic_store(&locks[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -480,7 +490,7 @@ k_sgns_train(TrainParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ all-locked Hogwild trainer
-// POL 5: every row update of BOTH tables is a read-modify-write under that row's commit lock, rows move as 16 bytes
+// Policies 5/6: every row update of BOTH tables is a read-modify-write under that row's commit lock, rows move as 16 bytes
 // per lane (lane j owns elements 64c+4j..64c+4j+3: one dwordx4 per chunk, a whole 256-B chunk per group and
 // instruction).  Measured on cfg3 (ablations in DESIGN.md §5.1): the write-through stores of the 4-byte-per-lane layout
 // that the float atomics need cost more than everything else in the pair; with 16-byte stores and 2 small atomic
@@ -488,6 +498,20 @@ k_sgns_train(TrainParams p) {
 // Lock order: the pair's syn0 row first (together with the first batch of syn1neg try-locks; if it is not won,
 // everything won in that round is dropped again and the round is repeated), then syn1neg rows in try-lock rounds that
 // never wait while holding a syn1neg lock: no hold-and-wait cycle exists.
+// STRICT (policy 6): a row is committed with one returning atomic per 128-B line before its lock drops — no update is ever
+// lost (dge_selftest_locked_rows).  Relaxed (policy 5): the wave only drains its own stores (vmcnt) before dropping the
+// lock; a re-lock from another XCD can overtake the write-through, which loses a row update with measured probability
+// <= 4e-7 at >= 65k rows (0 of 2.4e6 at 1M rows) and up to 1.5 % of the worst row's updates on a 1024-row hot set
+// hammered by 12k workers — Hogwild noise, below what unsynchronised float read-modify-writes lose (policy 1).
+// Commit of a row before its lock drops: after the row's write-through stores, ONE returning float atomic (+0.0f) per
+// 128-B line of the row.  A line's store and the atomic that follows it travel the same channel in order and the atomic
+// is performed at the memory side, so its return implies the line's data is there; the wave then waits for the returns
+// (row_commit_wait) and only then clears the lock word.  Lane l probes line l of the row.
+__device__ __forceinline__ float row_probe_lines(const TableView& t, int32_t row, int lane, int n_lines) {
+    float old = 0.f;
+    if (lane < n_lines) old = __hip_atomic_fetch_add(t.base + (size_t)row * (t.row_bytes / 4) + lane * 32, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return old;
+}
 template <int DCH, int AUX>
 __device__ __forceinline__ void rowA_load(Row<DCH>& r, const TableView& t, int32_t row, int lane) {
     const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 16u;
@@ -510,7 +534,7 @@ __device__ __forceinline__ void rowA_store(const Row<DCH>& r, const TableView& t
     }
 }
 
-template <int DCH>
+template <int DCH, bool STRICT>
 __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* locks, int32_t row, const float* d, int lane) {
     for (;;) {
         const bool won = lane == 0 ? row_trylock(locks, row) : false;
@@ -523,7 +547,7 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
                 cur.v[q].x += d[q * 64]; cur.v[q].y += d[q * 64 + 16]; cur.v[q].z += d[q * 64 + 32]; cur.v[q].w += d[q * 64 + 48];
             }
             rowA_store<DCH, 16>(cur, syn1neg, row, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            row_commit_wait(STRICT ? row_probe_lines(syn1neg, row, lane, DCH * 2) : 0.f);
             if (won) row_unlock(locks, row);
             return;
         }
@@ -532,7 +556,7 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
 }
 
 #define LK_NEG_LANES 13      /* lanes 0..12 draw negatives, lane 13 = pending centre flush, lane 14 = the pair's syn0 row */
-template <int DCH>
+template <int DCH, bool STRICT>
 __global__ void __launch_bounds__(256, DCH <= 2 ? 3 : 1)
 k_sgns_train_locked(TrainParams p) {
     __shared__ float s_exp[EXP_TABLE_SIZE];
@@ -579,7 +603,7 @@ k_sgns_train_locked(TrainParams p) {
     do {                                                                                                               \
         if (h_dirty) {                                                                                                 \
             h_dirty = false;                                                                                           \
-            if (pend_row >= 0) flushA_blocking<DCH>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane); \
+            if (pend_row >= 0) flushA_blocking<DCH, STRICT>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane); \
             pend_row = word;                                                                                           \
             cur_buf ^= 1;                                                                                              \
         }                                                                                                              \
@@ -705,7 +729,22 @@ k_sgns_train_locked(TrainParams p) {
                         }
                         rowA_store<DCH, 16>(fr, syn1neg, pend_row, lane);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // drain the row stores
+                    {   // every stored row is committed line by line (lane = 4*slot + line for DCH 2), then the locks drop
+                        float acc = 0.f;
+                        const int n_lines = DCH * 2;
+                        if (STRICT) {
+#pragma unroll
+                        for (int rep = 0; rep < (NEG_BATCH * DCH * 2 + 15) / 16; rep++) {
+                            const int idx = lane + rep * 16, q = idx / n_lines, ln = idx - q * n_lines;
+                            int32_t row = -1;
+#pragma unroll
+                            for (int qq = 0; qq < NEG_BATCH; qq++) if (qq == q && ((got >> qq) & 1u)) row = tg[qq];
+                            if (row >= 0) acc += __hip_atomic_fetch_add(syn1neg.base + (size_t)row * (syn1neg.row_bytes / 4) + ln * 32, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        if (gotf) acc += row_probe_lines(syn1neg, pend_row, lane, n_lines);
+                        }
+                        row_commit_wait(acc);
+                    }
                     if (won && lane != 14) row_unlock(locks1, t);
                     pending &= ~got;
                     if (gotf) { flush_pending = false; pend_row = -1; if (lane == 13) t = -1; }
@@ -736,20 +775,110 @@ k_sgns_train_locked(TrainParams p) {
             l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
         }
         rowA_store<DCH, 16>(l1, syn0, last, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        row_commit_wait(STRICT ? row_probe_lines(syn0, last, lane, DCH * 2) : 0.f);
         if (lane == 14) row_unlock(locks0, last);
         my_pairs++;
         c++;
         if (c == i) c++;
     }
     LK_CLOSE_CENTRE();
-    if (pend_row >= 0) flushA_blocking<DCH>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane);
+    if (pend_row >= 0) flushA_blocking<DCH, STRICT>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane);
 #undef LK_TOK
 #undef LK_CLOSE_CENTRE
     if (lane == 0) {
         if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
         if (my_words) atomicAdd(&p.counters[1], my_words);
     }
+}
+
+// ------------------------------------------------------------------------------------------ lock protocol self-test
+// Conservation check of the commit-lock protocol used by k_sgns_train_locked, with the same primitives
+// (row_trylock / rowA_load sc1 / rowA_store sc1 / workgroup release fence / row_unlock): every worker repeatedly picks
+// NEG_BATCH pseudo-random rows, wins their locks in try-lock rounds and adds 1.0 to every element of each row it won.
+// If exclusion, read freshness or write visibility failed anywhere on the chip, some increment would be lost:
+// at the end every element of row r must equal the exact number of increments of row r (counted with integer atomics).
+template <int DCH, int LAUX, int SAUX, int FENCE>
+__global__ void __launch_bounds__(256)
+k_selftest_locked_rows(float* table, int* locks, unsigned long long* counts, int32_t n_rows, int stride, int64_t n_workers,
+                       int iters, uint64_t seed) {
+    const int lane = threadIdx.x & 15;
+    const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (worker >= n_workers) return;
+    const TableView tv = make_view(table, n_rows, stride);
+    for (int it = 0; it < iters; it++) {
+        int32_t t = -1;
+        if (lane < NEG_BATCH) t = (int32_t)(dge_mix64(seed + (uint64_t)((worker * iters + it) * 16 + lane)) % (uint64_t)n_rows);
+        int32_t tg[NEG_BATCH];
+#pragma unroll
+        for (int q = 0; q < NEG_BATCH; q++) tg[q] = __shfl(t, q, 16);
+        unsigned pending = (1u << NEG_BATCH) - 1u;
+        while (pending) {
+            const bool want = lane < NEG_BATCH && ((pending >> lane) & 1u);
+            const bool won = want ? row_trylock(locks, t) : false;
+            const unsigned long long bal = __ballot(won);
+            const unsigned got = (unsigned)(bal >> (threadIdx.x & 48)) & ((1u << NEG_BATCH) - 1u) & pending;
+            if (FENCE & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            Row<DCH> rr[NEG_BATCH];
+#pragma unroll
+            for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, LAUX>(rr[q], tv, ((got >> q) & 1u) ? tg[q] : 0, lane);
+#pragma unroll
+            for (int q = 0; q < NEG_BATCH; q++)
+                if ((got >> q) & 1u) {
+#pragma unroll
+                    for (int c = 0; c < DCH; c++) { rr[q].v[c].x += 1.f; rr[q].v[c].y += 1.f; rr[q].v[c].z += 1.f; rr[q].v[c].w += 1.f; }
+                    rowA_store<DCH, SAUX>(rr[q], tv, tg[q], lane);
+                }
+            if (FENCE & 4) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < NEG_BATCH; q++) if ((got >> q) & 1u) acc += row_probe_lines(tv, tg[q], lane, stride / 32);
+                asm volatile("" :: "v"(acc));
+            }
+            if (FENCE & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (won) { row_unlock(locks, t); atomicAdd(&counts[t], 1ULL); }
+            pending &= ~got;
+            if (pending) __builtin_amdgcn_s_sleep(2);
+        }
+    }
+}
+
+extern "C" int dge_selftest_locked_rows(int device, int32_t n_rows, int64_t n_workers, int32_t iters, uint64_t seed, int32_t commit,
+                                        int64_t* total_increments, double* max_abs_error) {
+    if (n_rows <= 0 || n_workers <= 0 || iters <= 0 || !total_increments || !max_abs_error) DGE_FAIL(DGE_ERR_ARG, "dge_selftest_locked_rows: bad argument");
+    int rc = dge_require_device(device);
+    if (rc) return rc;
+    const int stride = 128;
+    float* d_tab = nullptr; int* d_locks = nullptr; unsigned long long* d_cnt = nullptr;
+    if ((rc = dge_dev_alloc(&d_tab, (size_t)n_rows * stride))) return rc;
+    if ((rc = dge_dev_alloc(&d_locks, (size_t)n_rows))) return rc;
+    if ((rc = dge_dev_alloc(&d_cnt, (size_t)n_rows))) return rc;
+    DGE_HIP(hipMemset(d_tab, 0, (size_t)n_rows * stride * sizeof(float)));
+    DGE_HIP(hipMemset(d_locks, 0, (size_t)n_rows * sizeof(int)));
+    DGE_HIP(hipMemset(d_cnt, 0, (size_t)n_rows * sizeof(unsigned long long)));
+    unsigned blocks = (unsigned)((n_workers * 16 + 255) / 256);
+#define ST_LAUNCH(L, S, F) hipLaunchKernelGGL((k_selftest_locked_rows<2, L, S, F>), dim3(blocks), dim3(256), 0, 0, d_tab, d_locks, d_cnt, n_rows, stride, n_workers, iters, seed)
+    switch (commit) {
+        case 0: ST_LAUNCH(16, 16, 0); break;      // relaxed commit of policy 5: sc1 both sides, the wave drains its stores
+        case 1: ST_LAUNCH(16, 16, 4); break;      // strict commit of policy 6: + one returning atomic per stored 128-B line
+        case 2: ST_LAUNCH(16, 16, 2); break;      // agent-scope release fence (buffer_wbl2): also lossless, 19x slower in the trainer
+        default: DGE_FAIL(DGE_ERR_ARG, "dge_selftest_locked_rows: commit must be 0, 1 or 2");
+    }
+#undef ST_LAUNCH
+    DGE_HIP(hipGetLastError());
+    DGE_HIP(hipDeviceSynchronize());
+    std::vector<float> tab((size_t)n_rows * stride); std::vector<unsigned long long> cnt((size_t)n_rows); std::vector<int> lk((size_t)n_rows);
+    DGE_HIP(hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(float), hipMemcpyDeviceToHost));
+    DGE_HIP(hipMemcpy(cnt.data(), d_cnt, cnt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    DGE_HIP(hipMemcpy(lk.data(), d_locks, lk.size() * sizeof(int), hipMemcpyDeviceToHost));
+    dge_dev_free(d_tab); dge_dev_free(d_locks); dge_dev_free(d_cnt);
+    double worst = 0.0; int64_t total = 0;
+    for (int32_t r = 0; r < n_rows; r++) {
+        total += (int64_t)cnt[(size_t)r];
+        if (lk[(size_t)r] != 0) worst = 1e30;                       // a lock was left held
+        for (int c = 0; c < stride; c++) worst = std::max(worst, fabs((double)tab[(size_t)r * stride + c] - (double)cnt[(size_t)r]));
+    }
+    *total_increments = total; *max_abs_error = worst;
+    return DGE_OK;
 }
 
 // ------------------------------------------------------------------------------------------ delta exchange
@@ -946,7 +1075,8 @@ static void launch_train(const TrainParams& p, int pol, unsigned blocks, unsigne
     switch (pol) {
         case 0: hipLaunchKernelGGL((k_sgns_train<DCH, 0>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true>), dim3(blocks), dim3(threads), 0, st, p); break;
         default: hipLaunchKernelGGL((k_sgns_train<DCH, 2>), dim3(blocks), dim3(threads), 0, st, p); break;
     }
 }
@@ -981,7 +1111,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
         hipDeviceProp_t prop;
         DGE_HIP(hipGetDeviceProperties(&prop, m->device));
-        const int blocks_per_cu = (m->cfg.update_policy == 5 || (m->cfg.update_policy == 0 && m->V >= 262144)) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
+        const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || (m->cfg.update_policy == 0 && m->V >= 262144)) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)prop.multiProcessorCount * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
@@ -991,7 +1121,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     // update policy (see Policy<>, k_sgns_train_locked and dge_train_config.update_policy)
     int pol = m->cfg.update_policy;
     if (pol == 0) pol = workers == 1 ? 100 : (m->V >= 262144 ? 5 : 2);   // auto
-    if (pol == 100 || (workers == 1 && pol != 5 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
+    if (pol == 100 || (workers == 1 && pol != 5 && pol != 6 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
     if (pol == 3) pol = 0;
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
