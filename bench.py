@@ -158,7 +158,9 @@ def main():
                        "sgns_workers": args.workers, "update_policy": args.policy, "parallelism": "walk-shard x%d, RCCL all-reduce of deltas per step" % N if N > 1 else "1 GPU",
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "k_sgns_train", "ms_per_launch": ms_per_launch,
+                         "traffic": measured_traffic(args.workload, args.policy, pairs_per_launch),
+                         "kernel": "k_sgns_train_locked" if (args.policy in (5, 6) or (args.policy == 0 and NV >= 262144)) else "k_sgns_train",
+                         "ms_per_launch": ms_per_launch,
                          "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
                          "walk_kernel_ms_per_launch": st["walk_kernel_ms"] / launches},
         }
@@ -172,12 +174,29 @@ def main():
         dist.destroy_process_group()
 
 
+def measured_traffic(workload, policy, pairs_per_launch):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE / WRITE_SIZE per pair of the same workload and policy, corrected as profiles/README.md describes).
+    bench.py cannot collect counters itself; None when no profile of this configuration is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path))
+        e = t.get("%s/policy%d" % (workload, policy))
+        return None if e is None else e["bytes_per_pair"] * pairs_per_launch
+    except (ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(walks, NV, D, L, K, seconds):
     """The CPU restatement (oracle, 'port') timed with Hogwild threads on this box's host cores, on a bounded sample
     of the same walks.  A reported baseline, not the target; not the Java reference (no JDK here)."""
     from oracle import oracle as O
     O.build()
-    cores = len(os.sched_getaffinity(0))
+    # the GPU box exposes every host core but one GPU's share is 16 of them (task notes); more threads than that only
+    # time-slice against the cgroup quota (measured: 256 threads run 1.3e6 edges/s, slower than 16)
+    cores = min(len(os.sched_getaffinity(0)), 16)
     probe = walks[:20_000]
     m = O.train_sgns(probe, NV, D, L, negative=K, threads=cores, table_size=10_000_000)
     rate = m.pairs / max(m.seconds, 1e-9)
