@@ -41,7 +41,8 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="SGNS walk workers (0 = fill the device)")
     ap.add_argument("--policy", type=int, default=0, help="dge_train_config.update_policy (0 auto = float atomics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--force-exchange", action="store_true", help="run the delta exchange even with one rank (plumbing check)")
     args = ap.parse_args()
 
     import numpy as np
@@ -95,7 +96,11 @@ def main():
     B = args.batch_walks or max(1, epoch_walks // 10)
     B = min(B, shard)
     delta = None
-    if N > 1:
+    exchange = N > 1 or args.force_exchange
+    if exchange and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+    if exchange:
         delta = torch.empty(model.sync_size(), dtype=torch.float32, device=dev)
         model.snapshot()
     setup_s = time.time() - t0
@@ -104,7 +109,7 @@ def main():
         row0 = (i * B) % max(shard - B + 1, 1)
         model.walk_and_train(g, corpus, row0, B, walk_seed=WALK_SEED, walk_index_base=shard0 + row0, epoch=0,
                              words_before=0, words_scale=float(N), total_walks=epoch_walks)
-        if N > 1:
+        if exchange:
             exchange_deltas(model, delta, N)
 
     def sync():
@@ -169,7 +174,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sample, NV, D, L, K, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    if N > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -200,7 +205,7 @@ def cpu_baseline(walks, NV, D, L, K, seconds):
     probe = walks[:20_000]
     m = O.train_sgns(probe, NV, D, L, negative=K, threads=cores, table_size=10_000_000)
     rate = m.pairs / max(m.seconds, 1e-9)
-    n = int(min(len(walks), max(20_000, seconds * rate / (m.pairs / len(probe)))))
+    n = int(min(len(walks), max(20_000, 0.5 * seconds * rate / (m.pairs / len(probe)))))   # the probe over-estimates the rate ~2x
     m = O.train_sgns(walks[:n], NV, D, L, negative=K, threads=cores, table_size=10_000_000)
     return {"value": m.pairs / max(m.seconds, 1e-9), "unit": "edges/s", "cores": cores, "kind": "port",
             "sample": "%d walks (%d pairs) of the same corpus, oracle/dge_oracle.c Hogwild with %d OpenMP threads, %.1f s"

@@ -220,3 +220,17 @@ def test_locked_policies_match_the_in_order_result(dge, oracle):
                 assert dm.stats()["pairs"] == om.pairs and np.array_equal(vid, om.vocab_ids)
                 assert cosine_rows(syn0, om.syn0).min() > tol, (dim, pol, workers)       # 1e-4 cosine at one worker
                 assert cosine_rows(dm.syn1neg(), om.syn1neg).min() > tol
+
+
+def test_long_sentences_take_the_memory_token_path(dge, oracle):
+    """Sentences longer than 64 tokens (text corpora through DeepWalk.learnEmbedding) read their tokens from memory
+    instead of registers; in-order result still bit-exact, locked policy still within rounding."""
+    rng = np.random.default_rng(4)
+    walks = rng.integers(0, 50, (40, 70)).astype(np.int32)
+    walks[::3, 40:] = -1                                   # ragged
+    om, dm = _fit_both(oracle, dge, walks, 50, arith=1, dim=16, window=5, min_count=1, table_size=1009)
+    assert np.array_equal(bits(dm.vectors()[0]), bits(om.syn0)) and dm.stats()["pairs"] == om.pairs
+    o0 = oracle.train_sgns(walks, 50, 16, 5, min_count=1, table_size=1009, arith=0)
+    c = dge.make_config(16, 5, 50, workers=1, min_count=1, table_size=1009, update_policy=6)
+    d6 = dge.SgnsModel.fit(walks, c, 0)
+    assert cosine_rows(d6.vectors()[0], o0.syn0).min() > 1 - 1e-4
