@@ -179,15 +179,15 @@ __device__ __forceinline__ int32_t walk_pick(const dge_slot* __restrict__ slots,
 #define WALK_BLOCK 256
 __global__ void __launch_bounds__(WALK_BLOCK)
 k_walks(const int64_t* __restrict__ row_ptr, const dge_slot* __restrict__ slots, const dge_slot* __restrict__ src_slots,
-        int64_t S, int32_t* __restrict__ out, int64_t n, int32_t L, uint64_t seed0, int64_t first_index,
-        const int64_t* __restrict__ d_offsets, int32_t* __restrict__ lens_out, int32_t* deadend_count) {
+        int64_t S, int32_t* __restrict__ out, int64_t n, int32_t L, uint64_t seed0, int64_t base_draw, int64_t draw_stride,
+        const int64_t* __restrict__ d_offsets, uint8_t* __restrict__ lens_out, int32_t* deadend_count) {
     extern __shared__ int32_t lds[];
     const int t = threadIdx.x;
     const int64_t blk0 = (int64_t)blockIdx.x * WALK_BLOCK;
     const int64_t i = blk0 + t;
     const int Lp = L | 1;
     if (i < n) {
-        uint64_t off = d_offsets ? (uint64_t)d_offsets[i] : (uint64_t)(first_index + i) * (uint64_t)L;
+        uint64_t off = d_offsets ? (uint64_t)d_offsets[i] : (uint64_t)base_draw + (uint64_t)i * (uint64_t)draw_stride;
         uint64_t s = dge_jr_jump(seed0, 2ULL * off);
         int32_t* row = lds + t * Lp;
         int len = 0;
@@ -206,9 +206,10 @@ k_walks(const int64_t* __restrict__ row_ptr, const dge_slot* __restrict__ slots,
             }
         }
         if (len < L && deadend_count) atomicAdd(deadend_count, 1);
-        if (lens_out) lens_out[i] = len;
+        if (lens_out) lens_out[i] = (uint8_t)len;
         for (int j = len; j < L; j++) row[j] = -1;
     }
+    if (!out) return;              // length-only pass of the sequential-stream resolver
     __syncthreads();
     const int64_t rows = min((int64_t)WALK_BLOCK, n - blk0);
     const int64_t cnt = rows * L;
@@ -244,6 +245,44 @@ __global__ void k_walks_sequential(const int64_t* row_ptr, const dge_slot* slots
         for (int j = len; j < L; j++) row[j] = -1;
     }
     *draws_out = draws;
+}
+
+// ---- the reference's shared sequential stream with dead ends, in parallel -------------------------------------------
+// Walk i starts at draw o_i with o_0 = first_draw and o_{i+1} = o_i + len(o_i), where len(o) = draws a walk started at
+// draw o consumes (1..L, data dependent: J/LayeredGraph.java:247-248).  (1) len(o) for EVERY o in [0, n*L) (k_walks in
+// length-only mode, draw stride 1); (2) the offset range is cut into blocks; from each of the L possible entry points
+// of a block one lane follows o -> o+len(o) to the block's end: exit point and hop count; (3) one lane chains the
+// blocks (entry of block b+1 = exit of block b); (4) one lane per block re-follows its chain and writes the start
+// draw of every walk; (5) k_walks with explicit offsets.  All exact: the walks are those of the sequential loop.
+#define SEQ_BLOCK 4096
+__global__ void k_seq_block_exits(const uint8_t* __restrict__ lens, int64_t N, int32_t L, int64_t n_blocks, int32_t* exit_e, int32_t* hops) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_blocks * L) return;
+    const int64_t b = t / L; const int e = (int)(t - b * L);
+    const int64_t end = min((b + 1) * (int64_t)SEQ_BLOCK, N);
+    int64_t o = b * (int64_t)SEQ_BLOCK + e; int32_t cnt = 0;
+    while (o < end) { o += lens[o]; cnt++; }
+    exit_e[t] = (int32_t)(o - end); hops[t] = cnt;
+}
+__global__ void k_seq_chain(const int32_t* exit_e, const int32_t* hops, int32_t L, int64_t n_blocks, int32_t* start_e, int64_t* start_idx) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int e = 0; int64_t idx = 0;
+    for (int64_t b = 0; b < n_blocks; b++) {
+        start_e[b] = e; start_idx[b] = idx;
+        idx += hops[b * L + e]; e = exit_e[b * L + e];
+    }
+}
+__global__ void k_seq_starts(const uint8_t* __restrict__ lens, int64_t N, int64_t n_blocks, const int32_t* start_e, const int64_t* start_idx,
+                             int64_t first_draw, int64_t n_walks, int64_t* starts, int64_t* draws_out) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const int64_t end = min((b + 1) * (int64_t)SEQ_BLOCK, N);
+    int64_t o = b * (int64_t)SEQ_BLOCK + start_e[b], idx = start_idx[b];
+    while (o < end && idx < n_walks) {
+        starts[idx] = first_draw + o;
+        if (idx == n_walks - 1) *draws_out = o + lens[o];
+        o += lens[o]; idx++;
+    }
 }
 
 __global__ void k_sample_next(const int64_t* row_ptr, const dge_slot* slots, int32_t v, double x, int32_t* out) {
@@ -595,7 +634,7 @@ int dge_launch_walks_strided(const dge_graph* g, hipStream_t stream, int32_t* d_
     size_t lds = (size_t)WALK_BLOCK * (size_t)(L | 1) * sizeof(int32_t);
     if (lds > 64 * 1024) DGE_FAIL(DGE_ERR_ARG, "walk length %d too long (max %d)", L, (int)(64 * 1024 / WALK_BLOCK / 4 - 1));
     hipLaunchKernelGGL(k_walks, dim3(grid_for(n, WALK_BLOCK)), dim3(WALK_BLOCK), lds, stream, g->d_row_ptr, g->d_slots, g->d_src_slots,
-                       g->S, d_out, n, L, dge_jr_scramble(seed), first_index, (const int64_t*)nullptr, (int32_t*)nullptr, d_deadend_count);
+                       g->S, d_out, n, L, dge_jr_scramble(seed), first_index * (int64_t)L, (int64_t)L, (const int64_t*)nullptr, (uint8_t*)nullptr, d_deadend_count);
     DGE_HIP(hipGetLastError());
     return DGE_OK;
 }
@@ -630,16 +669,44 @@ static int sample_walks_impl(const dge_graph* g, int64_t n_walks, int32_t max_le
         return DGE_OK;
     }
     if (dead == 0) { if (draws_consumed) *draws_consumed = n_walks * (int64_t)max_len; return DGE_OK; }
-    // some walk dead-ended (or the stream offset is unaligned): draw counts are data dependent, chain the walks
-    int64_t* d_draws = nullptr;
-    if ((rc = dge_dev_alloc(&d_draws, 1))) return rc;
-    hipLaunchKernelGGL(k_walks_sequential, dim3(1), dim3(64), 0, g->stream, g->d_row_ptr, g->d_slots, g->d_src_slots, g->S, d_out,
-                       n_walks, max_len, dge_jr_scramble(seed), first_index, d_draws);
+    // some walk dead-ended (or the stream offset is unaligned): draw counts are data dependent
     int64_t draws = 0;
-    DGE_HIP(hipMemcpyAsync(&draws, d_draws, sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
-    DGE_HIP(hipStreamSynchronize(g->stream));
-    DGE_HIP(hipGetLastError());
-    dge_dev_free(d_draws);
+    if (g->S == 0) {                  // no source: every walk is empty and consumes nothing
+        DGE_HIP(hipMemsetAsync(d_out, 0xFF, (size_t)(n_walks * max_len) * sizeof(int32_t), g->stream));
+        DGE_HIP(hipStreamSynchronize(g->stream));
+    } else if (n_walks < 2048) {      // short corpora: one lane chains the walks
+        int64_t* d_draws = nullptr;
+        if ((rc = dge_dev_alloc(&d_draws, 1))) return rc;
+        hipLaunchKernelGGL(k_walks_sequential, dim3(1), dim3(64), 0, g->stream, g->d_row_ptr, g->d_slots, g->d_src_slots, g->S, d_out,
+                           n_walks, max_len, dge_jr_scramble(seed), first_index, d_draws);
+        DGE_HIP(hipMemcpyAsync(&draws, d_draws, sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+        DGE_HIP(hipStreamSynchronize(g->stream));
+        DGE_HIP(hipGetLastError());
+        dge_dev_free(d_draws);
+    } else {                          // parallel resolver (see k_seq_block_exits)
+        const int64_t N = n_walks * (int64_t)max_len;
+        const int64_t n_blocks = (N + SEQ_BLOCK - 1) / SEQ_BLOCK;
+        uint8_t* d_lens = nullptr; int32_t *d_exit = nullptr, *d_hops = nullptr, *d_se = nullptr; int64_t *d_si = nullptr, *d_starts = nullptr, *d_draws = nullptr;
+        if ((rc = dge_dev_alloc(&d_lens, (size_t)N + 256))) return rc;
+        if ((rc = dge_dev_alloc(&d_exit, (size_t)(n_blocks * max_len)))) return rc;
+        if ((rc = dge_dev_alloc(&d_hops, (size_t)(n_blocks * max_len)))) return rc;
+        if ((rc = dge_dev_alloc(&d_se, (size_t)n_blocks))) return rc;
+        if ((rc = dge_dev_alloc(&d_si, (size_t)n_blocks))) return rc;
+        if ((rc = dge_dev_alloc(&d_starts, (size_t)n_walks))) return rc;
+        if ((rc = dge_dev_alloc(&d_draws, 1))) return rc;
+        const size_t lds = (size_t)WALK_BLOCK * (size_t)(max_len | 1) * sizeof(int32_t);
+        hipLaunchKernelGGL(k_walks, dim3(grid_for(N, WALK_BLOCK)), dim3(WALK_BLOCK), lds, g->stream, g->d_row_ptr, g->d_slots, g->d_src_slots, g->S,
+                           (int32_t*)nullptr, N, max_len, dge_jr_scramble(seed), first_index, (int64_t)1, (const int64_t*)nullptr, d_lens, (int32_t*)nullptr);
+        hipLaunchKernelGGL(k_seq_block_exits, dim3(grid_for(n_blocks * max_len, 256)), dim3(256), 0, g->stream, d_lens, N, max_len, n_blocks, d_exit, d_hops);
+        hipLaunchKernelGGL(k_seq_chain, dim3(1), dim3(64), 0, g->stream, d_exit, d_hops, max_len, n_blocks, d_se, d_si);
+        hipLaunchKernelGGL(k_seq_starts, dim3(grid_for(n_blocks, 256)), dim3(256), 0, g->stream, d_lens, N, n_blocks, d_se, d_si, first_index, n_walks, d_starts, d_draws);
+        hipLaunchKernelGGL(k_walks, dim3(grid_for(n_walks, WALK_BLOCK)), dim3(WALK_BLOCK), lds, g->stream, g->d_row_ptr, g->d_slots, g->d_src_slots, g->S,
+                           d_out, n_walks, max_len, dge_jr_scramble(seed), (int64_t)0, (int64_t)0, d_starts, (uint8_t*)nullptr, (int32_t*)nullptr);
+        DGE_HIP(hipMemcpyAsync(&draws, d_draws, sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+        DGE_HIP(hipStreamSynchronize(g->stream));
+        DGE_HIP(hipGetLastError());
+        dge_dev_free(d_lens); dge_dev_free(d_exit); dge_dev_free(d_hops); dge_dev_free(d_se); dge_dev_free(d_si); dge_dev_free(d_starts); dge_dev_free(d_draws);
+    }
     if (draws_consumed) *draws_consumed = draws;
     return DGE_OK;
 }

@@ -99,6 +99,11 @@ def test_walks_dead_ends_are_short_not_errors(dge, oracle):
     c = og.sample_walks(300, 6, seed=5, rng_mode=0, first_index=da)
     d = dg.sample_walks(300, 6, seed=5, rng_mode=0, first_index=db)
     assert np.array_equal(c, d)
+    # long corpora go through the parallel resolver of the sequential stream (block exits + chain): still the exact walks
+    for n, first in ((2048, 0), (50_000, 0), (30_001, da)):
+        a2, d2 = og.sample_walks(n, 6, seed=77, rng_mode=0, first_index=first, return_draws=True)
+        b2, e2 = dg.sample_walks(n, 6, seed=77, rng_mode=0, first_index=first, return_draws=True)
+        assert np.array_equal(a2, b2) and d2 == e2 and d2 == int((a2 >= 0).sum())
 
 
 def test_keep_nearest_k_vertices(dge, oracle):
