@@ -13,6 +13,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <fstream>
 #include <sstream>
@@ -194,6 +195,26 @@ class CrossTimeGraph : public LayeredGraph {
             std::string n = "0-" + std::to_string(r);
             if (g.allVertices.count(n)) g.addSourceVertex(n);
         }
+    }
+    // the same graph from the reference's own per-slice edge files "taxi-h<h>.od", one "src dst w" line per flow
+    // (J/Tracts.java:236-264, J/CommunityAreas.java:171-186; the CA writer also emits w == 0 lines, dropped here as
+    // the graph builders drop them, J/CrossTimeGraph.java:37-38).  files[h] is slice h; sources in ascending region id.
+    static void constructGraphFromOD(CrossTimeGraph& g, const std::vector<std::string>& files) {
+        numLayer = (int)files.size();
+        std::vector<Flow> flows;
+        std::vector<int> regions;
+        for (size_t h = 0; h < files.size(); h++) {
+            std::ifstream in(files[h]);
+            if (!in) throw std::runtime_error("cannot open " + files[h]);
+            long long a, b; double w;
+            while (in >> a >> b >> w) {
+                flows.push_back({(int)h, (int)a, (int)b, w});
+                if (h == 0) regions.push_back((int)a);
+            }
+        }
+        std::sort(regions.begin(), regions.end());
+        regions.erase(std::unique(regions.begin(), regions.end()), regions.end());
+        constructGraph(g, flows, regions);
     }
     // outputSampleSequence + sampleSequenceHelper  J/CrossTimeGraph.java:115-148: numSamples lines of space-joined names
     static void outputSampleSequence(CrossTimeGraph& g, const std::string& path, bool exactReferenceOrder = true) {

@@ -59,6 +59,27 @@ int main(int argc, char** argv) {
             CHECK(w.size() == 3 && w[0].substr(0, 2) == "0-" && w[1].substr(0, 2) == "1-" && w[2].substr(0, 2) == "2-");
         }
     }
+    {   // the same graph from the reference's .od edge files (J/Tracts.java:236-264): one "src dst w" line per flow and slice
+        std::vector<std::string> files;
+        for (int h = 0; h < 3; h++) {
+            files.push_back(tmp + "/taxi-h" + std::to_string(h) + ".od");
+            std::ofstream out(files.back());
+            for (const Flow& f : flows) if (f.slice == h) out << f.src << " " << f.dst << " " << (long long)f.count << "\n";
+            out << "100 101 0\n";                                     // zero flows are written by the CA exporter and must be dropped
+        }
+        CrossTimeGraph g2;
+        CrossTimeGraph::constructGraphFromOD(g2, files);
+        CHECK(CrossTimeGraph::numLayer == 3 && g2.allVertices.size() == 18 && g2.sourceVertices.size() == 6);
+        CHECK(g2.numEdges() == (int64_t)flows.size());
+        g2.initiateAliasTables();
+        CrossTimeGraph g1;
+        CrossTimeGraph::constructGraph(g1, flows, regions);
+        g1.initiateAliasTables();
+        LayeredGraph::numLayer = 3;
+        LayeredGraph::rnd = Random(5); std::vector<int32_t> w1 = g1.sampleVertexSequences(500);
+        LayeredGraph::rnd = Random(5); std::vector<int32_t> w2 = g2.sampleVertexSequences(500);
+        CHECK(w1 == w2);                                              // same ids, same tables, same stream -> same walks
+    }
     {   // spatial graph: position prefix + top-10 prune
         SpatialGraph::numLayer = 3; SpatialGraph::numSamples = 500;
         std::vector<std::string> names; std::vector<double> wt;

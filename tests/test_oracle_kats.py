@@ -242,3 +242,34 @@ def test_vec_format_fixture():
     head = open(os.path.join(GOLD, "taxi_all_head.vec")).readline().split()
     assert head == ["77", "8"] and rows.shape == (3, 9) and rows[:, 0].tolist() == [1.0, 2.0, 3.0]
     assert np.allclose(np.linalg.norm(rows[:, 1:5], axis=1), 1.0, atol=1e-4)      # two unit 4-vectors per row
+
+
+def test_file_formats_roundtrip(tmp_path, oracle):
+    """.od -> layered graph -> .seq -> ids, and .vec read-back (formats: embedding_amd/io.py header)."""
+    from embedding_amd import io
+    rng = np.random.default_rng(0)
+    paths = []
+    for h in range(3):
+        p = tmp_path / ("taxi-h%d.od" % h)
+        with open(p, "w") as f:
+            for s in (17031, 17045, 17099):
+                for d in (17031, 17045, 17099):
+                    f.write("%d %d %d\n" % (s, d, int(rng.integers(0, 4))))       # zeros are dropped
+        paths.append(str(p))
+    G = io.read_od_slices(paths)
+    assert G["R"] == 3 and G["T"] == 3 and (G["w"] > 0).all() and (G["src"] // 3 == (G["dst"] // 3 - 1) % 3).all()
+    g = oracle.Graph(); g.add_edges(G["src"], G["dst"], G["w"]); g.set_sources(G["sources"]); g.build_alias(True)
+    walks = g.sample_walks(50, 3, seed=1, rng_mode=0)
+    seq = tmp_path / "taxi-crosstime.seq"
+    io.write_seq(str(seq), walks, G["names"])
+    first = open(seq).readline().split()
+    assert first[0].startswith("0-170") and all(t.count("-") == 1 for t in first)
+    back, names = io.read_seq(str(seq))
+    assert back.shape[0] == 50 and [names[t] for t in back[0] if t >= 0] == first
+    vec = tmp_path / "x.vec"
+    with open(vec, "w") as f:
+        f.write("0-17031 0.5 -1.25\n1-17045 1e-3 2\n")
+    n, v = io.read_vec(str(vec))
+    assert n == ["0-17031", "1-17045"] and v.shape == (2, 2) and v[1, 0] == np.float32(1e-3)
+    n, v = io.read_vec(os.path.join(GOLD, "taxi_all_head.vec"), header=True)
+    assert n == ["1", "2", "3"] and v.shape == (3, 8)
