@@ -8,6 +8,14 @@ The reference is single-host; this layer is new.
 """
 
 
+def _wait_device(t):
+    """torch.distributed enqueues collectives on torch's streams; libdge.so works on its own stream, so the host waits
+    for the tensor's device before handing the pointer over."""
+    if getattr(t, "is_cuda", False):
+        import torch
+        torch.cuda.synchronize(t.device)
+
+
 def shard_plan(epoch_walks, world, rank):
     """(first_walk_index, n_walks) of `rank`: contiguous, disjoint, covering [0, world*(epoch_walks//world))."""
     if not (0 <= rank < world):
@@ -22,6 +30,7 @@ def allreduce_counts(counts, dist_mod=None):
     d = dist_mod or dist
     if d.is_initialized() and d.get_world_size() > 1:
         d.all_reduce(counts)
+        _wait_device(counts)
     return counts
 
 
@@ -32,7 +41,8 @@ def exchange_deltas(model, buf, world, dist_mod=None):
     model.sync_size() elements on the model's device."""
     import torch.distributed as dist
     d = dist_mod or dist
-    model.export_delta(buf)
-    if world > 1:
+    model.export_delta(buf)            # returns after the library's stream has drained
+    if world > 1 or (d.is_initialized() and getattr(buf, "is_cuda", False)):
         d.all_reduce(buf)
+        _wait_device(buf)              # the collective runs on torch's stream; libdge reads buf on its own stream
     model.import_delta(buf, 1.0 / world)

@@ -47,10 +47,10 @@ def test_vocabulary_table_and_init_match(dge, oracle):
         assert not dm.syn1neg().any()
 
 
-@pytest.mark.parametrize("dim,negative", [(32, 5), (20, 5), (64, 5), (128, 5), (256, 3), (100, 20), (130, 2)])
+@pytest.mark.parametrize("dim,negative", [(32, 5), (20, 5), (64, 5), (128, 5), (256, 3), (100, 20), (130, 2), (300, 2), (512, 1)])
 def test_in_order_training_bit_exact(dge, oracle, dim, negative):
     """workers=1 follows the oracle's order; dims cover padding (20,100,130), 1..4 row chunks and K>16 draws."""
-    walks, NV = _walks(oracle, dge, n=300 if dim >= 128 else 600)
+    walks, NV = _walks(oracle, dge, n=(100 if dim > 256 else 300) if dim >= 128 else 600)
     om, dm = _fit_both(oracle, dge, walks, NV, arith=1, dim=dim, negative=negative)
     syn0, vid = dm.vectors()
     assert np.array_equal(vid, om.vocab_ids)
@@ -210,7 +210,7 @@ def test_locked_policies_match_the_in_order_result(dge, oracle):
     """Policies 5 and 6 (layout with 16 B per lane, positive target last) against the oracle: one worker reproduces the
     sequential word2vec result to rounding, 16 workers stay within Hogwild noise."""
     walks, NV = _walks(oracle, dge, n=1500)
-    for dim in (64, 128, 20):
+    for dim in (64, 128, 20, 256):
         om = oracle.train_sgns(walks, NV, dim, 6, table_size=20011, arith=0)
         for pol in (5, 6):
             for workers, tol in ((1, 1 - 1e-4), (16, 0.99)):
