@@ -197,24 +197,45 @@ __device__ __forceinline__ float group16_sum(float p) {
 }
 
 // one table seen through a buffer descriptor: byte offset of (row, lane) = row*stride*4 + lane*16 (< 4 GiB)
+// Tables of 4 GiB and more (cfg5: 10 M rows x 256 floats = 10 GB) do not fit one descriptor's 32-bit window: their
+// accesses build a descriptor per ROW (base + row*row_bytes, one row long).  That descriptor differs between the four
+// groups of a wave, so the compiler serialises the instruction per distinct row (a "waterfall" of <= 4 trips); the
+// common case keeps the single table-wide descriptor (template parameter BIG of the kernels).
 struct TableView {
     __amdgpu_buffer_rsrc_t rsrc;
     float* base;
     uint32_t row_bytes;
+    bool big;
 };
 __device__ __forceinline__ TableView make_view(float* base, int64_t rows, int stride) {
     TableView t;
     t.base = base;
     t.row_bytes = (uint32_t)stride * 4u;
-    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(uint32_t)(rows * stride * 4), 0x00020000);
+    t.big = (uint64_t)rows * (uint64_t)stride * 4ull >= 0xFFFFFFFFull;
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, t.big ? 0 : (int)(uint32_t)(rows * stride * 4), 0x00020000);   // unused when BIG
     return t;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_view(const TableView& t, int32_t row) {
+    return __builtin_amdgcn_make_buffer_rsrc(t.base + (size_t)row * (t.row_bytes / 4), 0, (int)t.row_bytes, 0x00020000);
 }
 
 // Lane j of a 16-lane group owns elements {64c + 16m + j : m = 0..3} of chunk c (kept as v[c].{x,y,z,w}): every
 // memory instruction of a group then touches 64 CONTIGUOUS bytes of the row, which is the shape the memory-side
 // float atomics want (one 64-B request per group instead of four) and costs the loads nothing (HBM-bound).
-template <int DCH, int AUX>
+template <int DCH, int AUX, bool BIG>
 __device__ __forceinline__ void row_load(Row<DCH>& r, const TableView& t, int32_t row, int lane) {
+    if (BIG) {
+        const __amdgpu_buffer_rsrc_t rs = row_view(t, row);
+        const uint32_t o = (uint32_t)lane * 4u;
+#pragma unroll
+        for (int c = 0; c < DCH; c++) {
+            r.v[c].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + c * 256u), 0, AUX));
+            r.v[c].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + c * 256u + 64u), 0, AUX));
+            r.v[c].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + c * 256u + 128u), 0, AUX));
+            r.v[c].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + c * 256u + 192u), 0, AUX));
+        }
+        return;
+    }
     const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 4u;
 #pragma unroll
     for (int c = 0; c < DCH; c++) {
@@ -224,8 +245,20 @@ __device__ __forceinline__ void row_load(Row<DCH>& r, const TableView& t, int32_
         r.v[c].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, (int)(off + c * 256u + 192u), 0, AUX));
     }
 }
-template <int DCH, int AUX>
+template <int DCH, int AUX, bool BIG>
 __device__ __forceinline__ void row_store(const Row<DCH>& r, const TableView& t, int32_t row, int lane) {
+    if (BIG) {
+        const __amdgpu_buffer_rsrc_t rs = row_view(t, row);
+        const uint32_t o = (uint32_t)lane * 4u;
+#pragma unroll
+        for (int c = 0; c < DCH; c++) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].x), rs, (int)(o + c * 256u), 0, AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].y), rs, (int)(o + c * 256u + 64u), 0, AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].z), rs, (int)(o + c * 256u + 128u), 0, AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].w), rs, (int)(o + c * 256u + 192u), 0, AUX);
+        }
+        return;
+    }
     const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 4u;
 #pragma unroll
     for (int c = 0; c < DCH; c++) {
@@ -292,16 +325,16 @@ __device__ __forceinline__ uint64_t shfl16_u64(uint64_t v, int src) {
 }
 
 // one (target row, label 0) update against l1; sequential form used when a pair drew the same row twice
-template <int DCH, int POL>
+template <int DCH, int POL, bool BIG>
 __device__ __forceinline__ void neg_update_serial(const Row<DCH>& l1, Row<DCH>& neu, const TableView& syn1neg, int32_t tg,
                                                   int lane, float alpha, const float* s_exp) {
     Row<DCH> r;
-    row_load<DCH, Policy<POL>::LOAD_AUX>(r, syn1neg, tg, lane);
+    row_load<DCH, Policy<POL>::LOAD_AUX, BIG>(r, syn1neg, tg, lane);
     float f = row_dot(l1, r);
     float g = sgns_g(f, 0.0f, alpha, s_exp);
     row_axpy(neu, g, r);
     row_axpy(r, g, l1);
-    row_store<DCH, Policy<POL>::STORE_AUX>(r, syn1neg, tg, lane);
+    row_store<DCH, Policy<POL>::STORE_AUX, BIG>(r, syn1neg, tg, lane);
 }
 
 __device__ __forceinline__ int32_t walk_tok(bool in_regs, const int32_t* sen, int idx, int32_t tk0, int32_t tk1, int32_t tk2, int32_t tk3) {
@@ -311,8 +344,8 @@ __device__ __forceinline__ int32_t walk_tok(bool in_regs, const int32_t* sen, in
     return __shfl(v, idx & 15, 16);
 }
 
-template <int DCH, int POL>
-__global__ void __launch_bounds__(256, (DCH <= 2) ? 4 : 1)
+template <int DCH, int POL, bool BIG>
+__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? 4 : 1)
 k_sgns_train(TrainParams p) {
     using P = Policy<POL>;
     __shared__ float s_exp[EXP_TABLE_SIZE];
@@ -353,7 +386,7 @@ k_sgns_train(TrainParams p) {
         if (h_dirty) {                                                                                             \
             h_dirty = false;                                                                                       \
             if (P::ATOMIC) row_atomic_axpy(syn1neg, word, lane, 1.0f, dh);                                         \
-            else row_store<DCH, P::STORE_AUX>(h, syn1neg, word, lane);                                           \
+            else row_store<DCH, P::STORE_AUX, BIG>(h, syn1neg, word, lane);                                           \
         }                                                                                                          \
     } while (0)
 
@@ -402,9 +435,9 @@ k_sgns_train(TrainParams p) {
 
         // ------------------------------------------------------------------ one pair: l1 = syn0[last], target rows in syn1neg
         Row<DCH> l1, neu;
-        row_load<DCH, P::LOAD_AUX>(l1, syn0, last, lane);
+        row_load<DCH, P::LOAD_AUX, BIG>(l1, syn0, last, lane);
         if (new_centre) {
-            row_load<DCH, P::LOAD_AUX>(h, syn1neg, word, lane);
+            row_load<DCH, P::LOAD_AUX, BIG>(h, syn1neg, word, lane);
             if (P::ATOMIC) row_zero(dh);
         }
         row_zero(neu);
@@ -446,7 +479,7 @@ k_sgns_train(TrainParams p) {
                     // centre's own row, always valid), only the arithmetic and the store are guarded
                     Row<DCH> rr[NEG_BATCH];
 #pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX>(rr[q], syn1neg, tg[q] >= 0 ? tg[q] : word, lane);
+                    for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX, BIG>(rr[q], syn1neg, tg[q] >= 0 ? tg[q] : word, lane);
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++)
                         if (tg[q] >= 0) {
@@ -457,13 +490,13 @@ k_sgns_train(TrainParams p) {
                                 row_atomic_axpy(syn1neg, tg[q], lane, g, l1);
                             } else {
                                 row_axpy(rr[q], g, l1);
-                                row_store<DCH, P::STORE_AUX>(rr[q], syn1neg, tg[q], lane);
+                                row_store<DCH, P::STORE_AUX, BIG>(rr[q], syn1neg, tg[q], lane);
                             }
                         }
                 } else {
 #pragma unroll 1
                     for (int q = 0; q < NEG_BATCH; q++)
-                        if (tg[q] >= 0) neg_update_serial<DCH, POL>(l1, neu, syn1neg, tg[q], lane, alpha, s_exp);
+                        if (tg[q] >= 0) neg_update_serial<DCH, POL, BIG>(l1, neu, syn1neg, tg[q], lane, alpha, s_exp);
                 }
             }
         }
@@ -474,7 +507,7 @@ k_sgns_train(TrainParams p) {
             for (int q = 0; q < DCH; q++) {
                 l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
             }
-            row_store<DCH, P::STORE_AUX>(l1, syn0, last, lane);
+            row_store<DCH, P::STORE_AUX, BIG>(l1, syn0, last, lane);
         }
         my_pairs++;
         c++;
@@ -512,8 +545,17 @@ __device__ __forceinline__ float row_probe_lines(const TableView& t, int32_t row
     if (lane < n_lines) old = __hip_atomic_fetch_add(t.base + (size_t)row * (t.row_bytes / 4) + lane * 32, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return old;
 }
-template <int DCH, int AUX>
+template <int DCH, int AUX, bool BIG>
 __device__ __forceinline__ void rowA_load(Row<DCH>& r, const TableView& t, int32_t row, int lane) {
+    if (BIG) {
+        const __amdgpu_buffer_rsrc_t rs = row_view(t, row);
+#pragma unroll
+        for (int c = 0; c < DCH; c++) {
+            const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((uint32_t)lane * 16u + c * 256u), 0, AUX));
+            r.v[c] = make_float4(f.x, f.y, f.z, f.w);
+        }
+        return;
+    }
     const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 16u;
 #pragma unroll
     for (int c = 0; c < DCH; c++) {
@@ -523,8 +565,18 @@ __device__ __forceinline__ void rowA_load(Row<DCH>& r, const TableView& t, int32
         r.v[c] = make_float4(f.x, f.y, f.z, f.w);
     }
 }
-template <int DCH, int AUX>
+template <int DCH, int AUX, bool BIG>
 __device__ __forceinline__ void rowA_store(const Row<DCH>& r, const TableView& t, int32_t row, int lane) {
+    if (BIG) {
+        const __amdgpu_buffer_rsrc_t rs = row_view(t, row);
+#pragma unroll
+        for (int c = 0; c < DCH; c++) {
+            v4f f;
+            f.x = r.v[c].x; f.y = r.v[c].y; f.z = r.v[c].z; f.w = r.v[c].w;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), rs, (int)((uint32_t)lane * 16u + c * 256u), 0, AUX);
+        }
+        return;
+    }
     const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 16u;
 #pragma unroll
     for (int c = 0; c < DCH; c++) {
@@ -534,19 +586,19 @@ __device__ __forceinline__ void rowA_store(const Row<DCH>& r, const TableView& t
     }
 }
 
-template <int DCH, bool STRICT>
+template <int DCH, bool STRICT, bool BIG>
 __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* locks, int32_t row, const float* d, int lane) {
     for (;;) {
         const bool won = lane == 0 ? row_trylock(locks, row) : false;
         const bool got = __shfl((int)won, 0, 16) != 0;
         if (got) {
             Row<DCH> cur;
-            rowA_load<DCH, 16>(cur, syn1neg, got ? row : 0, lane);
+            rowA_load<DCH, 16, BIG>(cur, syn1neg, got ? row : 0, lane);
 #pragma unroll
             for (int q = 0; q < DCH; q++) {
                 cur.v[q].x += d[q * 64]; cur.v[q].y += d[q * 64 + 16]; cur.v[q].z += d[q * 64 + 32]; cur.v[q].w += d[q * 64 + 48];
             }
-            rowA_store<DCH, 16>(cur, syn1neg, row, lane);
+            rowA_store<DCH, 16, BIG>(cur, syn1neg, row, lane);
             row_commit_wait(STRICT ? row_probe_lines(syn1neg, row, lane, DCH * 2) : 0.f);
             if (won) row_unlock(locks, row);
             return;
@@ -556,8 +608,8 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
 }
 
 #define LK_NEG_LANES 13      /* lanes 0..12 draw negatives, lane 13 = pending centre flush, lane 14 = the pair's syn0 row */
-template <int DCH, bool STRICT>
-__global__ void __launch_bounds__(256, DCH <= 2 ? 3 : 1)
+template <int DCH, bool STRICT, bool BIG>
+__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? 3 : 1)
 k_sgns_train_locked(TrainParams p) {
     __shared__ float s_exp[EXP_TABLE_SIZE];
     __shared__ float s_dh[16 * 2 * DCH * 64];
@@ -603,7 +655,7 @@ k_sgns_train_locked(TrainParams p) {
     do {                                                                                                               \
         if (h_dirty) {                                                                                                 \
             h_dirty = false;                                                                                           \
-            if (pend_row >= 0) flushA_blocking<DCH, STRICT>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane); \
+            if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane); \
             pend_row = word;                                                                                           \
             cur_buf ^= 1;                                                                                              \
         }                                                                                                              \
@@ -651,7 +703,7 @@ k_sgns_train_locked(TrainParams p) {
 
         Row<DCH> l1, neu;
         if (new_centre) {
-            rowA_load<DCH, 16>(h, syn1neg, word, lane);       // unlocked read: stale by at most the updates in flight
+            rowA_load<DCH, 16, BIG>(h, syn1neg, word, lane);       // unlocked read: stale by at most the updates in flight
             float* d = my_dh + cur_buf * DCH * 64 + lane;
 #pragma unroll
             for (int q = 0; q < DCH; q++) { d[q * 64] = 0.f; d[q * 64 + 16] = 0.f; d[q * 64 + 32] = 0.f; d[q * 64 + 48] = 0.f; }
@@ -707,10 +759,10 @@ k_sgns_train_locked(TrainParams p) {
                     const unsigned got = (gotl >> base) & ((1u << NEG_BATCH) - 1u) & pending;
                     const bool gotf = flush_pending && ((gotl >> 13) & 1u);
                     Row<DCH> rr[NEG_BATCH], fr;
-                    if (got_l1) rowA_load<DCH, 16>(l1, syn0, (gotl >> 14) & 1u ? last : 0, lane);
+                    if (got_l1) rowA_load<DCH, 16, BIG>(l1, syn0, (gotl >> 14) & 1u ? last : 0, lane);
 #pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : word, lane);
-                    if (flush_pending) rowA_load<DCH, 16>(fr, syn1neg, gotf ? pend_row : word, lane);
+                    for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16, BIG>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : word, lane);
+                    if (flush_pending) rowA_load<DCH, 16, BIG>(fr, syn1neg, gotf ? pend_row : word, lane);
                     have_l1 = true;
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++)
@@ -719,7 +771,7 @@ k_sgns_train_locked(TrainParams p) {
                             float g = sgns_g(f, 0.0f, alpha, s_exp);
                             row_axpy(neu, g, rr[q]);
                             row_axpy(rr[q], g, l1);
-                            rowA_store<DCH, 16>(rr[q], syn1neg, tg[q], lane);
+                            rowA_store<DCH, 16, BIG>(rr[q], syn1neg, tg[q], lane);
                         }
                     if (gotf) {
                         const float* d = my_dh + (cur_buf ^ 1) * DCH * 64 + lane;
@@ -727,7 +779,7 @@ k_sgns_train_locked(TrainParams p) {
                         for (int q = 0; q < DCH; q++) {
                             fr.v[q].x += d[q * 64]; fr.v[q].y += d[q * 64 + 16]; fr.v[q].z += d[q * 64 + 32]; fr.v[q].w += d[q * 64 + 48];
                         }
-                        rowA_store<DCH, 16>(fr, syn1neg, pend_row, lane);
+                        rowA_store<DCH, 16, BIG>(fr, syn1neg, pend_row, lane);
                     }
                     {   // every stored row is committed line by line (lane = 4*slot + line for DCH 2), then the locks drop
                         float acc = 0.f;
@@ -774,7 +826,7 @@ k_sgns_train_locked(TrainParams p) {
         for (int q = 0; q < DCH; q++) {
             l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
         }
-        rowA_store<DCH, 16>(l1, syn0, last, lane);
+        rowA_store<DCH, 16, BIG>(l1, syn0, last, lane);
         row_commit_wait(STRICT ? row_probe_lines(syn0, last, lane, DCH * 2) : 0.f);
         if (lane == 14) row_unlock(locks0, last);
         my_pairs++;
@@ -782,7 +834,7 @@ k_sgns_train_locked(TrainParams p) {
         if (c == i) c++;
     }
     LK_CLOSE_CENTRE();
-    if (pend_row >= 0) flushA_blocking<DCH, STRICT>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane);
+    if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane);
 #undef LK_TOK
 #undef LK_CLOSE_CENTRE
     if (lane == 0) {
@@ -820,13 +872,13 @@ k_selftest_locked_rows(float* table, int* locks, unsigned long long* counts, int
             if (FENCE & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             Row<DCH> rr[NEG_BATCH];
 #pragma unroll
-            for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, LAUX>(rr[q], tv, ((got >> q) & 1u) ? tg[q] : 0, lane);
+            for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, LAUX, false>(rr[q], tv, ((got >> q) & 1u) ? tg[q] : 0, lane);
 #pragma unroll
             for (int q = 0; q < NEG_BATCH; q++)
                 if ((got >> q) & 1u) {
 #pragma unroll
                     for (int c = 0; c < DCH; c++) { rr[q].v[c].x += 1.f; rr[q].v[c].y += 1.f; rr[q].v[c].z += 1.f; rr[q].v[c].w += 1.f; }
-                    rowA_store<DCH, SAUX>(rr[q], tv, tg[q], lane);
+                    rowA_store<DCH, SAUX, false>(rr[q], tv, tg[q], lane);
                 }
             if (FENCE & 4) {
                 float acc = 0.f;
@@ -1033,10 +1085,6 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         MH(hipStreamSynchronize(st));
     }
     size_t tab = (size_t)V * (size_t)m->stride;
-    if (tab * sizeof(float) >= (size_t)0xFFFFFFFFull) {
-        model_release(m); delete m;
-        DGE_FAIL(DGE_ERR_ARG, "dge_model_create: a table of %lld rows x %d floats exceeds the 4 GiB buffer window of this build", (long long)V, m->stride);
-    }
     MC(dge_dev_alloc(&m->d_syn0, tab + 64)); MC(dge_dev_alloc(&m->d_syn1neg, tab + 64));
     MH(hipMemsetAsync(m->d_syn1neg, 0, (tab + 64) * sizeof(float), st));
     if (V) hipLaunchKernelGGL(k_init_syn0, dim3(grid_for(V, 256)), dim3(256), 0, st, m->d_syn0, V, m->D, m->stride, cfg->seed);
@@ -1070,15 +1118,20 @@ static int ensure_work(dge_model* m, int64_t n_rows, int32_t L) {
     return DGE_OK;
 }
 
-template <int DCH>
-static void launch_train(const TrainParams& p, int pol, unsigned blocks, unsigned threads, hipStream_t st) {
+template <int DCH, bool BIG>
+static void launch_train_b(const TrainParams& p, int pol, unsigned blocks, unsigned threads, hipStream_t st) {
     switch (pol) {
-        case 0: hipLaunchKernelGGL((k_sgns_train<DCH, 0>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true>), dim3(blocks), dim3(threads), 0, st, p); break;
-        default: hipLaunchKernelGGL((k_sgns_train<DCH, 2>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 0: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
+        default: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
     }
+}
+template <int DCH>
+static void launch_train(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, hipStream_t st) {
+    if (big) launch_train_b<DCH, true>(p, pol, blocks, threads, st);
+    else launch_train_b<DCH, false>(p, pol, blocks, threads, st);
 }
 
 static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32_t L, int64_t walk_index_base, int32_t epoch,
@@ -1126,16 +1179,19 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
 
+    // per-row descriptors (TableView) for tables of 4 GiB and more; DGE_FORCE_BIG=1 selects that code path on small
+    // tables too so that the parity tests can cover it
+    const bool big = (uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull || getenv("DGE_FORCE_BIG") != nullptr;
     EventPair ev; ev.kind = 0;
     DGE_HIP(hipEventCreate(&ev.a)); DGE_HIP(hipEventCreate(&ev.b));
     DGE_HIP(hipEventRecord(ev.a, st));
     switch (m->stride / 64) {
-        case 1: launch_train<1>(p, pol, blocks, threads, st); break;
-        case 2: launch_train<2>(p, pol, blocks, threads, st); break;
-        case 3: launch_train<3>(p, pol, blocks, threads, st); break;
-        case 4: launch_train<4>(p, pol, blocks, threads, st); break;
-        case 6: launch_train<6>(p, pol, blocks, threads, st); break;
-        default: launch_train<8>(p, pol, blocks, threads, st); break;
+        case 1: launch_train<1>(p, pol, big, blocks, threads, st); break;
+        case 2: launch_train<2>(p, pol, big, blocks, threads, st); break;
+        case 3: launch_train<3>(p, pol, big, blocks, threads, st); break;
+        case 4: launch_train<4>(p, pol, big, blocks, threads, st); break;
+        case 6: launch_train<6>(p, pol, big, blocks, threads, st); break;
+        default: launch_train<8>(p, pol, big, blocks, threads, st); break;
     }
     DGE_HIP(hipEventRecord(ev.b, st));
     m->pending.push_back(ev);

@@ -29,7 +29,7 @@ t = time.time(); om = O.train_sgns(walks, NV, D, L, negative=K, threads=1, table
 print("oracle seq: V", om.V, "pairs", om.pairs, "%.1fs" % t_or, "auc/pos/neg", auc(om.syn0, om.syn1neg, om.vocab_ids), flush=True)
 o8 = O.train_sgns(walks, NV, D, L, negative=K, threads=8, table_size=10_000_000, arith=0)
 print("oracle 8thr: auc", auc(o8.syn0, o8.syn1neg, o8.vocab_ids), "median cos vs seq", float(np.median(cosine_rows(o8.syn0, om.syn0))), flush=True)
-for workers, pol in ((0, 2), (0, 5), (0, 0), (1024, 5)):
+for workers, pol in ((0, 3), (0, 1), (0, 2), (0, 0), (1024, 5), (1024, 6), (64, 5)):
     cfg = E.make_config(D, L, NV, negative=K, workers=workers, table_size=10_000_000); cfg.update_policy = pol
     t = time.time(); dm = E.SgnsModel.fit(walks, cfg, 0); syn0, vid = dm.vectors(); dt = time.time() - t
     st = dm.stats()

@@ -234,3 +234,40 @@ def test_long_sentences_take_the_memory_token_path(dge, oracle):
     c = dge.make_config(16, 5, 50, workers=1, min_count=1, table_size=1009, update_policy=6)
     d6 = dge.SgnsModel.fit(walks, c, 0)
     assert cosine_rows(d6.vectors()[0], o0.syn0).min() > 1 - 1e-4
+
+
+def test_tables_beyond_4_gib(dge, oracle, monkeypatch):
+    """Tables of >= 4 GiB use one buffer descriptor per row (template BIG).  (a) the same code path forced on small tables
+    stays bit-exact in order and within rounding under the locked policy; (b) a real 4.3 GB table: rows at the far end
+    of the table are the ones that move, everything else keeps its initial value."""
+    walks, NV = _walks(oracle, dge, n=300)
+    monkeypatch.setenv("DGE_FORCE_BIG", "1")
+    for dim in (64, 128):
+        om, dm = _fit_both(oracle, dge, walks, NV, arith=1, dim=dim)
+        assert np.array_equal(bits(dm.vectors()[0]), bits(om.syn0)) and np.array_equal(bits(dm.syn1neg()), bits(om.syn1neg))
+        o0 = oracle.train_sgns(walks, NV, dim, 6, table_size=20011, arith=0)
+        for pol in (5, 6, 2):
+            c = dge.make_config(dim, 6, NV, workers=1, table_size=20011, update_policy=pol)
+            assert cosine_rows(dge.SgnsModel.fit(walks, c, 0).vectors()[0], o0.syn0).min() > 1 - 1e-4
+    monkeypatch.delenv("DGE_FORCE_BIG")
+    import torch
+    V, D = 2_200_000, 512                                  # 2.2 M rows x 2 KB = 4.5 GB per table
+    counts = torch.zeros(V, dtype=torch.int64, device="cuda:0")
+    counts[:] = 2
+    counts[-1000:] = 3                                     # the 1000 highest ids sort FIRST (count desc): rows 0..999
+    counts[:1000] = 1                                      # the 1000 lowest ids sort LAST: rows V-1000..V-1, beyond 4 GiB
+    cfg = dge.make_config(D, 2, V, negative=2, min_count=1, workers=0, table_size=1000)   # table covers rows 0..~999 only
+    m = dge.SgnsModel.create(cfg, counts, 0)
+    ids = np.arange(1000, dtype=np.int32)                  # walks over the LOW ids = the LAST rows of the tables
+    corpus = dge.WalkCorpus.from_host(np.stack([ids, ids[::-1]], 1).copy(), 0)
+    m.train(corpus)
+    st = m.stats()
+    assert st["pairs"] == 2000
+    import ctypes as C
+    p = C.c_void_p(0)
+    assert dge.lib.dge_model_syn1neg(m._h, C.byref(p)) == 0
+    syn1 = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(V, D))
+    tail, mid = syn1[-1000:], syn1[1_000_000:1_001_000]
+    # syn1neg starts at zero: the centre rows beyond the 4 GiB mark (and only rows the corpus or the table can reach) moved
+    assert np.isfinite(tail).all() and (np.abs(tail).max(1) > 0).all()
+    assert not mid.any()
