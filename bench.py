@@ -25,6 +25,9 @@ WORKLOADS = {
     # BASELINE.json configs[1]: 100k-node / 5M-edge static graph, D=64, K=5
     "cfg2": dict(R=100000, T=1, mean_degree=50, dim=64, negative=5, L=8, walks_per_vertex=10,
                  name="synthetic 100k-node / 5M-edge static flow graph, dim=64, K=5, L=W=8"),
+    # BASELINE.json configs[4]: power-law 10M-node / 1B-edge dynamic graph, D=256, K=20 (8 GPUs in the config; runs on 1)
+    "cfg5": dict(R=416667, T=24, n_edges=1_000_000_000, dim=256, negative=20, L=24, walks_per_vertex=1, powerlaw=True,
+                 name="power-law 10M-node / 1B-edge dynamic graph, 24 timeslices, dim=256, K=20, L=W=24"),
     # small smoke-sized workload for quick checks
     "tiny": dict(R=2000, T=8, mean_degree=20, dim=128, negative=5, L=8, walks_per_vertex=10,
                  name="tiny 16k-node graph (debug)"),
@@ -71,7 +74,10 @@ def main():
     t0 = time.time()
 
     # ---- setup (untimed): replicate the edge store on every GPU, build alias tables
-    G = synth.flow_graph_torch(R, T, wl["mean_degree"], dev)
+    if wl.get("powerlaw"):
+        G = synth.powerlaw_flow_graph_torch(R, T, wl["n_edges"], dev)
+    else:
+        G = synth.flow_graph_torch(R, T, wl["mean_degree"], dev)
     g = E.DeviceGraph(local_rank)
     g.add_edges_device(G["src"], G["dst"], G["w"])
     n_edges = G["n_edges"]

@@ -53,3 +53,38 @@ def flow_graph_torch(R, T, mean_degree, device, seed=SEED, sigma=1.0, weight_mea
     sources = np.arange(R, dtype=np.int32)
     return dict(src=src.contiguous(), dst=dst.to(torch.int32).contiguous(), w=w.contiguous(), sources=sources,
                 n_vertices=V, n_edges=E, R=R, T=T)
+
+
+def powerlaw_flow_graph_torch(R, T, n_edges, device, seed=SEED, alpha=2.1, max_degree=1_000_000, weight_mean=20.0):
+    """cfg5: power-law out-degree (exponent alpha, capped) AND power-law in-popularity of the destination
+    regions, T slices.  Generated on the device in chunks of vertices so that 1 B edges need no 1 B-element temporaries
+    beyond the three COO arrays.  Returns torch tensors like flow_graph_torch."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    V = R * T
+    # out-degree: Pareto with P(d >= x) ~ x^(1-alpha), rescaled to hit n_edges in expectation, clamped to [1, min(R, max)]
+    u = torch.rand(V, generator=g, device=device, dtype=torch.float64).clamp_(min=1e-12)
+    raw = u.pow(-1.0 / (alpha - 1.0))
+    cap = float(min(R, max_degree))
+    scale = n_edges / float(raw.clamp(max=cap).sum().item())
+    deg = (raw * scale).clamp_(1.0, cap).to(torch.int64)
+    E = int(deg.sum().item())
+    src = torch.repeat_interleave(torch.arange(V, device=device, dtype=torch.int32), deg)
+    del u, raw
+    # destination popularity: region rank r drawn with P ~ (r+1)^-1 (Zipf) through an inverse-CDF on a uniform
+    ur = torch.rand(E, generator=g, device=device, dtype=torch.float32)
+    dst_region = (torch.exp(ur * float(np.log(R + 1.0))) - 1.0).to(torch.int64).clamp_(0, R - 1).to(torch.int32)
+    del ur
+    if T > 1:
+        layer = torch.div(src, R, rounding_mode="floor")
+        dst = (((layer + 1) % T) * R + dst_region).to(torch.int32)
+        del layer
+    else:
+        dst = dst_region
+    del dst_region
+    uw = torch.rand(E, generator=g, device=device, dtype=torch.float32).clamp_(min=1e-7)
+    w = (1.0 + torch.floor(-weight_mean * torch.log(uw))).to(torch.float64)
+    del uw
+    sources = np.arange(R, dtype=np.int32)
+    return dict(src=src.contiguous(), dst=dst.contiguous(), w=w.contiguous(), sources=sources, n_vertices=V, n_edges=E, R=R, T=T)
