@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--batch-walks", type=int, default=0, help="walks per step per GPU (default: epoch/10)")
     ap.add_argument("--workers", type=int, default=0, help="SGNS walk workers (0 = fill the device)")
     ap.add_argument("--policy", type=int, default=0, help="dge_train_config.update_policy (0 auto = float atomics)")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--force-exchange", action="store_true", help="run the delta exchange even with one rank (plumbing check)")
@@ -68,7 +69,16 @@ def main():
     from embedding_amd import synth
     from embedding_amd.distributed import allreduce_counts, exchange_deltas, shard_plan
 
-    wl = WORKLOADS[args.workload]
+    def stage(msg):
+        if rank == 0:
+            print("[bench %7.1fs] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
+
+    t_start = time.time()
+    wl = dict(WORKLOADS[args.workload])
+    if args.scale != 1.0:          # shrink a workload (debugging): fewer regions and edges, same shape
+        wl["R"] = max(16, int(wl["R"] * args.scale))
+        if "n_edges" in wl:
+            wl["n_edges"] = int(wl["n_edges"] * args.scale)
     R, T, L, D, K = wl["R"], wl["T"], wl["L"], wl["dim"], wl["negative"]
     NV = R * T
     t0 = time.time()
@@ -78,26 +88,32 @@ def main():
         G = synth.powerlaw_flow_graph_torch(R, T, wl["n_edges"], dev)
     else:
         G = synth.flow_graph_torch(R, T, wl["mean_degree"], dev)
+    stage("edge list generated: %d edges" % G["n_edges"])
     g = E.DeviceGraph(local_rank)
     g.add_edges_device(G["src"], G["dst"], G["w"])
     n_edges = G["n_edges"]
     sources = G["sources"] if T > 1 else np.arange(R, dtype=np.int32)
     del G
     torch.cuda.empty_cache()
+    stage("edges copied into the store")
     g.set_sources(sources)
+    stage("CSR built, sources set")
     g.build_alias(exact=False)       # Vose pairing: same distribution as the reference order, O(k) for hubs
+    stage("alias tables built")
 
     # ---- setup: this rank's shard of the epoch corpus, global vocabulary
     epoch_walks = wl["walks_per_vertex"] * NV
     shard0, shard = shard_plan(epoch_walks, N, rank)
     WALK_SEED = 20171106
     corpus = g.sample_walks_device(shard, L, seed=WALK_SEED, rng_mode=1, first_index=shard0)
+    stage("epoch corpus sampled: %d walks" % shard)
     counts = torch.zeros(NV, dtype=torch.int64, device=dev)
     corpus.count_tokens(NV, counts)
     allreduce_counts(counts)
     # epochs only sets the learning-rate horizon (alpha decays over epochs*total_words); the bench steps stay near alpha0
     cfg = E.make_config(D, L, NV, negative=K, min_count=2, epochs=1000, workers=args.workers, seed=1, update_policy=args.policy)
     model = E.SgnsModel.create(cfg, counts, local_rank)
+    stage("vocabulary, unigram table and weights ready")
     total_words = int(counts.sum().item())
     B = args.batch_walks or max(1, epoch_walks // 10)
     B = min(B, shard)
@@ -127,6 +143,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
+    stage("warm-up done")
     model.reset_stats()
     t1 = time.perf_counter()
     for i in range(args.steps):
@@ -170,7 +187,7 @@ def main():
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": measured_traffic(args.workload, args.policy, pairs_per_launch),
-                         "kernel": "k_sgns_train_locked" if (args.policy in (5, 6) or (args.policy == 0 and NV >= 262144)) else "k_sgns_train",
+                         "kernel": "k_sgns_train_locked" if (args.policy in (5, 6) or (args.policy == 0 and args.workload == "cfg3")) else "k_sgns_train",
                          "ms_per_launch": ms_per_launch,
                          "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
                          "walk_kernel_ms_per_launch": st["walk_kernel_ms"] / launches},

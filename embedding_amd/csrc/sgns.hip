@@ -36,6 +36,7 @@ struct dge_model {
     int32_t D = 0, stride = 0, NV = 0;
     int64_t T = 0;
     int64_t total_words = 0;
+    double neg_collision = 1.0;                 // sum of squared negative-sampling probabilities: P(two draws hit one row)
     float *d_syn0 = nullptr, *d_syn1neg = nullptr, *d_snap = nullptr;
     int32_t* d_vocab_ids = nullptr;
     int64_t* d_counts = nullptr;
@@ -1055,6 +1056,11 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         std::vector<double> cum((size_t)V);
         double twp = 0.0; const double power = 0.75;
         for (int64_t i = 0; i < V; i++) twp += pow((double)m->h_counts[(size_t)i], power);
+        {
+            double s2 = 0.0;
+            for (int64_t i = 0; i < V; i++) { double q = pow((double)m->h_counts[(size_t)i], power) / twp; s2 += q * q; }
+            m->neg_collision = s2;
+        }
         double d1 = 0.0;
         for (int64_t i = 0; i < V; i++) { d1 = (i == 0) ? pow((double)m->h_counts[0], power) / twp : d1 + pow((double)m->h_counts[(size_t)i], power) / twp; cum[(size_t)i] = d1; }
         double* d_cum = nullptr; int32_t *d_g = nullptr, *d_m = nullptr;
@@ -1164,7 +1170,8 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
         hipDeviceProp_t prop;
         DGE_HIP(hipGetDeviceProperties(&prop, m->device));
-        const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || (m->cfg.update_policy == 0 && m->V >= 262144)) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
+        const bool auto_locked = m->cfg.update_policy == 0 && m->V >= 262144 && (double)((int64_t)256 * 3 * 16) * 5.0 * m->neg_collision < 0.25;
+        const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || auto_locked) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)prop.multiProcessorCount * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
@@ -1173,7 +1180,15 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     // update policy (see Policy<> and dge_train_config.update_policy)
     // update policy (see Policy<>, k_sgns_train_locked and dge_train_config.update_policy)
     int pol = m->cfg.update_policy;
-    if (pol == 0) pol = workers == 1 ? 100 : (m->V >= 262144 ? 5 : 2);   // auto
+    if (pol == 0) {
+        // auto.  The commit-lock kernel is the fast one while lock attempts rarely fail: a try fails when the row is among
+        // the ~5 rows another worker holds, i.e. with probability ~ workers * 5 * sum_i q_i^2 (q = unigram^0.75 sampling
+        // probabilities).  cfg3 (uniform-ish, 1M rows, 12k workers): 0.07 -> locked, 8.9e8 edges/s.  A Zipf-popular
+        // vocabulary (cfg5) gives >> 1: the same kernel spins on its hot rows (measured 5e5 edges/s) while memory-side
+        // atomics are indifferent to the skew (5.9e7 = their byte rate) -> atomics.
+        const double fail = (double)((int64_t)256 * 3 * 16) * 5.0 * m->neg_collision;
+        pol = workers == 1 ? 100 : ((m->V >= 262144 && fail < 0.25) ? 5 : 2);
+    }
     if (pol == 100 || (workers == 1 && pol != 5 && pol != 6 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
     if (pol == 3) pol = 0;
     unsigned threads = workers == 1 ? 64u : 256u;

@@ -128,7 +128,9 @@ typedef struct dge_train_config {
     int64_t table_size;      /* unigram^0.75 table length; 0 -> 100000000 (word2vec.c) */
     int32_t n_vertices;      /* vertex-id space of the corpus */
     int32_t update_policy;   /* how concurrent workers update the tables (MI355X has 8 L2s that are not coherent):
-                                0 = auto: 5 when the vocabulary has >= 262144 rows, else 2;
+                                0 = auto: 5 when the vocabulary has >= 262144 rows and its negative-sampling
+                                    distribution is flat enough for lock attempts to succeed (expected failure
+                                    rate < 0.25), else 2;
                                 1 = agent-scope row read-modify-write, write-through (last writer of a row wins);
                                 2 = agent-scope loads + memory-side float atomics (no update is lost);
                                 3 = plain cached accesses (debug only: every XCD trains a private stale copy);
