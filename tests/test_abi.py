@@ -52,3 +52,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
                 txt = open(os.path.join(d, f), errors="replace").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "dge_oracle" not in txt.replace("oracle/dge_oracle.c", ""), f
+
+
+def test_cpp_host_mirror_compiles_against_the_abi(tmp_path, dge):
+    """embedding_amd/host/embedding_host.hpp (the C++ mirror of LayeredGraph/CrossTimeGraph/SpatialGraph/DeepWalk) and its
+    test program build and link against libdge.so with plain g++; running it needs a GPU (tests/test_gpu_host_mirror.py)."""
+    import subprocess
+    libdir = os.path.join(ROOT, "embedding_amd")
+    exe = str(tmp_path / "host_mirror_test")
+    subprocess.check_call(["g++", "-O0", "-std=c++17", "-Wall", os.path.join(ROOT, "tests", "native", "host_mirror_test.cpp"), "-o", exe,
+                           "-L" + libdir, "-l:libdge.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    assert os.path.exists(exe)
