@@ -28,6 +28,10 @@ WORKLOADS = {
     # BASELINE.json configs[4]: power-law 10M-node / 1B-edge dynamic graph, D=256, K=20 (8 GPUs in the config; runs on 1)
     "cfg5": dict(R=416667, T=24, n_edges=1_000_000_000, dim=256, negative=20, L=24, walks_per_vertex=1, powerlaw=True,
                  name="power-law 10M-node / 1B-edge dynamic graph, 24 timeslices, dim=256, K=20, L=W=24"),
+    # BASELINE.json configs[0] at the reference's own size: tract level, 801 regions x 8 slices, D=20, 15.6 M walks
+    # (J/DeepWalk.java:62-66,89-104); the flow graph is synthetic (the taxi data is not shipped)
+    "cfg1": dict(R=801, T=8, mean_degree=200, dim=20, negative=5, L=8, walks_per_vertex=2434,
+                 name="reference-sized tract graph: 801 regions x 8 slices, dim=20, K=5, L=W=8, 15.6 M walks"),
     # small smoke-sized workload for quick checks
     "tiny": dict(R=2000, T=8, mean_degree=20, dim=128, negative=5, L=8, walks_per_vertex=10,
                  name="tiny 16k-node graph (debug)"),

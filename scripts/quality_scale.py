@@ -1,0 +1,51 @@
+"""Statistical parity at BASELINE's full size (cfg3 shape: 1 000 008 vertices, ~100 M edges, D=128, K=5, L=W=24):
+one epoch (10 M walks, 3.8e9 pairs) under each update policy on a graph WITH structure (regions form communities of 64;
+80 % of a vertex's flow stays inside its community), then link prediction on held-out walk steps:
+AUC of sigma(syn0[next] . syn1neg[current]) for true next-steps against random vertices of the same slice.
+Policy 2 (float atomics) loses no update and is the yardstick; 5/6 are the commit-lock kernels; 1 and 3 are shown for contrast."""
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+import embedding_amd as E
+
+R, T, L, D, K = 41667, 24, 24, 128, 5
+NV = R * T
+dev = "cuda:0"
+g0 = torch.Generator(device=dev); g0.manual_seed(1)
+deg = torch.exp(np.log(100) - 0.5 + torch.randn(NV, generator=g0, device=dev)).to(torch.int64).clamp_(1, R)
+Etot = int(deg.sum().item())
+src = torch.repeat_interleave(torch.arange(NV, device=dev, dtype=torch.int32), deg)
+reg = src % R
+inside = torch.rand(Etot, generator=g0, device=dev) < 0.8
+local = (reg // 64) * 64 + torch.randint(0, 64, (Etot,), generator=g0, device=dev, dtype=torch.int32)
+anyw = torch.randint(0, R, (Etot,), generator=g0, device=dev, dtype=torch.int32)
+dreg = torch.where(inside, local.clamp_(max=R - 1), anyw)
+dst = (((src // R + 1) % T) * R + dreg).to(torch.int32)
+w = (1.0 + torch.floor(-20.0 * torch.log(torch.rand(Etot, generator=g0, device=dev, dtype=torch.float64).clamp_(min=1e-12))))
+g = E.DeviceGraph(0); g.add_edges_device(src.contiguous(), dst.contiguous(), w.contiguous()); del src, dst, w, reg, inside, local, anyw, dreg
+g.set_sources(np.arange(R, dtype=np.int32)); g.build_alias(False)
+n = 10 * NV
+corpus = g.sample_walks_device(n, L, seed=5)
+test = torch.from_numpy(g.sample_walks(200_000, L, seed=99)).to(dev).to(torch.int64)
+counts = torch.zeros(NV, dtype=torch.int64, device=dev); corpus.count_tokens(NV, counts)
+
+def auc(m):
+    syn0, vid = m.vectors(); syn1 = m.syn1neg()
+    s0 = torch.from_numpy(syn0).to(dev); s1 = torch.from_numpy(syn1).to(dev)
+    remap = -torch.ones(NV, dtype=torch.int64, device=dev); remap[torch.from_numpy(vid.astype(np.int64)).to(dev)] = torch.arange(len(vid), device=dev)
+    a = remap[test[:, :-1].reshape(-1)]; b = remap[test[:, 1:].reshape(-1)]
+    ok = (a >= 0) & (b >= 0); a, b = a[ok], b[ok]
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    # negatives: a random region in the SAME slice as the true next vertex
+    vb = torch.from_numpy(vid.astype(np.int64)).to(dev)[b]
+    rb = remap[(vb // R) * R + torch.randint(0, R, (len(b),), generator=gen, device=dev)]
+    ok2 = rb >= 0; a, b, rb = a[ok2], b[ok2], rb[ok2]
+    pos = (s0[b] * s1[a]).sum(1); neg = (s0[rb] * s1[a]).sum(1)
+    return float((pos > neg).float().mean() + 0.5 * (pos == neg).float().mean()), float(pos.mean()), float(neg.mean())
+
+for pol in (2, 5, 6, 1, 3):
+    cfg = E.make_config(D, L, NV, negative=K, workers=0, update_policy=pol)
+    m = E.SgnsModel.create(cfg, counts, 0)
+    t = time.time(); m.train(corpus); st = m.stats(); dt = time.time() - t
+    print("policy", pol, "pairs %.3e" % st["pairs"], "kernel %.2fs" % (st["kernel_ms"] / 1e3), "-> %.3e edges/s" % (st["pairs"] / (st["kernel_ms"] / 1e3)),
+          "| AUC %.4f pos %.3f neg %.3f" % auc(m), flush=True)
+    m.close()
