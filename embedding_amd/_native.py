@@ -75,6 +75,10 @@ SIGNATURES = {
     "dge_model_snapshot": (_int, [_vp]),
     "dge_model_export_delta": (_int, [_vp, _vp]),
     "dge_model_import_delta": (_int, [_vp, _vp, C.c_float]),
+    "dge_comm_unique_id": (_int, [_vp]),
+    "dge_comm_create": (_int, [_P(_vp), _vp, _int, _int, _int]),
+    "dge_comm_free": (None, [_vp]),
+    "dge_model_allreduce_deltas": (_int, [_vp, _vp]),
     "dge_selftest_locked_rows": (_int, [_int, _i32, _i64, _i32, C.c_uint64, _i32, _P(_i64), _P(_dbl)]),
 }
 

@@ -1417,3 +1417,89 @@ extern "C" int dge_model_import_delta(dge_model* m, const float* d_buf, float sc
     DGE_HIP(hipGetLastError());
     return DGE_OK;
 }
+
+// ------------------------------------------------------------------------------------------ native RCCL exchange
+// For hosts without torch.distributed (the Java/JNI form): the same delta exchange with RCCL called directly.  librccl
+// is dlopen()ed on first use, so a process that already carries a RCCL (PyTorch bundles one) is never handed a second
+// copy at load time.
+#include <dlfcn.h>
+struct dge_comm {
+    void* nccl = nullptr;       // ncclComm_t
+    int rank = 0, nranks = 1, device = 0;
+    float* d_buf = nullptr; int64_t buf_floats = 0;
+};
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, dge_unique_id, int) = nullptr;     // ncclUniqueId is a 128-byte struct passed by value
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load() {
+    if (g_rccl.lib) return DGE_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) DGE_FAIL(DGE_ERR_DEVICE, "cannot load librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, dge_unique_id, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) DGE_FAIL(DGE_ERR_DEVICE, "librccl lacks an expected symbol");
+    g_rccl.lib = h;
+    return DGE_OK;
+}
+int rccl_fail(int rc, const char* what) {
+    DGE_FAIL(DGE_ERR_DEVICE, "RCCL %s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+}
+}  // namespace
+
+extern "C" int dge_comm_unique_id(dge_unique_id* out) {
+    if (!out) DGE_FAIL(DGE_ERR_ARG, "dge_comm_unique_id: null output");
+    int rc = rccl_load();
+    if (rc) return rc;
+    int n = g_rccl.GetUniqueId(out);
+    return n ? rccl_fail(n, "ncclGetUniqueId") : DGE_OK;
+}
+
+extern "C" int dge_comm_create(dge_comm** out, const dge_unique_id* id, int rank, int nranks, int device) {
+    if (!out || !id || nranks <= 0 || rank < 0 || rank >= nranks) DGE_FAIL(DGE_ERR_ARG, "dge_comm_create: bad argument");
+    *out = nullptr;
+    int rc = dge_require_device(device);
+    if (rc) return rc;
+    if ((rc = rccl_load())) return rc;
+    dge_comm* c = new dge_comm();
+    c->rank = rank; c->nranks = nranks; c->device = device;
+    int n = g_rccl.CommInitRank(&c->nccl, nranks, *id, rank);
+    if (n) { delete c; return rccl_fail(n, "ncclCommInitRank"); }
+    *out = c;
+    return DGE_OK;
+}
+
+extern "C" void dge_comm_free(dge_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl);
+    dge_dev_free(c->d_buf);
+    delete c;
+}
+
+// delta = tables - snapshot; all-reduce(sum) over the communicator; tables = snapshot + delta_sum / nranks; re-snapshot
+extern "C" int dge_model_allreduce_deltas(dge_model* m, dge_comm* c) {
+    if (!m || !c) DGE_FAIL(DGE_ERR_ARG, "dge_model_allreduce_deltas: null argument");
+    if (c->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_allreduce_deltas: communicator and model live on different devices");
+    DGE_HIP(hipSetDevice(m->device));
+    int64_t nfl = 0;
+    int rc = dge_model_sync_size(m, &nfl);
+    if (rc) return rc;
+    if (c->buf_floats < nfl) { dge_dev_free(c->d_buf); c->d_buf = nullptr; if ((rc = dge_dev_alloc(&c->d_buf, (size_t)nfl + 64))) return rc; c->buf_floats = nfl; }
+    if ((rc = dge_model_export_delta(m, c->d_buf))) return rc;
+    int n = g_rccl.AllReduce(c->d_buf, c->d_buf, (size_t)nfl, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->nccl, m->stream);
+    if (n) return rccl_fail(n, "ncclAllReduce");
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    return dge_model_import_delta(m, c->d_buf, 1.0f / (float)c->nranks);
+}

@@ -197,6 +197,17 @@ int  dge_model_snapshot(dge_model* m);                                     /* sn
 int  dge_model_export_delta(dge_model* m, float* d_buf);                  /* d_buf = current - snapshot */
 int  dge_model_import_delta(dge_model* m, const float* d_buf, float scale); /* current = snapshot + scale*d_buf; re-snapshot */
 
+/* The same exchange with RCCL called by the library itself (hosts without torch.distributed, e.g. the JNI form):
+ * rank 0 obtains an id, the host application hands it to the other ranks (any channel: file, socket, MPI), every rank
+ * creates its communicator, then dge_model_allreduce_deltas replaces the export/all-reduce/import triple.
+ * librccl is loaded lazily (dlopen) on the first of these calls. */
+typedef struct dge_comm dge_comm;
+typedef struct dge_unique_id { char bytes[128]; } dge_unique_id;          /* = ncclUniqueId */
+int  dge_comm_unique_id(dge_unique_id* out);
+int  dge_comm_create(dge_comm** out, const dge_unique_id* id, int rank, int nranks, int device);
+void dge_comm_free(dge_comm* c);
+int  dge_model_allreduce_deltas(dge_model* m, dge_comm* c);                /* needs dge_model_snapshot before the shard */
+
 /* ------------------------------------------------------------------------------------------------
  * Device self-test of the commit-lock protocol of update_policy 5 (new; no reference counterpart): n_workers groups
  * each do `iters` rounds of "lock 5 pseudo-random rows of an n_rows x 128 table, add 1.0 to every element, unlock".

@@ -273,3 +273,29 @@ def test_file_formats_roundtrip(tmp_path, oracle):
     assert n == ["0-17031", "1-17045"] and v.shape == (2, 2) and v[1, 0] == np.float32(1e-3)
     n, v = io.read_vec(os.path.join(GOLD, "taxi_all_head.vec"), header=True)
     assert n == ["1", "2", "3"] and v.shape == (3, 8)
+
+
+def test_quality_metric_restatement(oracle):
+    """embedding_amd/evaluate.py (P/embeddingEvaluation_tract.py:169-196,249-260): KNN by cosine distance + nDCG@k."""
+    from embedding_amd import evaluate as ev
+    rng = np.random.default_rng(0)
+    f = rng.normal(size=(12, 5)); f[3] = 0.0                        # a zero vector: cosine is NaN -> distance 2
+    rids = [100 + i for i in range(12)]
+    est, nb = ev.pairwise_estimator(f, rids)
+    assert all(len(nb[r]) == 11 and r not in nb[r] for r in rids)
+    assert all(np.all(np.diff([d for _, d in est[r]]) >= 0) for r in rids)      # ascending distance
+    assert est[100][-1] == (103, 2.0) and all(d == 2.0 for _, d in est[103])
+    i, j = 0, rids.index(nb[100][0])
+    assert abs(est[100][0][1] - (1 - f[i] @ f[j] / np.linalg.norm(f[i]) / np.linalg.norm(f[j]))) < 1e-12
+    assert abs(ev.ndcg_against(f, f, rids, k=5) - 1.0) < 1e-12        # a feature set against itself
+    g = f + 0.01 * rng.normal(size=f.shape); g[3] = 0.0
+    assert 0.9 < ev.ndcg_against(g, f, rids, k=5) <= 1.0 + 1e-12
+    assert ev.ndcg_against(rng.normal(size=f.shape), f, rids, k=5) < ev.ndcg_against(g, f, rids, k=5)
+    # statistical parity of two training schedules of the oracle on one slice of a small layered graph
+    src, dst, w, sources = layered_graph(R=40, T=4, deg=6, seed=1)
+    gph = oracle.Graph(); gph.add_edges(src, dst, w); gph.set_sources(sources); gph.build_alias(True)
+    walks = gph.sample_walks(4000, 4, seed=3, rng_mode=1)
+    a = oracle.train_sgns(walks, 160, 16, 4, table_size=5003, threads=1)
+    b = oracle.train_sgns(walks, 160, 16, 4, table_size=5003, threads=4)
+    sl = [r for r, v in enumerate(a.vocab_ids) if 40 <= v < 80]      # the rows of slice 1
+    assert ev.ndcg_against(b.syn0[sl], a.syn0[sl], [int(a.vocab_ids[r]) for r in sl], k=5) > 0.8
