@@ -194,7 +194,9 @@ def main():
                          "kernel": "k_sgns_train_locked" if (args.policy in (5, 6) or (args.policy == 0 and args.workload == "cfg3")) else "k_sgns_train",
                          "ms_per_launch": ms_per_launch,
                          "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
-                         "walk_kernel_ms_per_launch": st["walk_kernel_ms"] / launches},
+                         "walk_kernel_ms_per_launch": st["walk_kernel_ms"] / launches,
+                         "walk_steps_per_s": (B * L) / (st["walk_kernel_ms"] / launches * 1e-3) if st["walk_kernel_ms"] > 0 else None,
+                         "walk_bytes_per_step": 36},
         }
         if N == 1 and not args.no_cpu_baseline:
             sample = g.sample_walks(min(shard, 400_000), L, seed=WALK_SEED, rng_mode=1, first_index=shard0)   # = first rows of the corpus

@@ -37,6 +37,7 @@ struct dge_model {
     int64_t T = 0;
     int64_t total_words = 0;
     double neg_collision = 1.0;                 // sum of squared negative-sampling probabilities: P(two draws hit one row)
+    int n_cus = 256;
     float *d_syn0 = nullptr, *d_syn1neg = nullptr, *d_snap = nullptr;
     int32_t* d_vocab_ids = nullptr;
     int64_t* d_counts = nullptr;
@@ -1007,6 +1008,7 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     hipError_t he = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (he != hipSuccess) { delete m; DGE_FAIL(DGE_ERR_DEVICE, "hipStreamCreate failed"); }
     m->own_stream = true;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->n_cus = prop.multiProcessorCount; }
     hipStream_t st = m->stream;
     const int32_t NV = m->NV;
 
@@ -1168,11 +1170,9 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // fill the device: 4 blocks of 16 workers per CU, but never more concurrent walks than half the vocabulary
         // (Hogwild's premise is sparse collisions: measured, a 2.3k-row table keeps 0.99 cosine to the in-order
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
-        hipDeviceProp_t prop;
-        DGE_HIP(hipGetDeviceProperties(&prop, m->device));
-        const bool auto_locked = m->cfg.update_policy == 0 && m->V >= 262144 && (double)((int64_t)256 * 3 * 16) * 5.0 * m->neg_collision < 0.25;
+        const bool auto_locked = m->cfg.update_policy == 0 && m->V >= 262144 && (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision < 0.25;
         const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || auto_locked) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
-        workers = (int64_t)prop.multiProcessorCount * blocks_per_cu * 16;
+        workers = (int64_t)m->n_cus * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
     } else workers = m->cfg.workers;
@@ -1186,7 +1186,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // probabilities).  cfg3 (uniform-ish, 1M rows, 12k workers): 0.07 -> locked, 8.9e8 edges/s.  A Zipf-popular
         // vocabulary (cfg5) gives >> 1: the same kernel spins on its hot rows (measured 5e5 edges/s) while memory-side
         // atomics are indifferent to the skew (5.9e7 = their byte rate) -> atomics.
-        const double fail = (double)((int64_t)256 * 3 * 16) * 5.0 * m->neg_collision;
+        const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
         pol = workers == 1 ? 100 : ((m->V >= 262144 && fail < 0.25) ? 5 : 2);
     }
     if (pol == 100 || (workers == 1 && pol != 5 && pol != 6 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
