@@ -1172,7 +1172,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // (Hogwild's premise is sparse collisions: measured, a 2.3k-row table keeps 0.99 cosine to the in-order
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
         const bool auto_locked = m->cfg.update_policy == 0 && m->V >= 262144 && (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision < 0.25;
-        const int blocks_per_cu = ((m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || auto_locked) && ) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
+        const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || auto_locked) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)m->n_cus * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
