@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--force-exchange", action="store_true", help="run the delta exchange even with one rank (plumbing check)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo lets several ranks share one GPU (debugging the multi-rank plumbing)")
     args = ap.parse_args()
 
     import numpy as np
@@ -63,11 +65,16 @@ def main():
     if args.gpus != world and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     N = world
+    if args.backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)      # several ranks on one card (debug only)
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if N > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device(dev))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device(dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=N)
 
     import embedding_amd as E
     from embedding_amd import synth
@@ -125,7 +132,7 @@ def main():
     exchange = N > 1 or args.force_exchange
     if exchange and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+        dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": torch.device(dev)} if args.backend == "nccl" else {}))
     if exchange:
         delta = torch.empty(model.sync_size(), dtype=torch.float32, device=dev)
         model.snapshot()
