@@ -36,6 +36,19 @@ static inline int dge_dev_alloc(T** p, size_t n) {
 }
 static inline void dge_dev_free(void* p) { if (p) (void)hipFree(p); }
 
+// scratch device buffer of one call: freed on every exit path
+template <typename T>
+struct dge_tmp {
+    T* p = nullptr;
+    dge_tmp() = default;
+    dge_tmp(const dge_tmp&) = delete;
+    dge_tmp& operator=(const dge_tmp&) = delete;
+    ~dge_tmp() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { if (p) { (void)hipFree(p); p = nullptr; } return dge_dev_alloc(&p, n); }
+    T* release() { T* q = p; p = nullptr; return q; }
+    operator T*() const { return p; }
+};
+
 // One alias slot as the walk kernel reads it: 16 bytes, one dwordx4 load per step.
 // nbr_alias already resolves alias[i] to the neighbour it points at ("alias == -1" -> nbr itself).
 struct __attribute__((aligned(16))) dge_slot {

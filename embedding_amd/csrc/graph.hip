@@ -352,11 +352,11 @@ extern "C" int dge_graph_set_stream(dge_graph* g, void* hip_stream) {
 static int coo_reserve(dge_graph* g, int64_t extra) {
     if (g->n_coo + extra <= g->cap_coo) return DGE_OK;
     int64_t nc = (g->n_coo + extra) + (g->n_coo + extra) / 2 + 1024;
-    int32_t *ns = nullptr, *nd = nullptr; double* nw = nullptr;
+    dge_tmp<int32_t> ns, nd; dge_tmp<double> nw;
     int rc;
-    if ((rc = dge_dev_alloc(&ns, (size_t)nc))) return rc;
-    if ((rc = dge_dev_alloc(&nd, (size_t)nc))) return rc;
-    if ((rc = dge_dev_alloc(&nw, (size_t)nc))) return rc;
+    if ((rc = ns.alloc((size_t)nc))) return rc;
+    if ((rc = nd.alloc((size_t)nc))) return rc;
+    if ((rc = nw.alloc((size_t)nc))) return rc;
     if (g->n_coo) {
         DGE_HIP(hipMemcpyAsync(ns, g->d_coo_src, g->n_coo * sizeof(int32_t), hipMemcpyDeviceToDevice, g->stream));
         DGE_HIP(hipMemcpyAsync(nd, g->d_coo_dst, g->n_coo * sizeof(int32_t), hipMemcpyDeviceToDevice, g->stream));
@@ -364,7 +364,7 @@ static int coo_reserve(dge_graph* g, int64_t extra) {
         DGE_HIP(hipStreamSynchronize(g->stream));
     }
     dge_dev_free(g->d_coo_src); dge_dev_free(g->d_coo_dst); dge_dev_free(g->d_coo_w);
-    g->d_coo_src = ns; g->d_coo_dst = nd; g->d_coo_w = nw; g->cap_coo = nc;
+    g->d_coo_src = ns.release(); g->d_coo_dst = nd.release(); g->d_coo_w = nw.release(); g->cap_coo = nc;
     return DGE_OK;
 }
 
@@ -380,8 +380,8 @@ static int add_edges_common(dge_graph* g, const int32_t* src, const int32_t* dst
     DGE_HIP(hipMemcpyAsync(g->d_coo_dst + g->n_coo, dst, n * sizeof(int32_t), kind, g->stream));
     DGE_HIP(hipMemcpyAsync(g->d_coo_w + g->n_coo, w, n * sizeof(double), kind, g->stream));
     // id range check + vertex count (vertex ids are insertion ordinals: V = max id + 1)
-    int32_t* d_mm = nullptr;
-    if ((rc = dge_dev_alloc(&d_mm, 2))) return rc;
+    dge_tmp<int32_t> d_mm;
+    if ((rc = d_mm.alloc(2))) return rc;
     int32_t init[2] = {-1, 0x7fffffff};
     DGE_HIP(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, g->stream));
     unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
@@ -390,7 +390,6 @@ static int add_edges_common(dge_graph* g, const int32_t* src, const int32_t* dst
     int32_t mm[2];
     DGE_HIP(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, g->stream));
     DGE_HIP(hipStreamSynchronize(g->stream));
-    dge_dev_free(d_mm);
     if (mm[1] < 0) DGE_FAIL(DGE_ERR_RANGE, "dge_graph_add_edges: negative vertex id %d", mm[1]);
     if (mm[0] == 0x7fffffff) DGE_FAIL(DGE_ERR_RANGE, "dge_graph_add_edges: vertex id overflow");
     g->max_id = std::max(g->max_id, mm[0]);
@@ -420,23 +419,21 @@ int dge_graph_ensure_csr(dge_graph* g) {
     if ((rc = dge_dev_alloc(&g->d_outdeg, (size_t)V))) return rc;
     if (E > 0) {
         if (E >= (int64_t)0xFFFFFFFFLL) DGE_FAIL(DGE_ERR_ARG, "edge count %lld exceeds 2^32-1", (long long)E);
-        int32_t* d_keys = nullptr; uint32_t *d_idx = nullptr, *d_idx_sorted = nullptr;
-        if ((rc = dge_dev_alloc(&d_keys, (size_t)E))) return rc;
-        if ((rc = dge_dev_alloc(&d_idx, (size_t)E))) return rc;
-        if ((rc = dge_dev_alloc(&d_idx_sorted, (size_t)E))) return rc;
-        hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(E, 256)), dim3(256), 0, g->stream, d_idx, E);
+        dge_tmp<int32_t> d_keys; dge_tmp<uint32_t> d_idx, d_idx_sorted; dge_tmp<char> d_tmp;
+        if ((rc = d_keys.alloc((size_t)E))) return rc;
+        if ((rc = d_idx.alloc((size_t)E))) return rc;
+        if ((rc = d_idx_sorted.alloc((size_t)E))) return rc;
+        hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(E, 256)), dim3(256), 0, g->stream, d_idx.p, E);
         int end_bit = 1;
         while (end_bit < 31 && (1LL << end_bit) < (int64_t)V) end_bit++;
         size_t tmp_bytes = 0;
-        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, g->d_coo_src, d_keys, d_idx, d_idx_sorted, E, 0, end_bit, g->stream));
-        void* d_tmp = nullptr;
-        DGE_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
-        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, g->d_coo_src, d_keys, d_idx, d_idx_sorted, E, 0, end_bit, g->stream));
-        hipLaunchKernelGGL(k_gather_edges, dim3(grid_for(E, 256)), dim3(256), 0, g->stream, d_idx_sorted, g->d_coo_dst, g->d_coo_w, g->d_nbr, g->d_w, E);
-        hipLaunchKernelGGL(k_row_ptr, dim3(grid_for((int64_t)V + 1, 256)), dim3(256), 0, g->stream, d_keys, E, V, g->d_row_ptr);
+        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, g->d_coo_src, d_keys.p, d_idx.p, d_idx_sorted.p, E, 0, end_bit, g->stream));
+        if ((rc = d_tmp.alloc(tmp_bytes))) return rc;
+        DGE_HIP(hipcub::DeviceRadixSort::SortPairs((void*)d_tmp.p, tmp_bytes, g->d_coo_src, d_keys.p, d_idx.p, d_idx_sorted.p, E, 0, end_bit, g->stream));
+        hipLaunchKernelGGL(k_gather_edges, dim3(grid_for(E, 256)), dim3(256), 0, g->stream, d_idx_sorted.p, g->d_coo_dst, g->d_coo_w, g->d_nbr, g->d_w, E);
+        hipLaunchKernelGGL(k_row_ptr, dim3(grid_for((int64_t)V + 1, 256)), dim3(256), 0, g->stream, d_keys.p, E, V, g->d_row_ptr);
         hipLaunchKernelGGL(k_out_degree, dim3(grid_for(V, 256)), dim3(256), 0, g->stream, g->d_row_ptr, g->d_w, V, g->d_outdeg);
         DGE_HIP(hipStreamSynchronize(g->stream));
-        dge_dev_free(d_tmp); dge_dev_free(d_keys); dge_dev_free(d_idx); dge_dev_free(d_idx_sorted);
     } else {
         DGE_HIP(hipMemsetAsync(g->d_row_ptr, 0, ((size_t)V + 1) * sizeof(int64_t), g->stream));
         DGE_HIP(hipStreamSynchronize(g->stream));
@@ -455,13 +452,12 @@ extern "C" int dge_graph_set_sources(dge_graph* g, const int32_t* v, int64_t n, 
     free_sources(g);
     if ((rc = dge_dev_alloc(&g->d_srcv, (size_t)n))) return rc;
     if ((rc = dge_dev_alloc(&g->d_src_w, (size_t)n))) return rc;
-    double* d_sum = nullptr;
-    if ((rc = dge_dev_alloc(&d_sum, 1))) return rc;
+    dge_tmp<double> d_sum;
+    if ((rc = d_sum.alloc(1))) return rc;
     if (n) DGE_HIP(hipMemcpyAsync(g->d_srcv, v, n * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
-    hipLaunchKernelGGL(k_sources, dim3(1), dim3(64), 0, g->stream, g->d_srcv, n, g->d_outdeg, g->d_src_w, stream_sum, d_sum);
-    DGE_HIP(hipMemcpyAsync(&g->src_weight_sum, d_sum, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    hipLaunchKernelGGL(k_sources, dim3(1), dim3(64), 0, g->stream, g->d_srcv, n, g->d_outdeg, g->d_src_w, stream_sum, d_sum.p);
+    DGE_HIP(hipMemcpyAsync(&g->src_weight_sum, d_sum.p, sizeof(double), hipMemcpyDeviceToHost, g->stream));
     DGE_HIP(hipStreamSynchronize(g->stream));
-    dge_dev_free(d_sum);
     g->S = n;
     g->alias_built = false;
     return DGE_OK;
@@ -473,49 +469,45 @@ extern "C" int dge_graph_keep_top_k(dge_graph* g, int32_t k) {
     if (rc) return rc;
     const int32_t V = g->V; const int64_t E = g->E;
     if (V == 0) return DGE_OK;
-    unsigned long long* d_min = nullptr;
-    if ((rc = dge_dev_alloc(&d_min, 1))) return rc;
+    dge_tmp<unsigned long long> d_min;
+    if ((rc = d_min.alloc(1))) return rc;
     DGE_HIP(hipMemsetAsync(d_min, 0xFF, sizeof(unsigned long long), g->stream));
-    hipLaunchKernelGGL(k_min_degree, dim3(std::min<unsigned>(grid_for(V, 256), 2048u)), dim3(256), 0, g->stream, g->d_row_ptr, V, d_min);
+    hipLaunchKernelGGL(k_min_degree, dim3(std::min<unsigned>(grid_for(V, 256), 2048u)), dim3(256), 0, g->stream, g->d_row_ptr, V, d_min.p);
     unsigned long long mind = 0;
-    DGE_HIP(hipMemcpyAsync(&mind, d_min, sizeof(mind), hipMemcpyDeviceToHost, g->stream));
+    DGE_HIP(hipMemcpyAsync(&mind, d_min.p, sizeof(mind), hipMemcpyDeviceToHost, g->stream));
     DGE_HIP(hipStreamSynchronize(g->stream));
-    dge_dev_free(d_min);
     if (mind < (unsigned long long)k)
         DGE_FAIL(DGE_ERR_TOPK, "keepNearestKVertices(%d): a vertex has only %llu out-edges (the reference throws IndexOutOfBoundsException)", k, mind);
-    double* d_ws = nullptr; int32_t* d_ns = nullptr;
-    if ((rc = dge_dev_alloc(&d_ws, (size_t)E))) return rc;
-    if ((rc = dge_dev_alloc(&d_ns, (size_t)E))) return rc;
+    dge_tmp<double> d_ws; dge_tmp<int32_t> d_ns; dge_tmp<char> d_tmp;
+    if ((rc = d_ws.alloc((size_t)E))) return rc;
+    if ((rc = d_ns.alloc((size_t)E))) return rc;
     size_t tmp_bytes = 0;
-    DGE_HIP(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, tmp_bytes, g->d_w, d_ws, g->d_nbr, d_ns, E, V,
+    DGE_HIP(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, tmp_bytes, g->d_w, d_ws.p, g->d_nbr, d_ns.p, E, V,
                                                                   g->d_row_ptr, g->d_row_ptr + 1, 0, 64, g->stream));
-    void* d_tmp = nullptr;
-    DGE_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
-    DGE_HIP(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(d_tmp, tmp_bytes, g->d_w, d_ws, g->d_nbr, d_ns, E, V,
+    if ((rc = d_tmp.alloc(tmp_bytes))) return rc;
+    DGE_HIP(hipcub::DeviceSegmentedRadixSort::SortPairsDescending((void*)d_tmp.p, tmp_bytes, g->d_w, d_ws.p, g->d_nbr, d_ns.p, E, V,
                                                                   g->d_row_ptr, g->d_row_ptr + 1, 0, 64, g->stream));
-    int64_t* nrp = nullptr; double* nw = nullptr; int32_t* nn = nullptr;
+    dge_tmp<int64_t> nrp; dge_tmp<double> nw; dge_tmp<int32_t> nn;
     const int64_t NE = (int64_t)V * k;
-    if ((rc = dge_dev_alloc(&nrp, (size_t)V + 1))) return rc;
-    if ((rc = dge_dev_alloc(&nw, (size_t)NE))) return rc;
-    if ((rc = dge_dev_alloc(&nn, (size_t)NE))) return rc;
-    hipLaunchKernelGGL(k_topk_compact, dim3(grid_for((int64_t)V + 1, 256)), dim3(256), 0, g->stream, g->d_row_ptr, d_ws, d_ns, V, k,
-                       nrp, nw, nn, g->d_outdeg);
+    if ((rc = nrp.alloc((size_t)V + 1))) return rc;
+    if ((rc = nw.alloc((size_t)NE))) return rc;
+    if ((rc = nn.alloc((size_t)NE))) return rc;
+    hipLaunchKernelGGL(k_topk_compact, dim3(grid_for((int64_t)V + 1, 256)), dim3(256), 0, g->stream, g->d_row_ptr, d_ws.p, d_ns.p, V, k,
+                       nrp.p, nw.p, nn.p, g->d_outdeg);
     DGE_HIP(hipStreamSynchronize(g->stream));
     DGE_HIP(hipGetLastError());
-    dge_dev_free(d_tmp); dge_dev_free(d_ws); dge_dev_free(d_ns);
     dge_dev_free(g->d_row_ptr); dge_dev_free(g->d_w); dge_dev_free(g->d_nbr);
     dge_dev_free(g->d_prob); dge_dev_free(g->d_alias); dge_dev_free(g->d_slots);
     g->d_prob = nullptr; g->d_alias = nullptr; g->d_slots = nullptr;
-    g->d_row_ptr = nrp; g->d_w = nw; g->d_nbr = nn; g->E = NE;
+    g->d_row_ptr = nrp.release(); g->d_w = nw.release(); g->d_nbr = nn.release(); g->E = NE;
     g->alias_built = false;
     // source weights depend on outDegree: refresh them if sources were already set
     if (g->S > 0) {
-        double* d_sum = nullptr;
-        if ((rc = dge_dev_alloc(&d_sum, 1))) return rc;
-        hipLaunchKernelGGL(k_sources, dim3(1), dim3(64), 0, g->stream, g->d_srcv, g->S, g->d_outdeg, g->d_src_w, 1, d_sum);
-        DGE_HIP(hipMemcpyAsync(&g->src_weight_sum, d_sum, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+        dge_tmp<double> d_sum;
+        if ((rc = d_sum.alloc(1))) return rc;
+        hipLaunchKernelGGL(k_sources, dim3(1), dim3(64), 0, g->stream, g->d_srcv, g->S, g->d_outdeg, g->d_src_w, 1, d_sum.p);
+        DGE_HIP(hipMemcpyAsync(&g->src_weight_sum, d_sum.p, sizeof(double), hipMemcpyDeviceToHost, g->stream));
         DGE_HIP(hipStreamSynchronize(g->stream));
-        dge_dev_free(d_sum);
     }
     return DGE_OK;
 }
@@ -535,23 +527,22 @@ extern "C" int dge_graph_build_alias(dge_graph* g, int exact) {
     if ((rc = dge_dev_alloc(&g->d_src_prob, (size_t)S))) return rc;
     if ((rc = dge_dev_alloc(&g->d_src_alias, (size_t)S))) return rc;
     if ((rc = dge_dev_alloc(&g->d_src_slots, (size_t)S))) return rc;
-    uint64_t* d_bs = nullptr; int32_t* d_vs = nullptr;
+    dge_tmp<uint64_t> d_bs; dge_tmp<int32_t> d_vs;
     if (exact) {
         size_t words = (size_t)std::max<int64_t>(2 * (E / 32 + 6 * (int64_t)V) + 64, 2 * dge_bs_words(S) + 64);
-        if ((rc = dge_dev_alloc(&d_bs, words))) return rc;
+        if ((rc = d_bs.alloc(words))) return rc;
     } else {
-        if ((rc = dge_dev_alloc(&d_vs, (size_t)std::max<int64_t>(E, S) + 1))) return rc;
+        if ((rc = d_vs.alloc((size_t)std::max<int64_t>(E, S) + 1))) return rc;
     }
     if (V > 0)
         hipLaunchKernelGGL(k_alias_vertices, dim3(grid_for(V, 64)), dim3(64), 0, g->stream, V, g->d_row_ptr, g->d_w, g->d_nbr,
-                           g->d_outdeg, g->d_prob, g->d_alias, g->d_slots, exact, d_bs, d_vs);
+                           g->d_outdeg, g->d_prob, g->d_alias, g->d_slots, exact, d_bs.p, d_vs.p);
     DGE_HIP(hipStreamSynchronize(g->stream));
     if (S > 0)
         hipLaunchKernelGGL(k_alias_sources, dim3(1), dim3(64), 0, g->stream, S, g->d_src_w, g->src_weight_sum, g->d_srcv,
-                           g->d_src_prob, g->d_src_alias, g->d_src_slots, exact, d_bs, d_vs);
+                           g->d_src_prob, g->d_src_alias, g->d_src_slots, exact, d_bs.p, d_vs.p);
     DGE_HIP(hipStreamSynchronize(g->stream));
     DGE_HIP(hipGetLastError());
-    dge_dev_free(d_bs); dge_dev_free(d_vs);
     g->alias_built = true;
     return DGE_OK;
 }
@@ -617,13 +608,12 @@ extern "C" int dge_graph_sample_next(const dge_graph* g, int32_t v, double x, in
     if (v < 0 || v >= g->V) DGE_FAIL(DGE_ERR_RANGE, "dge_graph_sample_next: vertex %d not in graph (V=%d)", v, g->V);
     if (!(x >= 0.0 && x < 1.0)) DGE_FAIL(DGE_ERR_ARG, "dge_graph_sample_next: x must be in [0,1)");
     DGE_HIP(hipSetDevice(g->device));
-    int32_t* d_out = nullptr;
-    int rc = dge_dev_alloc(&d_out, 1);
+    dge_tmp<int32_t> d_out;
+    int rc = d_out.alloc(1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_sample_next, dim3(1), dim3(64), 0, g->stream, g->d_row_ptr, g->d_slots, v, x, d_out);
-    DGE_HIP(hipMemcpyAsync(next, d_out, sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+    hipLaunchKernelGGL(k_sample_next, dim3(1), dim3(64), 0, g->stream, g->d_row_ptr, g->d_slots, v, x, d_out.p);
+    DGE_HIP(hipMemcpyAsync(next, d_out.p, sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
     DGE_HIP(hipStreamSynchronize(g->stream));
-    dge_dev_free(d_out);
     return DGE_OK;
 }
 
@@ -645,10 +635,10 @@ static int sample_walks_impl(const dge_graph* g, int64_t n_walks, int32_t max_le
     if (rng_mode != 0 && rng_mode != 1) DGE_FAIL(DGE_ERR_ARG, "dge_sample_walks: rng_mode must be 0 or 1");
     DGE_HIP(hipSetDevice(g->device));
     if (n_walks == 0) { if (draws_consumed) *draws_consumed = 0; return DGE_OK; }
-    int32_t* d_dead = nullptr;
-    int rc = dge_dev_alloc(&d_dead, 1);
+    dge_tmp<int32_t> d_dead;
+    int rc = d_dead.alloc(1);
     if (rc) return rc;
-    DGE_HIP(hipMemsetAsync(d_dead, 0, sizeof(int32_t), g->stream));
+    DGE_HIP(hipMemsetAsync(d_dead.p, 0, sizeof(int32_t), g->stream));
     int64_t walk0 = first_index;
     if (rng_mode == 0) {
         // sequential stream: if no walk dead-ends every walk takes exactly max_len draws and the stream
@@ -658,12 +648,11 @@ static int sample_walks_impl(const dge_graph* g, int64_t n_walks, int32_t max_le
     }
     int32_t dead = 1;
     if (walk0 >= 0) {
-        rc = dge_launch_walks_strided(g, g->stream, d_out, n_walks, max_len, seed, walk0, d_dead);
-        if (rc) { dge_dev_free(d_dead); return rc; }
-        DGE_HIP(hipMemcpyAsync(&dead, d_dead, sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+        rc = dge_launch_walks_strided(g, g->stream, d_out, n_walks, max_len, seed, walk0, d_dead.p);
+        if (rc) return rc;
+        DGE_HIP(hipMemcpyAsync(&dead, d_dead.p, sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
         DGE_HIP(hipStreamSynchronize(g->stream));
     }
-    dge_dev_free(d_dead);
     if (rng_mode == 1) {
         if (draws_consumed) *draws_consumed = n_walks * (int64_t)max_len;   // stride, not data-dependent
         return DGE_OK;
@@ -675,37 +664,35 @@ static int sample_walks_impl(const dge_graph* g, int64_t n_walks, int32_t max_le
         DGE_HIP(hipMemsetAsync(d_out, 0xFF, (size_t)(n_walks * max_len) * sizeof(int32_t), g->stream));
         DGE_HIP(hipStreamSynchronize(g->stream));
     } else if (n_walks < 2048) {      // short corpora: one lane chains the walks
-        int64_t* d_draws = nullptr;
-        if ((rc = dge_dev_alloc(&d_draws, 1))) return rc;
+        dge_tmp<int64_t> d_draws;
+        if ((rc = d_draws.alloc(1))) return rc;
         hipLaunchKernelGGL(k_walks_sequential, dim3(1), dim3(64), 0, g->stream, g->d_row_ptr, g->d_slots, g->d_src_slots, g->S, d_out,
-                           n_walks, max_len, dge_jr_scramble(seed), first_index, d_draws);
-        DGE_HIP(hipMemcpyAsync(&draws, d_draws, sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+                           n_walks, max_len, dge_jr_scramble(seed), first_index, d_draws.p);
+        DGE_HIP(hipMemcpyAsync(&draws, d_draws.p, sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
         DGE_HIP(hipStreamSynchronize(g->stream));
         DGE_HIP(hipGetLastError());
-        dge_dev_free(d_draws);
     } else {                          // parallel resolver (see k_seq_block_exits)
         const int64_t N = n_walks * (int64_t)max_len;
         const int64_t n_blocks = (N + SEQ_BLOCK - 1) / SEQ_BLOCK;
-        uint8_t* d_lens = nullptr; int32_t *d_exit = nullptr, *d_hops = nullptr, *d_se = nullptr; int64_t *d_si = nullptr, *d_starts = nullptr, *d_draws = nullptr;
-        if ((rc = dge_dev_alloc(&d_lens, (size_t)N + 256))) return rc;
-        if ((rc = dge_dev_alloc(&d_exit, (size_t)(n_blocks * max_len)))) return rc;
-        if ((rc = dge_dev_alloc(&d_hops, (size_t)(n_blocks * max_len)))) return rc;
-        if ((rc = dge_dev_alloc(&d_se, (size_t)n_blocks))) return rc;
-        if ((rc = dge_dev_alloc(&d_si, (size_t)n_blocks))) return rc;
-        if ((rc = dge_dev_alloc(&d_starts, (size_t)n_walks))) return rc;
-        if ((rc = dge_dev_alloc(&d_draws, 1))) return rc;
+        dge_tmp<uint8_t> d_lens; dge_tmp<int32_t> d_exit, d_hops, d_se; dge_tmp<int64_t> d_si, d_starts, d_draws;
+        if ((rc = d_lens.alloc((size_t)N + 256))) return rc;
+        if ((rc = d_exit.alloc((size_t)(n_blocks * max_len)))) return rc;
+        if ((rc = d_hops.alloc((size_t)(n_blocks * max_len)))) return rc;
+        if ((rc = d_se.alloc((size_t)n_blocks))) return rc;
+        if ((rc = d_si.alloc((size_t)n_blocks))) return rc;
+        if ((rc = d_starts.alloc((size_t)n_walks))) return rc;
+        if ((rc = d_draws.alloc(1))) return rc;
         const size_t lds = (size_t)WALK_BLOCK * (size_t)(max_len | 1) * sizeof(int32_t);
         hipLaunchKernelGGL(k_walks, dim3(grid_for(N, WALK_BLOCK)), dim3(WALK_BLOCK), lds, g->stream, g->d_row_ptr, g->d_slots, g->d_src_slots, g->S,
-                           (int32_t*)nullptr, N, max_len, dge_jr_scramble(seed), first_index, (int64_t)1, (const int64_t*)nullptr, d_lens, (int32_t*)nullptr);
-        hipLaunchKernelGGL(k_seq_block_exits, dim3(grid_for(n_blocks * max_len, 256)), dim3(256), 0, g->stream, d_lens, N, max_len, n_blocks, d_exit, d_hops);
-        hipLaunchKernelGGL(k_seq_chain, dim3(1), dim3(64), 0, g->stream, d_exit, d_hops, max_len, n_blocks, d_se, d_si);
-        hipLaunchKernelGGL(k_seq_starts, dim3(grid_for(n_blocks, 256)), dim3(256), 0, g->stream, d_lens, N, n_blocks, d_se, d_si, first_index, n_walks, d_starts, d_draws);
+                           (int32_t*)nullptr, N, max_len, dge_jr_scramble(seed), first_index, (int64_t)1, (const int64_t*)nullptr, d_lens.p, (int32_t*)nullptr);
+        hipLaunchKernelGGL(k_seq_block_exits, dim3(grid_for(n_blocks * max_len, 256)), dim3(256), 0, g->stream, d_lens.p, N, max_len, n_blocks, d_exit.p, d_hops.p);
+        hipLaunchKernelGGL(k_seq_chain, dim3(1), dim3(64), 0, g->stream, d_exit.p, d_hops.p, max_len, n_blocks, d_se.p, d_si.p);
+        hipLaunchKernelGGL(k_seq_starts, dim3(grid_for(n_blocks, 256)), dim3(256), 0, g->stream, d_lens.p, N, n_blocks, d_se.p, d_si.p, first_index, n_walks, d_starts.p, d_draws.p);
         hipLaunchKernelGGL(k_walks, dim3(grid_for(n_walks, WALK_BLOCK)), dim3(WALK_BLOCK), lds, g->stream, g->d_row_ptr, g->d_slots, g->d_src_slots, g->S,
-                           d_out, n_walks, max_len, dge_jr_scramble(seed), (int64_t)0, (int64_t)0, d_starts, (uint8_t*)nullptr, (int32_t*)nullptr);
-        DGE_HIP(hipMemcpyAsync(&draws, d_draws, sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+                           d_out, n_walks, max_len, dge_jr_scramble(seed), (int64_t)0, (int64_t)0, (const int64_t*)d_starts.p, (uint8_t*)nullptr, (int32_t*)nullptr);
+        DGE_HIP(hipMemcpyAsync(&draws, d_draws.p, sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
         DGE_HIP(hipStreamSynchronize(g->stream));
         DGE_HIP(hipGetLastError());
-        dge_dev_free(d_lens); dge_dev_free(d_exit); dge_dev_free(d_hops); dge_dev_free(d_se); dge_dev_free(d_si); dge_dev_free(d_starts); dge_dev_free(d_draws);
     }
     if (draws_consumed) *draws_consumed = draws;
     return DGE_OK;

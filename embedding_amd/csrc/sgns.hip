@@ -1017,28 +1017,26 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
 #define MH(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { dge_set_error("HIP error %s at %s:%d", hipGetErrorName(e__), __FILE__, __LINE__); model_release(m); delete m; return DGE_ERR_DEVICE; } } while (0)
 
     // --- vocabulary: stable descending sort on count (ids ascending inside a tie), keep count >= min_count
-    int32_t *d_ids = nullptr, *d_ids_sorted = nullptr; int64_t* d_cnt_sorted = nullptr; unsigned long long* d_kept = nullptr;
-    MC(dge_dev_alloc(&d_ids, (size_t)NV)); MC(dge_dev_alloc(&d_ids_sorted, (size_t)NV)); MC(dge_dev_alloc(&d_cnt_sorted, (size_t)NV));
-    MC(dge_dev_alloc(&d_kept, 2));
-    hipLaunchKernelGGL(k_iota_i32, dim3(grid_for(NV, 256)), dim3(256), 0, st, d_ids, (int64_t)NV);
+    dge_tmp<int32_t> d_ids, d_ids_sorted; dge_tmp<int64_t> d_cnt_sorted; dge_tmp<unsigned long long> d_kept; dge_tmp<char> d_tmp;
+    MC(d_ids.alloc((size_t)NV)); MC(d_ids_sorted.alloc((size_t)NV)); MC(d_cnt_sorted.alloc((size_t)NV));
+    MC(d_kept.alloc(2));
+    hipLaunchKernelGGL(k_iota_i32, dim3(grid_for(NV, 256)), dim3(256), 0, st, d_ids.p, (int64_t)NV);
     size_t tmp_bytes = 0;
-    MH(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, d_counts, d_cnt_sorted, d_ids, d_ids_sorted, NV, 0, 64, st));
-    void* d_tmp = nullptr;
-    MH(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
-    MH(hipcub::DeviceRadixSort::SortPairsDescending(d_tmp, tmp_bytes, d_counts, d_cnt_sorted, d_ids, d_ids_sorted, NV, 0, 64, st));
-    MH(hipMemsetAsync(d_kept, 0, 2 * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_count_kept, dim3(std::min<unsigned>(grid_for(NV, 256), 2048u)), dim3(256), 0, st, d_cnt_sorted, (int64_t)NV,
-                       (int64_t)cfg->min_count, d_kept);
+    MH(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, d_counts, d_cnt_sorted.p, d_ids.p, d_ids_sorted.p, NV, 0, 64, st));
+    MC(d_tmp.alloc(tmp_bytes));
+    MH(hipcub::DeviceRadixSort::SortPairsDescending((void*)d_tmp.p, tmp_bytes, d_counts, d_cnt_sorted.p, d_ids.p, d_ids_sorted.p, NV, 0, 64, st));
+    MH(hipMemsetAsync(d_kept.p, 0, 2 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_count_kept, dim3(std::min<unsigned>(grid_for(NV, 256), 2048u)), dim3(256), 0, st, d_cnt_sorted.p, (int64_t)NV,
+                       (int64_t)cfg->min_count, d_kept.p);
     unsigned long long kept = 0;
-    MH(hipMemcpyAsync(&kept, d_kept, sizeof(kept), hipMemcpyDeviceToHost, st));
+    MH(hipMemcpyAsync(&kept, d_kept.p, sizeof(kept), hipMemcpyDeviceToHost, st));
     MH(hipStreamSynchronize(st));
-    dge_dev_free(d_tmp); d_tmp = nullptr;
     const int64_t V = (int64_t)kept;
     m->V = V;
     MC(dge_dev_alloc(&m->d_vocab_ids, (size_t)V)); MC(dge_dev_alloc(&m->d_counts, (size_t)V)); MC(dge_dev_alloc(&m->d_remap, (size_t)NV));
     if (V) {
-        MH(hipMemcpyAsync(m->d_vocab_ids, d_ids_sorted, V * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        MH(hipMemcpyAsync(m->d_counts, d_cnt_sorted, V * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+        MH(hipMemcpyAsync(m->d_vocab_ids, d_ids_sorted.p, V * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        MH(hipMemcpyAsync(m->d_counts, d_cnt_sorted.p, V * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
     }
     MH(hipMemsetAsync(m->d_remap, 0xFF, (size_t)NV * sizeof(int32_t), st));
     if (V) hipLaunchKernelGGL(k_scatter_remap, dim3(grid_for(V, 256)), dim3(256), 0, st, m->d_vocab_ids, V, m->d_remap);
@@ -1048,7 +1046,6 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         MH(hipMemcpyAsync(m->h_vocab_ids.data(), m->d_vocab_ids, V * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     }
     MH(hipStreamSynchronize(st));
-    dge_dev_free(d_ids); dge_dev_free(d_ids_sorted); dge_dev_free(d_cnt_sorted); dge_dev_free(d_kept);
     int64_t tw = 0;
     for (int64_t i = 0; i < V; i++) tw += m->h_counts[(size_t)i];
     m->total_words = tw;
@@ -1066,17 +1063,16 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         }
         double d1 = 0.0;
         for (int64_t i = 0; i < V; i++) { d1 = (i == 0) ? pow((double)m->h_counts[0], power) / twp : d1 + pow((double)m->h_counts[(size_t)i], power) / twp; cum[(size_t)i] = d1; }
-        double* d_cum = nullptr; int32_t *d_g = nullptr, *d_m = nullptr;
-        MC(dge_dev_alloc(&d_cum, (size_t)V)); MC(dge_dev_alloc(&d_g, (size_t)m->T)); MC(dge_dev_alloc(&d_m, (size_t)m->T));
-        MH(hipMemcpyAsync(d_cum, cum.data(), V * sizeof(double), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_table_chase, dim3(grid_for(m->T, 256)), dim3(256), 0, st, d_cum, V, m->T, d_g);
+        dge_tmp<double> d_cum; dge_tmp<int32_t> d_g, d_m; dge_tmp<char> d_tmp2;
+        MC(d_cum.alloc((size_t)V)); MC(d_g.alloc((size_t)m->T)); MC(d_m.alloc((size_t)m->T));
+        MH(hipMemcpyAsync(d_cum.p, cum.data(), V * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_table_chase, dim3(grid_for(m->T, 256)), dim3(256), 0, st, d_cum.p, V, m->T, d_g.p);
         tmp_bytes = 0;
-        MH(hipcub::DeviceScan::ExclusiveScan(nullptr, tmp_bytes, d_g, d_m, hipcub::Min(), (int32_t)0, m->T, st));
-        MH(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
-        MH(hipcub::DeviceScan::ExclusiveScan(d_tmp, tmp_bytes, d_g, d_m, hipcub::Min(), (int32_t)0, m->T, st));
-        hipLaunchKernelGGL(k_table_fill, dim3(grid_for(m->T, 256)), dim3(256), 0, st, d_m, V, m->T, m->d_table);
+        MH(hipcub::DeviceScan::ExclusiveScan(nullptr, tmp_bytes, d_g.p, d_m.p, hipcub::Min(), (int32_t)0, m->T, st));
+        MC(d_tmp2.alloc(tmp_bytes));
+        MH(hipcub::DeviceScan::ExclusiveScan((void*)d_tmp2.p, tmp_bytes, d_g.p, d_m.p, hipcub::Min(), (int32_t)0, m->T, st));
+        hipLaunchKernelGGL(k_table_fill, dim3(grid_for(m->T, 256)), dim3(256), 0, st, d_m.p, V, m->T, m->d_table);
         MH(hipStreamSynchronize(st));
-        dge_dev_free(d_tmp); dge_dev_free(d_cum); dge_dev_free(d_g); dge_dev_free(d_m);
     } else {
         MH(hipMemsetAsync(m->d_table, 0, (size_t)m->T * sizeof(int32_t), st));
     }
