@@ -311,3 +311,35 @@ def test_vec_writer_roundtrip(dge, oracle, tmp_path):
     assert first == [str(len(vid)), "20"]
     rn2, rv2 = io.read_vec(str(tmp_path / "y.vec"), header=True)
     assert rn2 == [str(v) for v in vid] and np.array_equal(rv2, syn0)
+
+
+def test_cfg3_sized_epoch_slice_properties(dge):
+    """BASELINE configs[2] at full size (1 000 008 vertices, ~100 M edges, D=128, K=5, L=W=24): one bench-sized step under
+    the default policy, checked through properties that do not need an oracle replay."""
+    import torch
+    from embedding_amd import synth
+    R, T, L = 41667, 24, 24
+    NV = R * T
+    G = synth.flow_graph_torch(R, T, 100, "cuda:0")
+    g = dge.DeviceGraph(0)
+    g.add_edges_device(G["src"], G["dst"], G["w"]); del G
+    g.set_sources(np.arange(R, dtype=np.int32)); g.build_alias(exact=False)
+    n = 500_000
+    corpus = g.sample_walks_device(n, L, seed=20171106)
+    counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0")
+    corpus.count_tokens(NV, counts)
+    assert int(counts.sum().item()) == n * L                         # no dead ends in this graph
+    per_layer = counts.view(T, R).sum(1)
+    assert bool((per_layer == n).all())                              # token j of every walk lies in slice j
+    m = dge.SgnsModel.create(dge.make_config(128, L, NV, workers=0), counts, 0)
+    before = m.vectors()[0]
+    m.train(corpus)
+    st = m.stats()
+    words = int(counts[counts >= 2].sum().item())
+    assert st["words"] == words
+    # every centre pairs with between 1 and 23 others; DL4J's window draw makes the mean 383.3/24 per token
+    assert abs(st["pairs"] / st["words"] - 383.3 / 24) < 0.2
+    after = m.vectors()[0]
+    assert np.isfinite(after).all() and (np.abs(after - before).max(1) > 0).mean() > 0.99    # every trained row moved
+    assert np.isfinite(m.syn1neg()).all()
+    assert st["kernel_ms"] > 0 and st["pairs"] / (st["kernel_ms"] * 1e-3) > 1e8             # and it is the fast path
