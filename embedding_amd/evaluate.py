@@ -49,3 +49,16 @@ def ndcg_against(features, gnd_features, rids, k=10):
     gnd = {r: dict(v) for r, v in gest.items()}
     dcg_max = {r: dcg_at_k(k, gnd[r], gnb[r]) for r in rids}
     return ndcg_at_k(k, list(rids), nb, gnd, dcg_max)
+
+
+def knn_cosine_gpu(features, k, device=0):
+    """The same KNN lists from libdge.so (dge_knn_cosine: exact-f32 MFMA tiles fused with top-k on the MI355X).
+    -> (idx int32 [n x k], dist float32 [n x k], kernel_ms)."""
+    import ctypes as C
+    from ._native import check, lib
+    f = np.ascontiguousarray(features, np.float32)
+    n, D = f.shape
+    idx = np.empty((n, k), np.int32); dist = np.empty((n, k), np.float32); ms = C.c_double(0)
+    check(lib.dge_knn_cosine(int(device), f.ctypes.data_as(C.c_void_p), n, D, int(k), idx.ctypes.data_as(C.c_void_p),
+                             dist.ctypes.data_as(C.c_void_p), C.byref(ms)))
+    return idx, dist, ms.value

@@ -209,6 +209,15 @@ void dge_comm_free(dge_comm* c);
 int  dge_model_allreduce_deltas(dge_model* m, dge_comm* c);                /* needs dge_model_snapshot before the shard */
 
 /* ------------------------------------------------------------------------------------------------
+ * Quality metric ("next" row of the scope table): pairwiseEstimator of P/embeddingEvaluation_tract.py:169-196 — for every
+ * row of features [n x dim] the k other rows nearest in cosine distance (1 - cos; a zero vector is at distance 2 from
+ * everything), ascending, smaller index first among equals.  Exact-f32 MFMA tiles fused with the top-k selection.
+ * dim <= 256, k <= 64.  Host buffers.
+ * ---------------------------------------------------------------------------------------------- */
+int  dge_knn_cosine(int device, const float* features, int32_t n, int32_t dim, int32_t k, int32_t* out_idx, float* out_dist,
+                    double* ms_kernel);
+
+/* ------------------------------------------------------------------------------------------------
  * Device self-test of the commit-lock protocol of update_policy 5 (new; no reference counterpart): n_workers groups
  * each do `iters` rounds of "lock 5 pseudo-random rows of an n_rows x 128 table, add 1.0 to every element, unlock".
  * Returns the number of row increments performed and the largest |element - increments of its row| (0 when no
