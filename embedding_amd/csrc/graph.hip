@@ -374,6 +374,9 @@ static int add_edges_common(dge_graph* g, const int32_t* src, const int32_t* dst
     if (g->csr_built && g->E != g->n_coo)
         DGE_FAIL(DGE_ERR_STATE, "dge_graph_add_edges: edges cannot be added after keep_top_k pruned the store");
     DGE_HIP(hipSetDevice(g->device));
+    // device sources come from the caller's streams (e.g. torch's): wait for whatever produced them — this handle's
+    // stream is non-blocking and would otherwise race with the producer
+    if (kind == hipMemcpyDeviceToDevice) DGE_HIP(hipDeviceSynchronize());
     int rc = coo_reserve(g, n);
     if (rc) return rc;
     DGE_HIP(hipMemcpyAsync(g->d_coo_src + g->n_coo, src, n * sizeof(int32_t), kind, g->stream));

@@ -1000,6 +1000,7 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     if (cfg->dim > 512) DGE_FAIL(DGE_ERR_ARG, "dge_model_create: dim %d > 512 is not supported", cfg->dim);
     int rc = dge_require_device(device);
     if (rc) return rc;
+    DGE_HIP(hipDeviceSynchronize());      // d_counts may have been produced on the caller's streams (count kernel, all-reduce)
     dge_model* m = new dge_model();
     m->device = device;
     m->cfg = *cfg;
@@ -1405,6 +1406,7 @@ extern "C" int dge_model_import_delta(dge_model* m, const float* d_buf, float sc
     if (!m || !d_buf) DGE_FAIL(DGE_ERR_ARG, "dge_model_import_delta: null argument");
     if (!m->d_snap) DGE_FAIL(DGE_ERR_STATE, "dge_model_import_delta: no snapshot");
     DGE_HIP(hipSetDevice(m->device));
+    DGE_HIP(hipDeviceSynchronize());      // d_buf comes from the caller's collective, on the caller's stream
     int64_t tab = m->V * (int64_t)m->stride;
     if (tab) {
         hipLaunchKernelGGL(k_delta_import, dim3(2048), dim3(256), 0, m->stream, m->d_syn0, m->d_snap, d_buf, scale, tab);

@@ -15,7 +15,9 @@
  *   - Vertex ids are the caller's insertion ordinals (J/LayeredGraph.java:160,166): name <-> id
  *     interning ("h-regionId" strings) stays on the host-language side.
  *   - "host" pointers are ordinary process memory; "d_" pointers are device memory on the handle's
- *     device (e.g. a torch tensor's data_ptr()).
+ *     device (e.g. a torch tensor's data_ptr()).  Handles work on their own non-blocking HIP stream: entry points that
+ *     READ a caller's device buffer first wait for the device (hipDeviceSynchronize), entry points that WRITE one return
+ *     after their stream has drained, so no stream handshake is needed on the caller's side.
  *   - Handles are not thread-safe; the reference's walk API is single-threaded
  *     (J/CrossTimeGraph.java:134-140) and the trainer owns its workers (J/DeepWalk.java:75).
  */
