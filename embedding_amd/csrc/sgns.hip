@@ -713,6 +713,7 @@ k_sgns_train_locked(TrainParams p) {
         }
         row_zero(neu);
         bool have_l1 = false, abort_pair = false;
+        const bool l1_only = retry_pair;
         int kd = 0;
         do {    // chunks of up to 13 negatives (at least one pass so that the syn0 row is locked and loaded even when K == 0)
             const int kc = min(LK_NEG_LANES, K - kd);
@@ -745,8 +746,12 @@ k_sgns_train_locked(TrainParams p) {
                 bool flush_pending = base == 0 && pend_row >= 0;
                 while (pending || !have_l1) {
                     const int myq = lane - base;
-                    const bool want = (myq >= 0 && myq < NEG_BATCH && lane < kc && ((pending >> myq) & 1u)) ||
-                                      (lane == 13 && flush_pending) || (lane == 14 && !have_l1);
+                    // a pair that already lost the race for its syn0 row once asks for that row ALONE until it has it:
+                    // otherwise the many waiting workers of a hot row keep grabbing (and dropping) the syn1neg rows the
+                    // row's current holder needs, and the holder starves (seen as a hang on a 3-row vocabulary)
+                    const bool others_ok = have_l1 || !l1_only;
+                    const bool want = (others_ok && myq >= 0 && myq < NEG_BATCH && lane < kc && ((pending >> myq) & 1u)) ||
+                                      (others_ok && lane == 13 && flush_pending) || (lane == 14 && !have_l1);
                     const bool won = want ? row_trylock(lane == 14 ? locks0 : locks1, t) : false;
                     const unsigned long long bal = __ballot(won);
                     const unsigned gotl = (unsigned)(bal >> (threadIdx.x & 48)) & 0xFFFFu;
@@ -809,7 +814,7 @@ k_sgns_train_locked(TrainParams p) {
             } while (base < kc && !abort_pair);
             kd += LK_NEG_LANES;
         } while (kd < K && !abort_pair);
-        if (abort_pair) { retry_pair = true; __builtin_amdgcn_s_sleep(4); continue; }
+        if (abort_pair) { retry_pair = true; __builtin_amdgcn_s_sleep(8); continue; }
         retry_pair = false;
 
         {   // positive target: the centre's row lives in registers, its delta in LDS

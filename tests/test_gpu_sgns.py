@@ -343,3 +343,41 @@ def test_cfg3_sized_epoch_slice_properties(dge):
     assert np.isfinite(after).all() and (np.abs(after - before).max(1) > 0).mean() > 0.99    # every trained row moved
     assert np.isfinite(m.syn1neg()).all()
     assert st["kernel_ms"] > 0 and st["pairs"] / (st["kernel_ms"] * 1e-3) > 1e8             # and it is the fast path
+
+
+@pytest.mark.parametrize("negative", [0, 1, 13, 14, 27])
+def test_locked_kernel_negative_count_edges(dge, oracle, negative):
+    """The commit-lock kernel draws negatives in chunks of 13 lanes and batches of 5 rows: K = 0 (only the syn0 row is
+    locked), the chunk boundaries 13/14 and a multi-chunk K, for both commit forms, against the sequential oracle."""
+    walks, NV = _walks(oracle, dge, n=400)
+    om = oracle.train_sgns(walks, NV, 32, 6, negative=negative, table_size=20011, arith=0)
+    for pol in (5, 6):
+        c = dge.make_config(32, 6, NV, negative=negative, workers=1, table_size=20011, update_policy=pol)
+        dm = dge.SgnsModel.fit(walks, c, 0)
+        assert dm.stats()["pairs"] == om.pairs
+        assert cosine_rows(dm.vectors()[0], om.syn0).min() > 1 - 1e-4
+        if negative > 0 or om.pairs > 0:
+            assert np.abs(dm.syn1neg() - om.syn1neg).max() < 1e-3
+
+
+def test_locked_kernel_tiny_vocabularies_terminate(dge, oracle):
+    """V = 3: nearly every batch holds the same row several times (won in successive lock rounds) and every worker wants
+    the same three rows; V = 1: every negative is the centre itself and is skipped.  Must terminate, keep every lock free
+    afterwards (a second run would hang otherwise) and, with one worker, reproduce the sequential result."""
+    rng = np.random.default_rng(0)
+    walks = rng.integers(0, 3, (400, 5)).astype(np.int32)
+    om = oracle.train_sgns(walks, 3, 8, 5, min_count=1, table_size=101, arith=0)
+    for workers in (1, 16, 64):
+        for pol in (5, 6):
+            c = dge.make_config(8, 5, 3, min_count=1, workers=workers, table_size=101, update_policy=pol)
+            dm = dge.SgnsModel.fit(walks, c, 0)
+            assert dm.stats()["pairs"] == om.pairs and np.isfinite(dm.vectors()[0]).all()
+            if workers == 1:
+                assert cosine_rows(dm.vectors()[0], om.syn0).min() > 1 - 1e-4
+            corpus = dge.WalkCorpus.from_host(walks, 0)
+            dm.train(corpus)                                  # locks were all released: a second pass completes too
+            assert dm.stats()["pairs"] == 2 * om.pairs
+    ones = np.zeros((50, 4), np.int32)
+    o1 = oracle.train_sgns(ones, 1, 8, 4, min_count=1, table_size=11, arith=0)
+    d1 = dge.SgnsModel.fit(ones, dge.make_config(8, 4, 1, min_count=1, workers=4, table_size=11, update_policy=5), 0)
+    assert d1.stats()["pairs"] == o1.pairs and np.isfinite(d1.vectors()[0]).all()
