@@ -365,9 +365,9 @@ def test_locked_kernel_tiny_vocabularies_terminate(dge, oracle):
     the same three rows; V = 1: every negative is the centre itself and is skipped.  Must terminate, keep every lock free
     afterwards (a second run would hang otherwise) and, with one worker, reproduce the sequential result."""
     rng = np.random.default_rng(0)
-    walks = rng.integers(0, 3, (400, 5)).astype(np.int32)
+    walks = rng.integers(0, 3, (200, 5)).astype(np.int32)
     om = oracle.train_sgns(walks, 3, 8, 5, min_count=1, table_size=101, arith=0)
-    for workers in (1, 16, 64):
+    for workers in (1, 16):
         for pol in (5, 6):
             c = dge.make_config(8, 5, 3, min_count=1, workers=workers, table_size=101, update_policy=pol)
             dm = dge.SgnsModel.fit(walks, c, 0)
