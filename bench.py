@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch-walks", type=int, default=0, help="walks per step per GPU (default: epoch/10)")
     ap.add_argument("--workers", type=int, default=0, help="SGNS walk workers (0 = fill the device)")
+    ap.add_argument("--hs", action="store_true", help="train the hierarchical-softmax term as well (dge_train_config.use_hs; not the headline path)")
     ap.add_argument("--policy", type=int, default=0, help="dge_train_config.update_policy (0 auto = float atomics)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,7 +123,7 @@ def main():
     corpus.count_tokens(NV, counts)
     allreduce_counts(counts)
     # epochs only sets the learning-rate horizon (alpha decays over epochs*total_words); the bench steps stay near alpha0
-    cfg = E.make_config(D, L, NV, negative=K, min_count=2, epochs=1000, workers=args.workers, seed=1, update_policy=args.policy)
+    cfg = E.make_config(D, L, NV, negative=K, min_count=2, epochs=1000, workers=args.workers, seed=1, update_policy=args.policy, use_hs=args.hs)
     model = E.SgnsModel.create(cfg, counts, local_rank)
     stage("vocabulary, unigram table and weights ready")
     total_words = int(counts.sum().item())
@@ -174,6 +175,10 @@ def main():
     if rank == 0:
         value = total_pairs / elapsed
         bytes_per_pair = 8 * D * (K + 2)                      # one syn0 row + K+1 syn1neg rows, read+written
+        if args.hs:                                           # + the inner-node rows on the centre's Huffman path (count-weighted mean)
+            off, _, _ = model.huffman()
+            cnt = model.counts().astype(np.float64)
+            bytes_per_pair += 8 * D * float((np.diff(off) * cnt).sum() / max(cnt.sum(), 1.0))
         launches = max(st["launches"], 1)
         ms_per_launch = st["kernel_ms"] / launches
         pairs_per_launch = st["pairs"] / launches
@@ -194,7 +199,7 @@ def main():
             "config": {"workload": wl["name"], "vertices": NV, "edges": int(n_edges), "timeslices": T, "dim": D,
                        "negatives": K, "walk_len": L, "window": L, "walks_per_step_per_gpu": B,
                        "pairs_per_step_per_gpu": st["pairs"] / args.steps, "vocabulary": int((counts >= 2).sum().item()),
-                       "sgns_workers": args.workers, "update_policy": args.policy, "parallelism": "walk-shard x%d, RCCL all-reduce of deltas per step" % N if N > 1 else "1 GPU",
+                       "sgns_workers": args.workers, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": "walk-shard x%d, RCCL all-reduce of deltas per step" % N if N > 1 else "1 GPU",
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": measured_traffic(args.workload, args.policy, pairs_per_launch),

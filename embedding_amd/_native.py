@@ -20,6 +20,7 @@ class TrainConfig(C.Structure):
         ("dim", C.c_int32), ("window", C.c_int32), ("negative", C.c_int32), ("min_count", C.c_int32),
         ("epochs", C.c_int32), ("workers", C.c_int32), ("alpha", C.c_float), ("min_alpha", C.c_float),
         ("seed", C.c_uint64), ("table_size", C.c_int64), ("n_vertices", C.c_int32), ("update_policy", C.c_int32),
+        ("use_hs", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -65,6 +66,8 @@ SIGNATURES = {
     "dge_model_walk_and_train": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i64, _dbl, _i64]),
     "dge_model_vectors": (_int, [_vp, _P(_vp), _P(_vp), _P(_i64), _P(_i32)]),
     "dge_model_syn1neg": (_int, [_vp, _P(_vp)]),
+    "dge_model_syn1": (_int, [_vp, _P(_vp), _P(_i64)]),
+    "dge_model_huffman": (_int, [_vp, _P(_vp), _P(_vp), _P(_vp)]),
     "dge_model_counts": (_int, [_vp, _P(_vp)]),
     "dge_model_table": (_int, [_vp, _P(_vp), _P(_i64)]),
     "dge_model_stats": (_int, [_vp, _P(TrainStats)]),
@@ -81,6 +84,7 @@ SIGNATURES = {
     "dge_model_allreduce_deltas": (_int, [_vp, _vp]),
     "dge_knn_cosine": (_int, [_int, _vp, _i32, _i32, _i32, _vp, _vp, _P(_dbl)]),
     "dge_selftest_locked_rows": (_int, [_int, _i32, _i64, _i32, C.c_uint64, _i32, _P(_i64), _P(_dbl)]),
+    "dge_selftest_hot_add": (_int, [_int, _i32, _i64, _i32, _i32, C.c_uint64, _P(_i64), _P(_dbl)]),
 }
 
 

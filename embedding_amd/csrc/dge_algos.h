@@ -246,3 +246,55 @@ DGE_HD void dge_alias_vose(const double* w, int64_t k, double total, double* pro
     while (ns > 0) { int32_t s = scratch[--ns]; prob[s] = 1.0; }
     while (nl > 0) { int32_t l = scratch[k - nl]; nl--; prob[l] = 1.0; }
 }
+
+// ---------------------------------------------------------------- Huffman paths (hierarchical softmax)
+// The tree word2vec.c's CreateBinaryTree builds over counts sorted descending: leaves are consumed from the rare end,
+// merged nodes are appended in creation order (so they form a second, ascending queue); of two equal heads the MERGED
+// node is taken first (the leaf test is a strict <); the second node taken gets branch bit 1.  Inner node V+a is row a
+// of syn1, the root is row V-2.  Output in CSR form: path of word r = points[off[r] .. off[r+1]) from the root down,
+// bit d of codes[r] = branch at step d.  Returns the longest code; a code longer than 40 (word2vec.c's MAX_CODE_LENGTH)
+// is reported, not truncated.  Host only: a serial two-queue merge, O(V).
+#include <stddef.h>
+#include <vector>
+inline int dge_huffman_paths(const int64_t* counts, int64_t V, std::vector<int64_t>& off, std::vector<int32_t>& points,
+                             std::vector<uint64_t>& codes) {
+    off.assign((size_t)V + 1, 0); points.clear(); codes.assign((size_t)V, 0);
+    if (V < 2) return 0;
+    const int64_t n_inner = V - 1;
+    std::vector<int64_t> weight((size_t)n_inner);          // merged nodes, in creation order
+    std::vector<int32_t> up((size_t)(V + n_inner), -1);    // parent (as inner-node row) of leaf r / of inner node V+a
+    std::vector<uint8_t> bit((size_t)(V + n_inner), 0);
+    int64_t leaf = V - 1, merged = 0;                      // heads of the two queues
+    for (int64_t a = 0; a < n_inner; a++) {
+        for (int pick = 0; pick < 2; pick++) {
+            int64_t node;
+            if (leaf >= 0 && (merged >= a || counts[leaf] < weight[(size_t)merged])) node = leaf--;
+            else node = V + merged++;
+            up[(size_t)node] = (int32_t)a; bit[(size_t)node] = (uint8_t)pick;
+            weight[(size_t)a] = pick == 0 ? (node < V ? counts[node] : weight[(size_t)(node - V)])
+                                          : weight[(size_t)a] + (node < V ? counts[node] : weight[(size_t)(node - V)]);
+        }
+    }
+    // depth of every inner node from the root (row V-2), parents are created after their children
+    std::vector<int32_t> depth((size_t)n_inner, 0);
+    for (int64_t a = n_inner - 2; a >= 0; a--) depth[(size_t)a] = depth[(size_t)up[(size_t)(V + a)]] + 1;
+    int longest = 0;
+    for (int64_t r = 0; r < V; r++) {
+        int len = depth[(size_t)up[(size_t)r]] + 1;
+        off[(size_t)r + 1] = off[(size_t)r] + len;
+        if (len > longest) longest = len;
+    }
+    if (longest > 64) return longest;
+    points.resize((size_t)off[(size_t)V]);
+    for (int64_t r = 0; r < V; r++) {
+        int64_t node = r; uint64_t c = 0;
+        int32_t* out = points.data() + off[(size_t)r];
+        for (int d = (int)(off[(size_t)r + 1] - off[(size_t)r]) - 1; d >= 0; d--) {
+            c |= (uint64_t)bit[(size_t)node] << d;
+            out[d] = up[(size_t)node];
+            node = V + up[(size_t)node];
+        }
+        codes[(size_t)r] = c;
+    }
+    return longest;
+}

@@ -39,6 +39,12 @@ struct dge_model {
     double neg_collision = 1.0;                 // sum of squared negative-sampling probabilities: P(two draws hit one row)
     int n_cus = 256;
     float *d_syn0 = nullptr, *d_syn1neg = nullptr, *d_snap = nullptr;
+    // hierarchical softmax (cfg.use_hs): inner-node table and the Huffman paths in CSR form
+    float* d_syn1 = nullptr;
+    int64_t* d_hs_off = nullptr; int32_t* d_hs_points = nullptr; uint64_t* d_hs_codes = nullptr;
+    std::vector<int64_t> h_hs_off; std::vector<int32_t> h_hs_points; std::vector<uint64_t> h_hs_codes;
+    std::vector<float> h_syn1;
+
     int32_t* d_vocab_ids = nullptr;
     int64_t* d_counts = nullptr;
     int32_t* d_remap = nullptr;
@@ -150,6 +156,10 @@ struct TrainParams {
     int64_t n_workers;
     unsigned long long* counters;
     int* locks;               // one commit-lock word per syn1neg row (all zero between launches)
+    float* syn1;              // hierarchical softmax: inner-node rows, Huffman paths (null when off)
+    const int64_t* hs_off; const int32_t* hs_points; const uint64_t* hs_codes;
+    int32_t hs_hot0, hs_n_hot; // inner nodes [hs_hot0, hs_hot0 + hs_n_hot) — the ones nearest the root — combine in LDS
+    int32_t hs_drain;         // an LDS accumulator is drained to memory every hs_drain additions
 };
 
 template <int DCH> struct Row { float4 v[DCH]; };
@@ -345,6 +355,49 @@ __device__ __forceinline__ void neg_update_serial(const Row<DCH>& l1, Row<DCH>& 
     row_store<DCH, Policy<POL>::STORE_AUX, BIG>(r, syn1neg, tg, lane);
 }
 
+// Hierarchical softmax, Hogwild: every pair walks its centre's Huffman path from the root, so an inner node of subtree
+// weight w takes a fraction w/total of ALL pairs' updates — the root all of them.  As memory-side atomics those
+// serialise on a handful of rows (measured on cfg3: 12 ns per 64-B request, 38 s per step).  The hs_n_hot nodes
+// nearest the root (the highest rows: weights ascend with the row index) therefore collect their updates in per-block
+// LDS accumulators; the worker that makes an accumulator's hs_drain-th addition takes its content out (an exchange
+// per element, so concurrent additions are never lost) and adds it to the row in memory.  Rows are still READ from
+// memory: a block sees its own parked updates at most hs_drain additions late.
+extern __shared__ float s_dyn[];
+template <int DCH>
+__device__ __forceinline__ void hot_add(float* s_hot, int* s_cnt, int slot, int drain, const TableView& t, int32_t row, int lane,
+                                        float g, const Row<DCH>& x) {
+    float* a = s_hot + slot * (DCH * 64) + lane;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        atomicAdd(a + c * 64 + 0, g * x.v[c].x);
+        atomicAdd(a + c * 64 + 16, g * x.v[c].y);
+        atomicAdd(a + c * 64 + 32, g * x.v[c].z);
+        atomicAdd(a + c * 64 + 48, g * x.v[c].w);
+    }
+    int n = 0;
+    if (lane == 0) n = atomicAdd(&s_cnt[slot], 1) + 1;
+    n = __shfl(n, 0, 16);
+    if (n % drain == 0) {
+        float* gp = t.base + (size_t)row * (t.row_bytes / 4) + lane;
+#pragma unroll
+        for (int c = 0; c < DCH; c++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const float v = atomicExch(a + c * 64 + m * 16, 0.f);
+                if (v != 0.f) atomicAdd(gp + c * 64 + m * 16, v);
+            }
+    }
+}
+
+// end of the kernel, every thread of the block: what is still parked in LDS goes to memory (rows are contiguous)
+__device__ __forceinline__ void hot_drain_block(const float* s_hot, int n_floats, float* first_row) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_floats; i += blockDim.x) {
+        const float v = s_hot[i];
+        if (v != 0.f) atomicAdd(first_row + i, v);
+    }
+}
+
 __device__ __forceinline__ int32_t walk_tok(bool in_regs, const int32_t* sen, int idx, int32_t tk0, int32_t tk1, int32_t tk2, int32_t tk3) {
     if (!in_regs) return sen[idx];
     const int r = idx >> 4;
@@ -352,7 +405,7 @@ __device__ __forceinline__ int32_t walk_tok(bool in_regs, const int32_t* sen, in
     return __shfl(v, idx & 15, 16);
 }
 
-template <int DCH, int POL, bool BIG>
+template <int DCH, int POL, bool BIG, bool HS>
 __global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? 4 : 1)
 k_sgns_train(TrainParams p) {
     using P = Policy<POL>;
@@ -362,10 +415,19 @@ k_sgns_train(TrainParams p) {
 
     const int lane = threadIdx.x & 15;
     const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    if (worker >= p.n_workers) return;
+    constexpr bool HOT = HS && P::ATOMIC;         // inner nodes near the root combine their updates in LDS (hot_add)
+    float* s_hot = HOT ? s_dyn : nullptr;
+    int* s_hot_cnt = HOT ? (int*)(s_dyn + (size_t)p.hs_n_hot * DCH * 64) : nullptr;
+    if (HOT) {
+        for (int i = threadIdx.x; i < p.hs_n_hot * (DCH * 64 + 1); i += blockDim.x) s_dyn[i] = 0.f;   // +0.0f == int 0
+        __syncthreads();
+    }
+    if (!HOT && worker >= p.n_workers) return;    // (the HOT kernel keeps every thread for its final block-wide drain)
 
     const TableView syn0 = make_view(p.syn0, p.V, p.stride);
     const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride);
+    const TableView syn1 = make_view(HS ? p.syn1 : p.syn1neg, p.V, p.stride);
+    int64_t hs_o = 0; int hs_n = 0; uint64_t hs_bits = 0;   // Huffman path of the open centre
 
     // lane j turns the pair's LCG state s into the state after j+1 draws: s*mA + cA
     uint64_t mA = 1, cA = 0;
@@ -376,7 +438,7 @@ k_sgns_train(TrainParams p) {
     unsigned long long my_pairs = 0, my_words = 0;
 
     // ---- per-worker state: walk w, centre i, next context c (contexts are c..c_hi without i)
-    int64_t w = worker - p.n_workers;
+    int64_t w = (HOT && worker >= p.n_workers) ? p.n_rows - p.n_workers : worker - p.n_workers;   // surplus workers find no walk
     int len = 0, i = 0, c = 1, c_hi = 0;
     int32_t tk0 = -1, tk1 = -1, tk2 = -1, tk3 = -1;       // the walk's tokens: lane j holds tokens j, j+16, j+32, j+48
     const int32_t* sen = p.sen;
@@ -437,6 +499,7 @@ k_sgns_train(TrainParams p) {
             if (c_hi == i) c_hi--;
             if (c == i) c++;
             new_centre = true;
+            if (HS) { hs_o = p.hs_off[word]; hs_n = (int)(p.hs_off[word + 1] - hs_o); hs_bits = p.hs_codes[word]; }
         }
         if (!alive) break;
         const int32_t last = DGE_TOK(c);
@@ -449,6 +512,45 @@ k_sgns_train(TrainParams p) {
             if (P::ATOMIC) row_zero(dh);
         }
         row_zero(neu);
+        if (HS) {
+            // word2vec.c "HIERARCHICAL SOFTMAX", ahead of the negatives: the inner nodes on the centre's Huffman path,
+            // label 1 - code.  Outside (-6, 6) the step is skipped (not saturated, unlike the negative-sampling branch).
+            // The rows of one path are distinct and l1 does not change within the pair, so a batch in flight is the
+            // sequential result.
+            for (int kd = 0; kd < hs_n; kd += 16) {
+                const int kc = min(16, hs_n - kd);
+                const int32_t t = lane < kc ? p.hs_points[hs_o + kd + lane] : -1;
+                for (int base = 0; base < kc; base += NEG_BATCH) {
+                    int32_t tg[NEG_BATCH];
+                    Row<DCH> rr[NEG_BATCH];
+#pragma unroll
+                    for (int q = 0; q < NEG_BATCH; q++) {
+                        int32_t v = __shfl(t, (base + q) & 15, 16);
+                        tg[q] = (base + q < kc) ? v : -1;
+                    }
+#pragma unroll
+                    for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX, BIG>(rr[q], syn1, tg[q] >= 0 ? tg[q] : 0, lane);
+#pragma unroll
+                    for (int q = 0; q < NEG_BATCH; q++)
+                        if (tg[q] >= 0) {
+                            const float f = row_dot(l1, rr[q]);
+                            if (f > -(float)MAX_EXP && f < (float)MAX_EXP) {
+                                const int idx = (int)((f + (float)MAX_EXP) * (float)(EXP_TABLE_SIZE / MAX_EXP / 2));
+                                const float code = (float)((hs_bits >> (kd + base + q)) & 1ULL);
+                                const float g = (1.0f - code - s_exp[idx]) * alpha;
+                                row_axpy(neu, g, rr[q]);
+                                if (P::ATOMIC) {
+                                    if (tg[q] >= p.hs_hot0) hot_add<DCH>(s_hot, s_hot_cnt, tg[q] - p.hs_hot0, p.hs_drain, syn1, tg[q], lane, g, l1);
+                                    else row_atomic_axpy(syn1, tg[q], lane, g, l1);
+                                } else {
+                                    row_axpy(rr[q], g, l1);
+                                    row_store<DCH, P::STORE_AUX, BIG>(rr[q], syn1, tg[q], lane);
+                                }
+                            }
+                        }
+                }
+            }
+        }
         {   // d == 0: target = word, label 1 (word2vec order: positive first)
             float f = row_dot(l1, h);
             float g = sgns_g(f, 1.0f, alpha, s_exp);
@@ -528,6 +630,7 @@ k_sgns_train(TrainParams p) {
         if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
         if (my_words) atomicAdd(&p.counters[1], my_words);
     }
+    if (HOT) hot_drain_block(s_hot, p.hs_n_hot * DCH * 64, p.syn1 + (size_t)p.hs_hot0 * (DCH * 64));
 }
 
 // ------------------------------------------------------------------------------------------ all-locked Hogwild trainer
@@ -947,6 +1050,58 @@ extern "C" int dge_selftest_locked_rows(int device, int32_t n_rows, int64_t n_wo
     return DGE_OK;
 }
 
+// hot_add / hot_drain_block in isolation: every worker adds 1.0 to every element of pseudo-random hot rows `iters` times;
+// afterwards each row must hold exactly the number of additions it received (integers < 2^24 are exact in float).
+__global__ void __launch_bounds__(256) k_selftest_hot_add(float* rows, unsigned long long* hits, int n_hot, int drain, int iters, uint64_t seed, int64_t n_workers) {
+    const int lane = threadIdx.x & 15;
+    const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    float* s_hot = s_dyn;
+    int* s_cnt = (int*)(s_dyn + (size_t)n_hot * 64);
+    for (int i = threadIdx.x; i < n_hot * 65; i += blockDim.x) s_dyn[i] = 0.f;
+    __syncthreads();
+    const TableView t = make_view(rows, n_hot, 64);
+    Row<1> one; one.v[0] = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (worker < n_workers) {
+        uint64_t s = dge_mix64(seed + (uint64_t)worker);
+        for (int it = 0; it < iters; it++) {
+            s = s * DGE_W2V_MULT + 11;
+            // skewed like a Huffman path: slot k with probability ~2^-(k+1)
+            int slot = min(n_hot - 1, (int)__builtin_ctzll((s >> 20) | (1ull << 40)));
+            slot = n_hot - 1 - slot;
+            hot_add<1>(s_hot, s_cnt, slot, drain, t, slot, lane, 1.0f, one);
+            if (lane == 0) atomicAdd(&hits[slot], 1ULL);
+        }
+    }
+    hot_drain_block(s_hot, n_hot * 64, rows);
+}
+
+extern "C" int dge_selftest_hot_add(int device, int32_t n_hot, int64_t n_workers, int32_t iters, int32_t drain, uint64_t seed,
+                                    int64_t* total_additions, double* max_abs_error) {
+    if (n_hot <= 0 || n_hot > 118 || n_workers <= 0 || iters <= 0 || drain <= 0 || !total_additions || !max_abs_error)
+        DGE_FAIL(DGE_ERR_ARG, "dge_selftest_hot_add: bad argument");
+    int rc = dge_require_device(device);
+    if (rc) return rc;
+    dge_tmp<float> d_rows; dge_tmp<unsigned long long> d_hits;
+    if ((rc = d_rows.alloc((size_t)n_hot * 64))) return rc;
+    if ((rc = d_hits.alloc((size_t)n_hot))) return rc;
+    DGE_HIP(hipMemset(d_rows.p, 0, (size_t)n_hot * 64 * sizeof(float)));
+    DGE_HIP(hipMemset(d_hits.p, 0, (size_t)n_hot * sizeof(unsigned long long)));
+    const unsigned blocks = (unsigned)((n_workers * 16 + 255) / 256);
+    hipLaunchKernelGGL(k_selftest_hot_add, dim3(blocks), dim3(256), (size_t)n_hot * 65 * 4, 0, d_rows.p, d_hits.p, n_hot, drain, iters, seed, n_workers);
+    DGE_HIP(hipGetLastError());
+    DGE_HIP(hipDeviceSynchronize());
+    std::vector<float> rows((size_t)n_hot * 64); std::vector<unsigned long long> hits((size_t)n_hot);
+    DGE_HIP(hipMemcpy(rows.data(), d_rows.p, rows.size() * sizeof(float), hipMemcpyDeviceToHost));
+    DGE_HIP(hipMemcpy(hits.data(), d_hits.p, hits.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    int64_t total = 0; double worst = 0;
+    for (int r = 0; r < n_hot; r++) {
+        total += (int64_t)hits[(size_t)r];
+        for (int e = 0; e < 64; e++) worst = std::max(worst, fabs((double)rows[(size_t)r * 64 + e] - (double)hits[(size_t)r]));
+    }
+    *total_additions = total; *max_abs_error = worst;
+    return DGE_OK;
+}
+
 // ------------------------------------------------------------------------------------------ delta exchange
 __global__ void k_delta_export(const float* __restrict__ cur, const float* __restrict__ snap, float* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = cur[i] - snap[i];
@@ -975,6 +1130,7 @@ extern "C" int dge_count_tokens(const dge_walks* w, int64_t row0, int64_t n_rows
 
 static void model_release(dge_model* m) {
     dge_dev_free(m->d_syn0); dge_dev_free(m->d_syn1neg); dge_dev_free(m->d_snap); dge_dev_free(m->d_vocab_ids);
+    dge_dev_free(m->d_syn1); dge_dev_free(m->d_hs_off); dge_dev_free(m->d_hs_points); dge_dev_free(m->d_hs_codes);
     dge_dev_free(m->d_counts); dge_dev_free(m->d_remap); dge_dev_free(m->d_table); dge_dev_free(m->d_exp);
     dge_dev_free(m->d_sen); dge_dev_free(m->d_len); dge_dev_free(m->d_wb); dge_dev_free(m->d_scan_tmp); dge_dev_free(m->d_counters); dge_dev_free(m->d_locks);
     for (auto& e : m->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1009,6 +1165,8 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     int dch = (cfg->dim + 63) / 64;
     if (!dim_supported(dch)) dch = dch <= 6 ? 6 : 8;
     if (cfg->dim > 512) DGE_FAIL(DGE_ERR_ARG, "dge_model_create: dim %d > 512 is not supported", cfg->dim);
+    if (cfg->use_hs && cfg->update_policy != 0 && cfg->update_policy != 2 && cfg->update_policy != 3)
+        DGE_FAIL(DGE_ERR_ARG, "dge_model_create: use_hs runs under update_policy 0 (auto), 2 or 3, not %d", cfg->update_policy);
     int rc = dge_require_device(device);
     if (rc) return rc;
     DGE_HIP(hipDeviceSynchronize());      // d_counts may have been produced on the caller's streams (count kernel, all-reduce)
@@ -1105,6 +1263,17 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     MC(dge_dev_alloc(&m->d_syn0, tab + 64)); MC(dge_dev_alloc(&m->d_syn1neg, tab + 64));
     MH(hipMemsetAsync(m->d_syn1neg, 0, (tab + 64) * sizeof(float), st));
     if (V) hipLaunchKernelGGL(k_init_syn0, dim3(grid_for(V, 256)), dim3(256), 0, st, m->d_syn0, V, m->D, m->stride, cfg->seed);
+    if (cfg->use_hs) {
+        // inner-node table (V rows allocated, V-1 used: the tables stay the same size for the delta exchange) and paths
+        const int longest = dge_huffman_paths(m->h_counts.data(), V, m->h_hs_off, m->h_hs_points, m->h_hs_codes);
+        MC(dge_dev_alloc(&m->d_syn1, tab + 64));
+        MH(hipMemsetAsync(m->d_syn1, 0, (tab + 64) * sizeof(float), st));
+        if (longest > 40) { model_release(m); delete m; DGE_FAIL(DGE_ERR_ARG, "dge_model_create: a Huffman code of %d bits exceeds word2vec's MAX_CODE_LENGTH 40", longest); }
+        MC(dge_dev_alloc(&m->d_hs_off, (size_t)V + 1)); MC(dge_dev_alloc(&m->d_hs_points, m->h_hs_points.size())); MC(dge_dev_alloc(&m->d_hs_codes, (size_t)V));
+        MH(hipMemcpyAsync(m->d_hs_off, m->h_hs_off.data(), ((size_t)V + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        if (!m->h_hs_points.empty()) MH(hipMemcpyAsync(m->d_hs_points, m->h_hs_points.data(), m->h_hs_points.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        if (V) MH(hipMemcpyAsync(m->d_hs_codes, m->h_hs_codes.data(), (size_t)V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    }
     MC(dge_dev_alloc(&m->d_locks, 2 * ((size_t)V + 1)));      // [0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows
     MH(hipMemsetAsync(m->d_locks, 0, 2 * ((size_t)V + 1) * sizeof(int), st));
     MC(dge_dev_alloc(&m->d_counters, 2));
@@ -1136,19 +1305,21 @@ static int ensure_work(dge_model* m, int64_t n_rows, int32_t L) {
 }
 
 template <int DCH, bool BIG>
-static void launch_train_b(const TrainParams& p, int pol, unsigned blocks, unsigned threads, hipStream_t st) {
+static void launch_train_b(const TrainParams& p, int pol, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st) {
     switch (pol) {
-        case 0: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 0: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 10: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, true>), dim3(blocks), dim3(threads), 0, st, p); break;    // + hierarchical softmax
+        case 12: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, true>), dim3(blocks), dim3(threads), shmem, st, p); break;
         case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
-        default: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
+        default: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
     }
 }
 template <int DCH>
-static void launch_train(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, hipStream_t st) {
-    if (big) launch_train_b<DCH, true>(p, pol, blocks, threads, st);
-    else launch_train_b<DCH, false>(p, pol, blocks, threads, st);
+static void launch_train(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st) {
+    if (big) launch_train_b<DCH, true>(p, pol, blocks, threads, shmem, st);
+    else launch_train_b<DCH, false>(p, pol, blocks, threads, shmem, st);
 }
 
 static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32_t L, int64_t walk_index_base, int32_t epoch,
@@ -1173,13 +1344,16 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.alpha0 = m->cfg.alpha; p.min_alpha = m->cfg.min_alpha;
     p.counters = m->d_counters;
     p.locks = m->d_locks;
+    p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
+    p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1;
+    const bool hs = m->cfg.use_hs != 0;
 
     int64_t workers;
     if (m->cfg.workers == 0) {
         // fill the device: 4 blocks of 16 workers per CU, but never more concurrent walks than half the vocabulary
         // (Hogwild's premise is sparse collisions: measured, a 2.3k-row table keeps 0.99 cosine to the in-order
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
-        const bool auto_locked = m->cfg.update_policy == 0 && m->V >= 262144 && (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision < 0.25;
+        const bool auto_locked = !hs && m->cfg.update_policy == 0 && m->V >= 262144 && (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision < 0.25;
         const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || auto_locked) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)m->n_cus * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
@@ -1196,10 +1370,23 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // vocabulary (cfg5) gives >> 1: the same kernel spins on its hot rows (measured 5e5 edges/s) while memory-side
         // atomics are indifferent to the skew (5.9e7 = their byte rate) -> atomics.
         const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
-        pol = workers == 1 ? 100 : ((m->V >= 262144 && fail < 0.25) ? 5 : 2);
+        pol = workers == 1 ? 100 : ((!hs && m->V >= 262144 && fail < 0.25) ? 5 : 2);
     }
     if (pol == 100 || (workers == 1 && pol != 5 && pol != 6 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
     if (pol == 3) pol = 0;
+    size_t shmem = 0;
+    if (hs) {
+        pol = pol == 0 ? 10 : 12;               // dge_model_create admitted policies 0/2/3 only
+        if (pol == 12) {
+            // LDS accumulators for the inner nodes nearest the root: 30 KB a block (4 blocks a CU stay resident)
+            const int64_t row_b = (int64_t)m->stride * 4 + 4;
+            p.hs_n_hot = (int32_t)std::min<int64_t>(std::max<int64_t>(m->V - 1, 0), 30720 / row_b);
+            p.hs_hot0 = (int32_t)(std::max<int64_t>(m->V - 1, 0) - p.hs_n_hot);
+            p.hs_drain = 64;
+            if (const char* e = getenv("DGE_HS_DRAIN")) { int v = atoi(e); if (v >= 1) p.hs_drain = v; }      // tuning/ablation knob
+            shmem = (size_t)p.hs_n_hot * (size_t)row_b;
+        }
+    }
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
 
@@ -1210,12 +1397,12 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     DGE_HIP(hipEventCreate(&ev.a)); DGE_HIP(hipEventCreate(&ev.b));
     DGE_HIP(hipEventRecord(ev.a, st));
     switch (m->stride / 64) {
-        case 1: launch_train<1>(p, pol, big, blocks, threads, st); break;
-        case 2: launch_train<2>(p, pol, big, blocks, threads, st); break;
-        case 3: launch_train<3>(p, pol, big, blocks, threads, st); break;
-        case 4: launch_train<4>(p, pol, big, blocks, threads, st); break;
-        case 6: launch_train<6>(p, pol, big, blocks, threads, st); break;
-        default: launch_train<8>(p, pol, big, blocks, threads, st); break;
+        case 1: launch_train<1>(p, pol, big, blocks, threads, shmem, st); break;
+        case 2: launch_train<2>(p, pol, big, blocks, threads, shmem, st); break;
+        case 3: launch_train<3>(p, pol, big, blocks, threads, shmem, st); break;
+        case 4: launch_train<4>(p, pol, big, blocks, threads, shmem, st); break;
+        case 6: launch_train<6>(p, pol, big, blocks, threads, shmem, st); break;
+        default: launch_train<8>(p, pol, big, blocks, threads, shmem, st); break;
     }
     DGE_HIP(hipEventRecord(ev.b, st));
     m->pending.push_back(ev);
@@ -1281,17 +1468,19 @@ extern "C" int dge_train_sgns(int device, const int32_t* walks, int64_t n_walks,
     return rc;
 }
 
-static int sync_tables_to_host(dge_model* m, bool want_syn0, bool want_syn1) {
+static int sync_tables_to_host(dge_model* m, bool want_syn0, bool want_syn1, bool want_hs = false) {
     DGE_HIP(hipSetDevice(m->device));
     DGE_HIP(hipStreamSynchronize(m->stream));
     size_t tab = (size_t)m->V * (size_t)m->stride;
     std::vector<float> tmp(tab ? tab : 1);
-    for (int which = 0; which < 2; which++) {
-        if ((which == 0 && !want_syn0) || (which == 1 && !want_syn1)) continue;
-        if (tab) DGE_HIP(hipMemcpy(tmp.data(), which == 0 ? m->d_syn0 : m->d_syn1neg, tab * sizeof(float), hipMemcpyDeviceToHost));
-        std::vector<float>& dst = which == 0 ? m->h_syn0 : m->h_syn1neg;
-        dst.resize((size_t)m->V * (size_t)m->D);
-        for (int64_t r = 0; r < m->V; r++) memcpy(dst.data() + r * m->D, tmp.data() + r * m->stride, (size_t)m->D * sizeof(float));
+    for (int which = 0; which < 3; which++) {
+        if ((which == 0 && !want_syn0) || (which == 1 && !want_syn1) || (which == 2 && !want_hs)) continue;
+        const float* src = which == 0 ? m->d_syn0 : (which == 1 ? m->d_syn1neg : m->d_syn1);
+        if (tab) DGE_HIP(hipMemcpy(tmp.data(), src, tab * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<float>& dst = which == 0 ? m->h_syn0 : (which == 1 ? m->h_syn1neg : m->h_syn1);
+        const int64_t rows = which == 2 ? std::max<int64_t>(m->V - 1, 0) : m->V;
+        dst.resize((size_t)rows * (size_t)m->D + 1);
+        for (int64_t r = 0; r < rows; r++) memcpy(dst.data() + r * m->D, tmp.data() + r * m->stride, (size_t)m->D * sizeof(float));
     }
     return DGE_OK;
 }
@@ -1311,6 +1500,23 @@ extern "C" int dge_model_syn1neg(dge_model* m, const float** syn1neg) {
     int rc = sync_tables_to_host(m, false, true);
     if (rc) return rc;
     *syn1neg = m->h_syn1neg.data();
+    return DGE_OK;
+}
+extern "C" int dge_model_syn1(dge_model* m, const float** syn1, int64_t* rows) {
+    if (!m || !syn1) DGE_FAIL(DGE_ERR_ARG, "dge_model_syn1: null argument");
+    if (!m->d_syn1) DGE_FAIL(DGE_ERR_STATE, "dge_model_syn1: the model was created without use_hs");
+    int rc = sync_tables_to_host(m, false, false, true);
+    if (rc) return rc;
+    *syn1 = m->h_syn1.data();
+    if (rows) *rows = std::max<int64_t>(m->V - 1, 0);
+    return DGE_OK;
+}
+extern "C" int dge_model_huffman(dge_model* m, const int64_t** offsets, const int32_t** points, const uint64_t** codes) {
+    if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_huffman: null model");
+    if (!m->d_syn1) DGE_FAIL(DGE_ERR_STATE, "dge_model_huffman: the model was created without use_hs");
+    if (offsets) *offsets = m->h_hs_off.data();
+    if (points) *points = m->h_hs_points.data();
+    if (codes) *codes = m->h_hs_codes.data();
     return DGE_OK;
 }
 extern "C" int dge_model_counts(dge_model* m, const int64_t** counts) {
@@ -1384,7 +1590,7 @@ extern "C" int dge_write_vec(dge_model* m, const char* const* names, const char*
 // ------------------------------------------------------------------------------------------ multi-GPU exchange
 extern "C" int dge_model_sync_size(const dge_model* m, int64_t* n_floats) {
     if (!m || !n_floats) DGE_FAIL(DGE_ERR_ARG, "dge_model_sync_size: null argument");
-    *n_floats = 2 * m->V * (int64_t)m->stride;
+    *n_floats = (m->d_syn1 ? 3 : 2) * m->V * (int64_t)m->stride;
     return DGE_OK;
 }
 
@@ -1392,9 +1598,10 @@ extern "C" int dge_model_snapshot(dge_model* m) {
     if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_snapshot: null model");
     DGE_HIP(hipSetDevice(m->device));
     size_t tab = (size_t)m->V * (size_t)m->stride;
-    if (!m->d_snap) { int rc = dge_dev_alloc(&m->d_snap, 2 * tab + 64); if (rc) return rc; }
+    if (!m->d_snap) { int rc = dge_dev_alloc(&m->d_snap, (m->d_syn1 ? 3 : 2) * tab + 64); if (rc) return rc; }
     DGE_HIP(hipMemcpyAsync(m->d_snap, m->d_syn0, tab * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
     DGE_HIP(hipMemcpyAsync(m->d_snap + tab, m->d_syn1neg, tab * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+    if (m->d_syn1) DGE_HIP(hipMemcpyAsync(m->d_snap + 2 * tab, m->d_syn1, tab * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
     DGE_HIP(hipStreamSynchronize(m->stream));
     return DGE_OK;
 }
@@ -1407,6 +1614,7 @@ extern "C" int dge_model_export_delta(dge_model* m, float* d_buf) {
     if (tab) {
         hipLaunchKernelGGL(k_delta_export, dim3(2048), dim3(256), 0, m->stream, m->d_syn0, m->d_snap, d_buf, tab);
         hipLaunchKernelGGL(k_delta_export, dim3(2048), dim3(256), 0, m->stream, m->d_syn1neg, m->d_snap + tab, d_buf + tab, tab);
+        if (m->d_syn1) hipLaunchKernelGGL(k_delta_export, dim3(2048), dim3(256), 0, m->stream, m->d_syn1, m->d_snap + 2 * tab, d_buf + 2 * tab, tab);
     }
     DGE_HIP(hipStreamSynchronize(m->stream));
     DGE_HIP(hipGetLastError());
@@ -1422,6 +1630,7 @@ extern "C" int dge_model_import_delta(dge_model* m, const float* d_buf, float sc
     if (tab) {
         hipLaunchKernelGGL(k_delta_import, dim3(2048), dim3(256), 0, m->stream, m->d_syn0, m->d_snap, d_buf, scale, tab);
         hipLaunchKernelGGL(k_delta_import, dim3(2048), dim3(256), 0, m->stream, m->d_syn1neg, m->d_snap + tab, d_buf + tab, scale, tab);
+        if (m->d_syn1) hipLaunchKernelGGL(k_delta_import, dim3(2048), dim3(256), 0, m->stream, m->d_syn1, m->d_snap + 2 * tab, d_buf + 2 * tab, scale, tab);
     }
     DGE_HIP(hipStreamSynchronize(m->stream));
     DGE_HIP(hipGetLastError());

@@ -155,9 +155,9 @@ class WalkCorpus:
 
 
 def make_config(dim, window, n_vertices, negative=5, min_count=2, epochs=1, workers=0, alpha=0.025, min_alpha=1e-4,
-                seed=1, table_size=100_000_000, update_policy=0):
+                seed=1, table_size=100_000_000, update_policy=0, use_hs=False):
     return TrainConfig(int(dim), int(window), int(negative), int(min_count), int(epochs), int(workers), float(alpha),
-                       float(min_alpha), int(seed), int(table_size), int(n_vertices), int(update_policy))
+                       float(min_alpha), int(seed), int(table_size), int(n_vertices), int(update_policy), int(bool(use_hs)), 0)
 
 
 class SgnsModel:
@@ -225,6 +225,30 @@ class SgnsModel:
         if syn0.size == 0:
             return np.zeros_like(syn0)
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(syn0.size,)).copy().reshape(syn0.shape)
+
+    def syn1(self):
+        """Inner-node table of the hierarchical softmax, [V-1 x dim] (models created with use_hs)."""
+        p = C.c_void_p(0); rows = C.c_int64(0)
+        check(lib.dge_model_syn1(self._h, C.byref(p), C.byref(rows)))
+        n = rows.value * self.cfg.dim
+        if n == 0:
+            return np.zeros((0, self.cfg.dim), np.float32)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,)).copy().reshape(rows.value, self.cfg.dim)
+
+    def huffman(self):
+        """Huffman paths of the vocabulary rows: (offsets[V+1], points, codes) — bit d of codes[r] is the branch at
+        points[offsets[r] + d] (word2vec.c CreateBinaryTree)."""
+        _, vid = self.vectors()
+        V = len(vid)
+        po, pp, pc = C.c_void_p(0), C.c_void_p(0), C.c_void_p(0)
+        check(lib.dge_model_huffman(self._h, C.byref(po), C.byref(pp), C.byref(pc)))
+        if V == 0:
+            return np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.uint64)
+        off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_int64)), shape=(V + 1,)).copy()
+        n = int(off[-1])
+        pts = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_int32)), shape=(max(n, 1),)).copy()[:n]
+        codes = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_uint64)), shape=(V,)).copy()
+        return off, pts, codes
 
     def counts(self):
         _, vid = self.vectors()

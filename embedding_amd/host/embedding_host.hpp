@@ -280,6 +280,9 @@ inline int SpatialGraph::numLayer = 8;
 class DeepWalk {
  public:
     static int Year;   // J/DeepWalk.java:25
+    // The reference's builder (:73-76) never calls .useHierarchicSoftmax(false), so DL4J trained the hierarchical-softmax
+    // term next to the 5 negatives; true reproduces that, false is the negative-sampling path BASELINE.json names.
+    static bool useHierarchicSoftmax;
     // learnEmbedding: every line of the .seq files is a sentence of whitespace-separated names (DefaultTokenizerFactory,
     // :70); trains SGNS with the reference's builder values and writes "name v1 .. vD" lines (:82).
     static dge_train_stats learnEmbedding(const std::vector<std::string>& seqFiles, const std::string& outVec, int layerSize,
@@ -315,6 +318,7 @@ class DeepWalk {
         cfg.alpha = 0.025f; cfg.min_alpha = 1e-4f; // DL4J defaults
         cfg.seed = seed; cfg.table_size = 0;
         cfg.n_vertices = (int32_t)std::max<size_t>(names.size(), 1);
+        cfg.use_hs = useHierarchicSoftmax ? 1 : 0;
         dge_model* m = nullptr;
         dge_check(dge_train_sgns(device, walks.data(), (int64_t)rows.size(), (int32_t)maxLen, &cfg, &m));
         std::vector<const char*> cn(names.size());
@@ -327,5 +331,6 @@ class DeepWalk {
     }
 };
 inline int DeepWalk::Year = 2013;
+inline bool DeepWalk::useHierarchicSoftmax = false;
 
 }  // namespace embedding

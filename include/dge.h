@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DGE_VERSION 100
+#define DGE_VERSION 101
 
 enum {
     DGE_OK = 0,
@@ -142,6 +142,12 @@ typedef struct dge_train_config {
                                 6 = as 5 with strict commit (one returning atomic per stored 128-B line: no update
                                     is ever lost).
                                 workers == 1 with policy 0/3 is the in-order schedule with plain accesses. */
+    int32_t use_hs;          /* .useHierarchicSoftmax(b): 0 = negative sampling only (the north-star path);
+                                1 = the hierarchical-softmax term as well, before the negatives of each pair — what
+                                DL4J's builder leaves on when J/DeepWalk.java:73-76 does not call it.  Huffman codes over
+                                the vocabulary counts (word2vec.c CreateBinaryTree), inner-node table syn1 [V-1 x dim].
+                                Policies 0/2/3 only (in-order, or memory-side atomics). */
+    int32_t reserved;        /* 0 */
 } dge_train_config;
 
 typedef struct dge_train_stats {
@@ -179,6 +185,10 @@ int  dge_model_walk_and_train(dge_model* m, const dge_graph* g, dge_walks* w, in
 /* results (w2v.lookupTable): host copies [V x dim], borrowed until the next call on m / dge_model_free */
 int  dge_model_vectors(dge_model* m, const float** syn0, const int32_t** vocab_ids, int64_t* V, int32_t* dim);
 int  dge_model_syn1neg(dge_model* m, const float** syn1neg);
+/* use_hs: inner-node table [max(V-1,0) x dim]; and the Huffman paths of the vocabulary rows in CSR form —
+ * offsets[V+1], points (inner-node rows, root first), codes (bit d of codes[r] = branch taken at points[offsets[r]+d]) */
+int  dge_model_syn1(dge_model* m, const float** syn1, int64_t* rows);
+int  dge_model_huffman(dge_model* m, const int64_t** offsets, const int32_t** points, const uint64_t** codes);
 int  dge_model_counts(dge_model* m, const int64_t** counts);
 int  dge_model_table(dge_model* m, const int32_t** table, int64_t* table_size);
 int  dge_model_stats(const dge_model* m, dge_train_stats* out);
@@ -228,6 +238,11 @@ int  dge_knn_cosine(int device, const float* features, int32_t n, int32_t dim, i
 int  dge_selftest_locked_rows(int device, int32_t n_rows, int64_t n_workers, int32_t iters, uint64_t seed,
                               int32_t commit /* 0 relaxed (policy 5), 1 strict (policy 6), 2 agent release fence */,
                               int64_t* total_increments, double* max_abs_error);
+/* the LDS combining of the hierarchical-softmax updates near the root (hot_add) in isolation: n_workers workers add 1.0
+ * to skewed pseudo-random rows `iters` times with the given drain period; max_abs_error = worst |row element - additions
+ * that row received| (0 when no addition is lost or doubled). */
+int  dge_selftest_hot_add(int device, int32_t n_hot, int64_t n_workers, int32_t iters, int32_t drain, uint64_t seed,
+                          int64_t* total_additions, double* max_abs_error);
 
 #ifdef __cplusplus
 }

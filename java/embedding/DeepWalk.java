@@ -38,7 +38,9 @@ public class DeepWalk {
         long m = NativeEngine.trainSgns(Integer.getInteger("dge.device", 0), walks, rows.size(), maxLen,
                 layerSize, LayeredGraph.numLayer /* .windowSize(LayeredGraph.numLayer) :74 */, 5 /* .negativeSample(5) */,
                 2 /* .minWordFrequency(2) */, 1 /* .iterations(1) */, 0 /* .workers(8) -> fill the GPU */,
-                0.025f, 1e-4f, 1L, names.size());
+                0.025f, 1e-4f, 1L, names.size(),
+                Boolean.getBoolean("dge.hs") /* DL4J's builder default leaves the hierarchical-softmax term on (:73-76 never
+                                                 call useHierarchicSoftmax); -Ddge.hs=true trains it as well */);
         NativeEngine.writeVec(m, names.toArray(new String[0]), out, false);      // WordVectorSerializer.writeWordVectors :82
         NativeEngine.modelFree(m);
     }

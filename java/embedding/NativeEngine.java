@@ -23,7 +23,8 @@ final class NativeEngine {
     static native long sampleWalks(long g, long nWalks, int maxLen, long seed, int rngMode, long firstIndex, int[] out);
     /** w2v.fit(): returns a model handle */
     static native long trainSgns(int device, int[] walks, long nWalks, int maxLen, int dim, int window, int negative,
-                                 int minCount, int epochs, int workers, float alpha, float minAlpha, long seed, int nVertices);
+                                 int minCount, int epochs, int workers, float alpha, float minAlpha, long seed, int nVertices,
+                                 boolean useHierarchicSoftmax);
     static native void writeVec(long model, String[] names, String path, boolean header);
     static native float[] modelVectors(long model, int[] vocabIdsOut);
     static native void modelFree(long m);

@@ -46,9 +46,10 @@ JNIEXPORT jlong JNICALL J(sampleWalks)(JNIEnv* e, jclass, jlong g, jlong n, jint
     e->ReleaseIntArrayElements(out, p, 0); fail(e, rc); return draws;
 }
 JNIEXPORT jlong JNICALL J(trainSgns)(JNIEnv* e, jclass, jint device, jintArray walks, jlong n, jint L, jint dim, jint window, jint negative,
-                                     jint minCount, jint epochs, jint workers, jfloat alpha, jfloat minAlpha, jlong seed, jint nVertices) {
+                                     jint minCount, jint epochs, jint workers, jfloat alpha, jfloat minAlpha, jlong seed, jint nVertices,
+                                     jboolean useHierarchicSoftmax) {
     dge_train_config c{}; c.dim = dim; c.window = window; c.negative = negative; c.min_count = minCount; c.epochs = epochs; c.workers = workers;
-    c.alpha = alpha; c.min_alpha = minAlpha; c.seed = (uint64_t)seed; c.n_vertices = nVertices;
+    c.alpha = alpha; c.min_alpha = minAlpha; c.seed = (uint64_t)seed; c.n_vertices = nVertices; c.use_hs = useHierarchicSoftmax ? 1 : 0;
     jint* p = e->GetIntArrayElements(walks, nullptr); dge_model* m = nullptr;
     int rc = dge_train_sgns(device, (const int32_t*)p, n, L, &c, &m);
     e->ReleaseIntArrayElements(walks, p, JNI_ABORT); fail(e, rc); return (jlong)m;

@@ -393,9 +393,11 @@ uint64_t orc_mix64(uint64_t x) {                     /* splitmix64 output functi
     return x ^ (x >> 31);
 }
 
+#define MAX_CODE_LENGTH 40
 struct orc_model {
     int64_t V; int32_t dim;
-    float *syn0, *syn1neg;
+    float *syn0, *syn1neg, *syn1;
+    int32_t* points; uint8_t* codes; int32_t* codelen;     /* Huffman paths, [V x MAX_CODE_LENGTH] */
     int32_t* vocab_ids; int64_t* counts;
     int32_t* table; int64_t table_size;
     int64_t pairs, total_words;
@@ -406,6 +408,13 @@ int64_t orc_model_vocab_size(const orc_model* m) { return m->V; }
 int32_t orc_model_dim(const orc_model* m) { return m->dim; }
 const float* orc_model_syn0(const orc_model* m) { return m->syn0; }
 const float* orc_model_syn1neg(const orc_model* m) { return m->syn1neg; }
+const float* orc_model_syn1(const orc_model* m) { return m->syn1; }
+int32_t orc_model_code(const orc_model* m, int64_t row, int32_t* points, uint8_t* codes, int32_t cap) {
+    if (!m->codelen || row < 0 || row >= m->V) return -1;
+    int32_t n = m->codelen[row];
+    for (int32_t i = 0; i < n && i < cap; i++) { points[i] = m->points[row * MAX_CODE_LENGTH + i]; codes[i] = m->codes[row * MAX_CODE_LENGTH + i]; }
+    return n;
+}
 const int32_t* orc_model_vocab_ids(const orc_model* m) { return m->vocab_ids; }
 const int64_t* orc_model_counts(const orc_model* m) { return m->counts; }
 const int32_t* orc_model_table(const orc_model* m) { return m->table; }
@@ -414,7 +423,8 @@ int64_t orc_model_total_words(const orc_model* m) { return m->total_words; }
 double orc_model_seconds(const orc_model* m) { return m->seconds; }
 void orc_model_free(orc_model* m) {
     if (!m) return;
-    free(m->syn0); free(m->syn1neg); free(m->vocab_ids); free(m->counts); free(m->table); free(m);
+    free(m->syn0); free(m->syn1neg); free(m->syn1); free(m->points); free(m->codes); free(m->codelen);
+    free(m->vocab_ids); free(m->counts); free(m->table); free(m);
 }
 
 typedef struct { int64_t cnt; int32_t id; } vc_item;
@@ -461,6 +471,61 @@ static inline float alpha_for(const orc_train_config* cfg, int64_t words_done, i
     return af;
 }
 
+/* word2vec.c CreateBinaryTree: Huffman tree over the vocabulary counts (rows are sorted by count descending);
+ * point[] = inner nodes from the root, code[] = branch taken at each of them. */
+static void create_binary_tree(orc_model* m) {
+    const int64_t V = m->V;
+    m->points = (int32_t*)calloc((size_t)(V ? V : 1) * MAX_CODE_LENGTH, sizeof(int32_t));
+    m->codes = (uint8_t*)calloc((size_t)(V ? V : 1) * MAX_CODE_LENGTH, 1);
+    m->codelen = (int32_t*)calloc((size_t)(V ? V : 1), sizeof(int32_t));
+    if (V < 2) return;
+    int64_t* count = (int64_t*)calloc((size_t)V * 2 + 1, sizeof(int64_t));
+    int64_t* binary = (int64_t*)calloc((size_t)V * 2 + 1, sizeof(int64_t));
+    int64_t* parent = (int64_t*)calloc((size_t)V * 2 + 1, sizeof(int64_t));
+    for (int64_t a = 0; a < V; a++) count[a] = m->counts[a];
+    for (int64_t a = V; a < V * 2; a++) count[a] = (int64_t)1e15;
+    int64_t pos1 = V - 1, pos2 = V, min1i, min2i;
+    for (int64_t a = 0; a < V - 1; a++) {
+        if (pos1 >= 0) { if (count[pos1] < count[pos2]) { min1i = pos1; pos1--; } else { min1i = pos2; pos2++; } }
+        else { min1i = pos2; pos2++; }
+        if (pos1 >= 0) { if (count[pos1] < count[pos2]) { min2i = pos1; pos1--; } else { min2i = pos2; pos2++; } }
+        else { min2i = pos2; pos2++; }
+        count[V + a] = count[min1i] + count[min2i];
+        parent[min1i] = V + a; parent[min2i] = V + a;
+        binary[min2i] = 1;
+    }
+    for (int64_t a = 0; a < V; a++) {
+        int64_t b = a, i = 0; uint8_t code[MAX_CODE_LENGTH]; int64_t point[MAX_CODE_LENGTH];
+        for (;;) {
+            code[i] = (uint8_t)binary[b]; point[i] = b; i++;
+            b = parent[b];
+            if (b == V * 2 - 2 || i >= MAX_CODE_LENGTH - 1) break;
+        }
+        m->codelen[a] = (int32_t)i;
+        m->points[a * MAX_CODE_LENGTH] = (int32_t)(V - 2);
+        for (b = 0; b < i; b++) {
+            m->codes[a * MAX_CODE_LENGTH + i - b - 1] = code[b];
+            if (i - b < MAX_CODE_LENGTH) m->points[a * MAX_CODE_LENGTH + i - b] = (int32_t)(point[b] - V);
+        }
+    }
+    free(count); free(binary); free(parent);
+}
+
+/* the tree alone, for tests of the product's path builder: counts must be sorted descending */
+int orc_huffman(const int64_t* counts, int64_t V, int32_t* codelen, int32_t* points, uint8_t* codes) {
+    if (!counts || V < 0) return -1;
+    orc_model m; memset(&m, 0, sizeof m);
+    m.V = V; m.counts = (int64_t*)counts;
+    create_binary_tree(&m);
+    for (int64_t r = 0; r < V; r++) {
+        codelen[r] = m.codelen[r];
+        memcpy(points + r * MAX_CODE_LENGTH, m.points + r * MAX_CODE_LENGTH, MAX_CODE_LENGTH * sizeof(int32_t));
+        memcpy(codes + r * MAX_CODE_LENGTH, m.codes + r * MAX_CODE_LENGTH, MAX_CODE_LENGTH);
+    }
+    free(m.points); free(m.codes); free(m.codelen);
+    return 0;
+}
+
 static int64_t train_walk(const orc_train_config* cfg, orc_model* m, const int32_t* sen, int len,
                           int64_t gidx_base, float alpha, float* neu1e) {
     const int D = cfg->dim, W = cfg->window, K = cfg->negative;
@@ -480,6 +545,22 @@ static int64_t train_walk(const orc_train_config* cfg, orc_model* m, const int32
             if (last < 0) continue;
             float* l1 = m->syn0 + (int64_t)last * D;
             for (int k = 0; k < D; k++) neu1e[k] = 0;
+            if (cfg->use_hs)                       /* word2vec.c: HIERARCHICAL SOFTMAX, before the negative sampling */
+                for (int d = 0; d < m->codelen[word]; d++) {
+                    float* l2 = m->syn1 + (int64_t)m->points[(int64_t)word * MAX_CODE_LENGTH + d] * D;
+                    float f = cfg->arith ? dot_lane16(l1, l2, D) : dot_seq(l1, l2, D);
+                    if (f <= -MAX_EXP) continue;
+                    else if (f >= MAX_EXP) continue;
+                    f = g_exp_table[(int)((f + MAX_EXP) * (EXP_TABLE_SIZE / MAX_EXP / 2))];
+                    float g = (1 - m->codes[(int64_t)word * MAX_CODE_LENGTH + d] - f) * alpha;
+                    if (cfg->arith) {
+                        for (int k = 0; k < D; k++) neu1e[k] = fmaf(g, l2[k], neu1e[k]);
+                        for (int k = 0; k < D; k++) l2[k] = fmaf(g, l1[k], l2[k]);
+                    } else {
+                        for (int k = 0; k < D; k++) neu1e[k] += g * l2[k];
+                        for (int k = 0; k < D; k++) l2[k] += g * l1[k];
+                    }
+                }
             for (int d = 0; d < K + 1; d++) {
                 int64_t target; float label;
                 if (d == 0) { target = word; label = 1; }
@@ -551,6 +632,7 @@ int orc_train_sgns(const int32_t* walks, int64_t n_walks, int32_t max_len,
     /* --- weights: word2vec.c InitNet — syn0 = ((lcg & 0xFFFF)/65536 - 0.5)/D, syn1neg = 0 --- */
     m->syn0 = (float*)malloc((size_t)(V * D + 1) * sizeof(float));
     m->syn1neg = (float*)calloc((size_t)(V * D + 1), sizeof(float));
+    if (cfg->use_hs) { m->syn1 = (float*)calloc((size_t)(V * D + 1), sizeof(float)); create_binary_tree(m); }
     {
         uint64_t r = cfg->seed;
         for (int64_t a = 0; a < V; a++)

@@ -72,6 +72,9 @@ typedef struct orc_train_config {
     int64_t total_walks;     /* global number of walks per epoch (0 = n_walks) */
     int64_t total_words;     /* global in-vocab tokens per epoch (0 = count locally) */
     int64_t words_before;    /* in-vocab tokens of walks before walk_index_base */
+    int32_t use_hs;          /* hierarchical-softmax term as well (DL4J's default when the builder does not disable it,
+                                J/DeepWalk.java:73-76; word2vec.c -hs 1): Huffman codes over the counts, table syn1 */
+    int32_t reserved;
 } orc_train_config;
 
 typedef struct orc_model orc_model;
@@ -82,6 +85,10 @@ int64_t orc_model_vocab_size(const orc_model* m);
 int32_t orc_model_dim(const orc_model* m);
 const float*   orc_model_syn0(const orc_model* m);      /* [V x dim] */
 const float*   orc_model_syn1neg(const orc_model* m);   /* [V x dim] */
+const float*   orc_model_syn1(const orc_model* m);      /* [V-1 x dim] inner nodes of the Huffman tree (use_hs), else null */
+/* word2vec.c CreateBinaryTree over counts sorted descending: codelen[V], points/codes [V x 40] */
+int orc_huffman(const int64_t* counts, int64_t V, int32_t* codelen, int32_t* points, uint8_t* codes);
+int32_t orc_model_code(const orc_model* m, int64_t row, int32_t* points, uint8_t* codes, int32_t cap);   /* code length of a word */
 const int32_t* orc_model_vocab_ids(const orc_model* m); /* vertex id of row r */
 const int64_t* orc_model_counts(const orc_model* m);    /* token count of row r */
 const int32_t* orc_model_table(const orc_model* m);     /* [table_size] */

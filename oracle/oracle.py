@@ -27,7 +27,7 @@ class TrainConfig(C.Structure):
         ("epochs", C.c_int32), ("threads", C.c_int32), ("alpha", C.c_float), ("min_alpha", C.c_float),
         ("seed", C.c_uint64), ("table_size", C.c_int64), ("arith", C.c_int32), ("n_vertices", C.c_int32),
         ("walk_index_base", C.c_int64), ("total_walks", C.c_int64), ("total_words", C.c_int64),
-        ("words_before", C.c_int64),
+        ("words_before", C.c_int64), ("use_hs", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -60,9 +60,11 @@ def lib():
     L.orc_graph_sample_next.argtypes = [vp, i32, dbl, P(i32)]
     L.orc_sample_walks.argtypes = [vp, i64, i32, i64, C.c_int, i64, vp, P(i64)]
     L.orc_train_sgns.argtypes = [vp, i64, i32, P(TrainConfig), P(vp)]
-    for name, rt in (("vocab_size", i64), ("dim", i32), ("syn0", vp), ("syn1neg", vp), ("vocab_ids", vp),
+    for name, rt in (("vocab_size", i64), ("dim", i32), ("syn0", vp), ("syn1neg", vp), ("syn1", vp), ("vocab_ids", vp),
                      ("counts", vp), ("table", vp), ("pairs", i64), ("total_words", i64), ("seconds", dbl)):
         f = getattr(L, "orc_model_" + name); f.argtypes = [vp]; f.restype = rt
+    L.orc_model_code.argtypes = [vp, i64, vp, vp, i32]; L.orc_model_code.restype = i32
+    L.orc_huffman.argtypes = [vp, i64, vp, vp, vp]
     L.orc_model_free.argtypes = [vp]
     L.orc_exp_table.argtypes = [C.c_int]; L.orc_exp_table.restype = C.c_float
     L.orc_mix64.argtypes = [u64]; L.orc_mix64.restype = u64
@@ -181,12 +183,20 @@ class Model:
 
         self.syn0 = arr(L.orc_model_syn0(h), n, np.float32).reshape(self.V, self.dim)
         self.syn1neg = arr(L.orc_model_syn1neg(h), n, np.float32).reshape(self.V, self.dim)
+        p1 = L.orc_model_syn1(h)
+        self.syn1 = arr(p1, max(self.V - 1, 0) * self.dim, np.float32).reshape(max(self.V - 1, 0), self.dim) if p1 else None
         self.vocab_ids = arr(L.orc_model_vocab_ids(h), self.V, np.int32)
         self.counts = arr(L.orc_model_counts(h), self.V, np.int64)
         self.pairs = int(L.orc_model_pairs(h)); self.total_words = int(L.orc_model_total_words(h))
         self.seconds = float(L.orc_model_seconds(h))
         self._table_ptr = L.orc_model_table(h)
         self._h = h
+
+    def code(self, row):
+        """Huffman path of vocabulary row `row`: (points, codes)."""
+        pts = np.zeros(40, np.int32); cds = np.zeros(40, np.uint8)
+        n = lib().orc_model_code(self._h, int(row), _ptr(pts), _ptr(cds), 40)
+        return pts[:n].copy(), cds[:n].copy()
 
     def table(self, table_size):
         return np.ctypeslib.as_array(C.cast(self._table_ptr, C.POINTER(C.c_int32)), shape=(table_size,)).copy()
@@ -199,16 +209,26 @@ class Model:
 
 def train_sgns(walks, n_vertices, dim, window, negative=5, min_count=2, epochs=1, threads=1, alpha=0.025,
                min_alpha=1e-4, seed=1, table_size=100_000_000, arith=0, walk_index_base=0, total_walks=0,
-               total_words=0, words_before=0):
+               total_words=0, words_before=0, use_hs=False):
     walks = np.ascontiguousarray(walks, np.int32)
     n, L = walks.shape
     cfg = TrainConfig(dim, window, negative, min_count, epochs, threads, alpha, min_alpha, seed, table_size,
-                      arith, n_vertices, walk_index_base, total_walks, total_words, words_before)
+                      arith, n_vertices, walk_index_base, total_walks, total_words, words_before, int(bool(use_hs)), 0)
     h = C.c_void_p(0)
     rc = lib().orc_train_sgns(_ptr(walks), n, L, C.byref(cfg), C.byref(h))
     if rc != 0:
         raise RuntimeError("oracle train_sgns failed: rc=%d" % rc)
     return Model(h)
+
+
+def huffman(counts):
+    """word2vec.c CreateBinaryTree over counts sorted descending -> (codelen[V], points[V,40], codes[V,40])."""
+    counts = np.ascontiguousarray(counts, np.int64)
+    V = len(counts)
+    codelen = np.zeros(V, np.int32); points = np.zeros((V, 40), np.int32); codes = np.zeros((V, 40), np.uint8)
+    if lib().orc_huffman(_ptr(counts), V, _ptr(codelen), _ptr(points), _ptr(codes)) != 0:
+        raise RuntimeError("oracle huffman failed")
+    return codelen, points, codes
 
 
 def exp_table():

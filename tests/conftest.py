@@ -39,6 +39,7 @@ def algos_harness():
     H.harness_w2v_jump.argtypes = [C.c_uint64, C.c_uint64]; H.harness_w2v_jump.restype = C.c_uint64
     H.harness_stream_sum.argtypes = [C.c_void_p, C.c_int64]; H.harness_stream_sum.restype = C.c_double
     H.harness_bitset_selftest.argtypes = [C.c_int64, C.c_uint64, C.c_int64]; H.harness_bitset_selftest.restype = C.c_int64
+    H.harness_huffman.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     return H
 
 

@@ -17,6 +17,14 @@ double harness_jr_next_double(uint64_t* s) { return dge_jr_next_double(*s); }
 uint64_t harness_mix64(uint64_t x) { return dge_mix64(x); }
 uint64_t harness_w2v_jump(uint64_t s, uint64_t n) { return dge_w2v_jump(s, n); }
 double harness_stream_sum(const double* x, int64_t n) { return dge_java8_stream_sum(x, n); }
+int harness_huffman(const int64_t* counts, int64_t V, int64_t* off, int32_t* points, int64_t cap, uint64_t* codes) {
+    std::vector<int64_t> o; std::vector<int32_t> p; std::vector<uint64_t> c;
+    int longest = dge_huffman_paths(counts, V, o, p, c);
+    for (int64_t i = 0; i <= V; i++) off[i] = o[i];
+    for (int64_t i = 0; i < (int64_t)p.size() && i < cap; i++) points[i] = p[i];
+    for (int64_t i = 0; i < V; i++) codes[i] = c[i];
+    return longest;
+}
 int64_t harness_bitset_selftest(int64_t k, uint64_t seed, int64_t ops) {
     std::vector<uint64_t> mem(dge_bs_words(k) + 1);
     dge_bitset4 s; dge_bs_init(s, mem.data(), k);

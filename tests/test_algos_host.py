@@ -62,3 +62,28 @@ def test_stream_sum_matches_oracle_top_k_degree(algos_harness, oracle):
     g.keep_top_k(10)
     top = np.sort(w)[::-1][:10].copy()
     assert algos_harness.harness_stream_sum(top.ctypes.data, 10) == g.get_alias(0)["out_degree"]
+
+
+def test_huffman_paths_match_word2vec_tree(algos_harness, oracle):
+    """dge_huffman_paths (product, CSR form) == CreateBinaryTree as restated in the oracle, ties included."""
+    rng = np.random.default_rng(5)
+    cases = [np.array([7], np.int64), np.array([5, 5], np.int64), np.array([9, 4, 4, 4, 1, 1, 1, 1, 1], np.int64),
+             np.full(64, 3, np.int64), np.full(37, 1, np.int64),
+             np.sort(rng.integers(1, 50, 1000))[::-1].astype(np.int64),
+             np.sort(rng.zipf(1.3, 5000).clip(max=10**9))[::-1].astype(np.int64),
+             np.sort((1e6 / np.arange(1, 20001) ** 1.1).astype(np.int64) + 1)[::-1].astype(np.int64)]
+    for counts in cases:
+        counts = np.ascontiguousarray(counts)
+        V = len(counts)
+        codelen, points, codes = oracle.huffman(counts)
+        off = np.zeros(V + 1, np.int64); pts = np.zeros(max(int(codelen.sum()), 1), np.int32); bits = np.zeros(V, np.uint64)
+        longest = algos_harness.harness_huffman(counts.ctypes.data, V, off.ctypes.data, pts.ctypes.data, len(pts), bits.ctypes.data)
+        assert longest == (codelen.max() if V > 1 else 0) and longest <= 40
+        assert np.array_equal(np.diff(off), codelen)
+        for r in range(V):
+            n = codelen[r]
+            assert np.array_equal(pts[off[r]:off[r] + n], points[r, :n])
+            assert [(int(bits[r]) >> d) & 1 for d in range(n)] == list(codes[r, :n])
+        if V > 1:       # a full binary tree: Kraft equality, every inner node on some path
+            assert abs(sum(2.0 ** -int(l) for l in codelen) - 1.0) < 1e-9
+            assert set(pts[:off[V]].tolist()) == set(range(V - 1))
