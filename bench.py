@@ -202,8 +202,8 @@ def main():
                        "sgns_workers": args.workers, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": "walk-shard x%d, RCCL all-reduce of deltas per step" % N if N > 1 else "1 GPU",
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": measured_traffic(args.workload, args.policy, pairs_per_launch),
-                         "kernel": "k_sgns_train_locked" if (args.policy in (5, 6) or (args.policy == 0 and args.workload == "cfg3")) else "k_sgns_train",
+                         "traffic": None if args.hs else measured_traffic(args.workload, args.policy, pairs_per_launch),
+                         "kernel": "k_sgns_train<HS>" if args.hs else "k_sgns_train_locked" if (args.policy in (5, 6) or (args.policy == 0 and args.workload == "cfg3")) else "k_sgns_train",
                          "ms_per_launch": ms_per_launch,
                          "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
                          "walk_kernel_ms_per_launch": st["walk_kernel_ms"] / launches,
