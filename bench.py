@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch-walks", type=int, default=0, help="walks per step per GPU (default: epoch/10)")
     ap.add_argument("--workers", type=int, default=0, help="SGNS walk workers (0 = fill the device)")
+    ap.add_argument("--dim", type=int, default=0, help="override the workload's embedding dimension (experiments)")
+    ap.add_argument("--negative", type=int, default=-1, help="override the workload's negative count (experiments)")
     ap.add_argument("--hs", action="store_true", help="train the hierarchical-softmax term as well (dge_train_config.use_hs; not the headline path)")
     ap.add_argument("--policy", type=int, default=0, help="dge_train_config.update_policy (0 auto = float atomics)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug)")
@@ -91,6 +93,10 @@ def main():
         wl["R"] = max(16, int(wl["R"] * args.scale))
         if "n_edges" in wl:
             wl["n_edges"] = int(wl["n_edges"] * args.scale)
+    if args.dim > 0:
+        wl["dim"] = args.dim; wl["name"] += " [dim=%d]" % args.dim
+    if args.negative >= 0:
+        wl["negative"] = args.negative; wl["name"] += " [K=%d]" % args.negative
     R, T, L, D, K = wl["R"], wl["T"], wl["L"], wl["dim"], wl["negative"]
     NV = R * T
     t0 = time.time()
@@ -183,6 +189,10 @@ def main():
         ms_per_launch = st["kernel_ms"] / launches
         pairs_per_launch = st["pairs"] / launches
         achieved = pairs_per_launch * bytes_per_pair / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        sched = model.schedule()
+        kernel_name = ("k_sgns_train<HS>" if args.hs else
+                       {5: "k_sgns_train_locked", 6: "k_sgns_train_locked<strict>", 7: "k_sgns_train_locked<head rows by atomics>",
+                        2: "k_sgns_train<atomics>", 1: "k_sgns_train<row rmw>", 0: "k_sgns_train<in-order>"}[sched["update_policy"]])
         out = {
             "metric": "SGNS training edges/sec",
             "value": value,
@@ -202,8 +212,8 @@ def main():
                        "sgns_workers": args.workers, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": "walk-shard x%d, RCCL all-reduce of deltas per step" % N if N > 1 else "1 GPU",
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None if args.hs else measured_traffic(args.workload, args.policy, pairs_per_launch),
-                         "kernel": "k_sgns_train<HS>" if args.hs else "k_sgns_train_locked" if (args.policy in (5, 6) or (args.policy == 0 and args.workload == "cfg3")) else "k_sgns_train",
+                         "traffic": None if (args.hs or args.dim or args.negative >= 0) else measured_traffic(args.workload, sched["update_policy"], pairs_per_launch),
+                         "kernel": kernel_name, "schedule": sched,
                          "ms_per_launch": ms_per_launch,
                          "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
                          "walk_kernel_ms_per_launch": st["walk_kernel_ms"] / launches,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "dge_model_table": (_int, [_vp, _P(_vp), _P(_i64)]),
     "dge_model_stats": (_int, [_vp, _P(TrainStats)]),
     "dge_model_reset_stats": (_int, [_vp]),
+    "dge_model_schedule": (_int, [_vp, _P(_i32), _P(_i64), _P(_i32)]),
     "dge_write_vec": (_int, [_vp, _vp, C.c_char_p, _int]),
     "dge_model_free": (None, [_vp]),
     "dge_model_sync_size": (_int, [_vp, _P(_i64)]),

@@ -24,6 +24,9 @@
 #define EXP_TABLE_SIZE 1000
 #define MAX_EXP 6
 #define NEG_BATCH 5
+#ifndef DGE_HS_WAVES
+#define DGE_HS_WAVES 4
+#endif
 
 struct EventPair { hipEvent_t a, b; int kind; };
 
@@ -37,6 +40,7 @@ struct dge_model {
     int64_t T = 0;
     int64_t total_words = 0;
     double neg_collision = 1.0;                 // sum of squared negative-sampling probabilities: P(two draws hit one row)
+    int64_t hot_rows_auto = 0;                  // head rows that policy 7 keeps out of the lock protocol (see dge_model_create)
     int n_cus = 256;
     float *d_syn0 = nullptr, *d_syn1neg = nullptr, *d_snap = nullptr;
     // hierarchical softmax (cfg.use_hs): inner-node table and the Huffman paths in CSR form
@@ -64,6 +68,7 @@ struct dge_model {
     std::vector<EventPair> pending;
     double kernel_ms = 0, walk_ms = 0;
     int64_t launches = 0;
+    int last_policy = -1; int64_t last_workers = 0; int32_t last_hot_rows = 0;   // what the latest launch ran with
 };
 
 // ------------------------------------------------------------------------------------------ vocabulary
@@ -160,6 +165,7 @@ struct TrainParams {
     const int64_t* hs_off; const int32_t* hs_points; const uint64_t* hs_codes;
     int32_t hs_hot0, hs_n_hot; // inner nodes [hs_hot0, hs_hot0 + hs_n_hot) — the ones nearest the root — combine in LDS
     int32_t hs_drain;         // an LDS accumulator is drained to memory every hs_drain additions
+    int32_t hot_rows;         // policy 7: vocabulary rows [0, hot_rows) — the most frequent — are never locked, they take atomics
 };
 
 template <int DCH> struct Row { float4 v[DCH]; };
@@ -406,7 +412,7 @@ __device__ __forceinline__ int32_t walk_tok(bool in_regs, const int32_t* sen, in
 }
 
 template <int DCH, int POL, bool BIG, bool HS>
-__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? 4 : 1)
+__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HS ? DGE_HS_WAVES : 4) : 1)
 k_sgns_train(TrainParams p) {
     using P = Policy<POL>;
     __shared__ float s_exp[EXP_TABLE_SIZE];
@@ -697,8 +703,40 @@ __device__ __forceinline__ void rowA_store(const Row<DCH>& r, const TableView& t
     }
 }
 
-template <int DCH, bool STRICT, bool BIG>
-__device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* locks, int32_t row, const float* d, int lane) {
+// Policy 7 (HOTMIX): rows the vocabulary's head are wanted by many workers at once — under row locks they make the
+// kernel spin (cfg5: 5e5 edges/s).  Those rows are never locked: they are read with agent-scope loads and updated with
+// memory-side float atomics, like policy 2; all other rows keep the lock protocol.  A row is always updated one way or
+// the other, never both, so neither side can overwrite the other's update.
+// The atomics want 64 contiguous bytes per group instruction (lane j' -> element 64c + 16m + j'), the registers hold the
+// 16-byte layout (lane j -> elements 64c + 4j .. 4j+3): element 16m + j' sits in lane 4m + j'/4, component j' % 4.
+template <int DCH>
+__device__ __forceinline__ void rowA_atomic_axpy(const TableView& t, int32_t row, int lane, float g, const Row<DCH>& x) {
+    float* p = t.base + (size_t)row * (t.row_bytes / 4) + lane;
+    const int hi = lane >> 2, comp = lane & 3;
+#pragma unroll
+    for (int c = 0; c < DCH; c++)
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int src = 4 * m + hi;
+            const float x0 = __shfl(x.v[c].x, src, 16), x1 = __shfl(x.v[c].y, src, 16), x2 = __shfl(x.v[c].z, src, 16), x3 = __shfl(x.v[c].w, src, 16);
+            const float v = comp == 0 ? x0 : (comp == 1 ? x1 : (comp == 2 ? x2 : x3));
+            atomicAdd(p + c * 64 + 16 * m, g * v);
+        }
+}
+// the centre's delta parked in LDS (index 64q + 16*component + lane holds element 64q + 4*lane + component)
+template <int DCH>
+__device__ __forceinline__ void ldsA_atomic_add(const TableView& t, int32_t row, int lane, const float* d_base) {
+    float* p = t.base + (size_t)row * (t.row_bytes / 4) + lane;
+    const int hi = lane >> 2, comp = lane & 3;
+#pragma unroll
+    for (int c = 0; c < DCH; c++)
+#pragma unroll
+        for (int m = 0; m < 4; m++) atomicAdd(p + c * 64 + 16 * m, d_base[c * 64 + comp * 16 + 4 * m + hi]);
+}
+
+template <int DCH, bool STRICT, bool BIG, bool HOTMIX = false>
+__device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* locks, int32_t row, const float* d, int lane, int32_t hot_rows = 0) {
+    if (HOTMIX && row < hot_rows) { ldsA_atomic_add<DCH>(syn1neg, row, lane, d - lane); return; }
     for (;;) {
         const bool won = lane == 0 ? row_trylock(locks, row) : false;
         const bool got = __shfl((int)won, 0, 16) != 0;
@@ -720,8 +758,8 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
 
 #define LK_NEG_LANES 13      /* lanes 0..12 draw negatives, lane 13 = pending centre flush, lane 14 = the pair's syn0 row */
 // 3 waves per SIMD is the measured optimum for D <= 128: 4 (128 VGPRs) spills 88 B per lane and runs 20 % slower, 2 runs 12 % slower
-template <int DCH, bool STRICT, bool BIG>
-__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? 3 : 1)
+template <int DCH, bool STRICT, bool BIG, bool HOTMIX>
+__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? 3 : ((HOTMIX && DCH <= 4) ? 2 : 1))
 k_sgns_train_locked(TrainParams p) {
     __shared__ float s_exp[EXP_TABLE_SIZE];
     __shared__ float s_dh[16 * 2 * DCH * 64];
@@ -737,6 +775,7 @@ k_sgns_train_locked(TrainParams p) {
     const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride);
     int* const locks1 = p.locks;
     int* const locks0 = p.locks + p.V + 1;
+    const int32_t hot_rows = HOTMIX ? p.hot_rows : 0;
 
     uint64_t mA = 1, cA = 0;
     for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
@@ -767,7 +806,7 @@ k_sgns_train_locked(TrainParams p) {
     do {                                                                                                               \
         if (h_dirty) {                                                                                                 \
             h_dirty = false;                                                                                           \
-            if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane); \
+            if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows); \
             pend_row = word;                                                                                           \
             cur_buf ^= 1;                                                                                              \
         }                                                                                                              \
@@ -861,8 +900,9 @@ k_sgns_train_locked(TrainParams p) {
                     const bool others_ok = have_l1 || !l1_only;
                     const bool want = (others_ok && myq >= 0 && myq < NEG_BATCH && lane < kc && ((pending >> myq) & 1u)) ||
                                       (others_ok && lane == 13 && flush_pending) || (lane == 14 && !have_l1);
-                    const bool won = want ? row_trylock(lane == 14 ? locks0 : locks1, t) : false;
-                    const unsigned long long bal = __ballot(won);
+                    const bool lockfree = HOTMIX && want && t < hot_rows;          // a head row: no lock, atomics
+                    const bool won = (want && !lockfree) ? row_trylock(lane == 14 ? locks0 : locks1, t) : false;
+                    const unsigned long long bal = __ballot(won || lockfree);
                     const unsigned gotl = (unsigned)(bal >> (threadIdx.x & 48)) & 0xFFFFu;
                     if (!have_l1 && !((gotl >> 14) & 1u)) {
                         // the pair's syn0 row is busy (possibly held by another group of THIS wave, which can only drop it
@@ -887,10 +927,16 @@ k_sgns_train_locked(TrainParams p) {
                             float f = row_dot(l1, rr[q]);
                             float g = sgns_g(f, 0.0f, alpha, s_exp);
                             row_axpy(neu, g, rr[q]);
-                            row_axpy(rr[q], g, l1);
-                            rowA_store<DCH, 16, BIG>(rr[q], syn1neg, tg[q], lane);
+                            if (HOTMIX && tg[q] < hot_rows) {
+                                rowA_atomic_axpy<DCH>(syn1neg, tg[q], lane, g, l1);
+                            } else {
+                                row_axpy(rr[q], g, l1);
+                                rowA_store<DCH, 16, BIG>(rr[q], syn1neg, tg[q], lane);
+                            }
                         }
-                    if (gotf) {
+                    if (gotf && HOTMIX && pend_row < hot_rows) {
+                        ldsA_atomic_add<DCH>(syn1neg, pend_row, lane, my_dh + (cur_buf ^ 1) * DCH * 64);
+                    } else if (gotf) {
                         const float* d = my_dh + (cur_buf ^ 1) * DCH * 64 + lane;
 #pragma unroll
                         for (int q = 0; q < DCH; q++) {
@@ -943,15 +989,19 @@ k_sgns_train_locked(TrainParams p) {
         for (int q = 0; q < DCH; q++) {
             l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
         }
-        rowA_store<DCH, 16, BIG>(l1, syn0, last, lane);
-        row_commit_wait(STRICT ? row_probe_lines(syn0, last, lane, DCH * 2) : 0.f);
-        if (lane == 14) row_unlock<STRICT>(locks0, last);
+        if (HOTMIX && last < hot_rows) {
+            rowA_atomic_axpy<DCH>(syn0, last, lane, 1.0f, neu);
+        } else {
+            rowA_store<DCH, 16, BIG>(l1, syn0, last, lane);
+            row_commit_wait(STRICT ? row_probe_lines(syn0, last, lane, DCH * 2) : 0.f);
+            if (lane == 14) row_unlock<STRICT>(locks0, last);
+        }
         my_pairs++;
         c++;
         if (c == i) c++;
     }
     LK_CLOSE_CENTRE();
-    if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane);
+    if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows);
 #undef LK_TOK
 #undef LK_CLOSE_CENTRE
     if (lane == 0) {
@@ -1165,6 +1215,7 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     int dch = (cfg->dim + 63) / 64;
     if (!dim_supported(dch)) dch = dch <= 6 ? 6 : 8;
     if (cfg->dim > 512) DGE_FAIL(DGE_ERR_ARG, "dge_model_create: dim %d > 512 is not supported", cfg->dim);
+    if (cfg->update_policy < 0 || cfg->update_policy == 4 || cfg->update_policy > 7) DGE_FAIL(DGE_ERR_ARG, "dge_model_create: unknown update_policy %d", cfg->update_policy);
     if (cfg->use_hs && cfg->update_policy != 0 && cfg->update_policy != 2 && cfg->update_policy != 3)
         DGE_FAIL(DGE_ERR_ARG, "dge_model_create: use_hs runs under update_policy 0 (auto), 2 or 3, not %d", cfg->update_policy);
     int rc = dge_require_device(device);
@@ -1230,6 +1281,20 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
             double s2 = 0.0;
             for (int64_t i = 0; i < V; i++) { double q = pow((double)m->h_counts[(size_t)i], power) / twp; s2 += q * q; }
             m->neg_collision = s2;
+            // Head of the vocabulary for the mixed policy (7).  A try-lock fails when another worker holds the row: per pair
+            // ~5 syn1neg rows drawn with q_i (unigram^0.75) and one syn0 row that occurs with p_i (unigram), held for the whole
+            // pair.  Expected failures per attempt with W workers ~ W * 5 * (sum q_i^2 + sum p_i^2) over the LOCKED rows; the
+            // head [0, H) is taken out until that is below 0.1.  (cfg3: 0.14 with H = 0 — left alone, see train_rows; cfg5: 3.3 M
+            // rows, H ~ 1e4.)
+            const double W0 = (double)((int64_t)m->n_cus * 3 * 16);
+            double tail = 0.0; int64_t H = V;
+            while (H > 0) {
+                const double c = (double)m->h_counts[(size_t)(H - 1)];
+                const double q = pow(c, power) / twp, pp = c / (double)tw;
+                if (W0 * 5.0 * (tail + q * q + pp * pp) >= 0.1) break;
+                tail += q * q + pp * pp; H--;
+            }
+            m->hot_rows_auto = H;
         }
         double d1 = 0.0;
         for (int64_t i = 0; i < V; i++) { d1 = (i == 0) ? pow((double)m->h_counts[0], power) / twp : d1 + pow((double)m->h_counts[(size_t)i], power) / twp; cum[(size_t)i] = d1; }
@@ -1311,8 +1376,9 @@ static void launch_train_b(const TrainParams& p, int pol, unsigned blocks, unsig
         case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 10: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, true>), dim3(blocks), dim3(threads), 0, st, p); break;    // + hierarchical softmax
         case 12: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, true>), dim3(blocks), dim3(threads), shmem, st, p); break;
-        case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 7: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true>), dim3(blocks), dim3(threads), 0, st, p); break;
         default: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
     }
 }
@@ -1345,7 +1411,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.counters = m->d_counters;
     p.locks = m->d_locks;
     p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
-    p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1;
+    p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0;
     const bool hs = m->cfg.use_hs != 0;
 
     int64_t workers;
@@ -1354,7 +1420,8 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // (Hogwild's premise is sparse collisions: measured, a 2.3k-row table keeps 0.99 cosine to the in-order
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
         const bool auto_locked = !hs && m->cfg.update_policy == 0 && m->V >= 262144 && (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision < 0.25;
-        const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || auto_locked) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
+        const bool auto_mixed = !hs && m->cfg.update_policy == 0 && !auto_locked && m->V >= 262144 && m->hot_rows_auto <= m->V / 8;
+        const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || m->cfg.update_policy == 7 || auto_locked || auto_mixed) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)m->n_cus * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
@@ -1370,9 +1437,15 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // vocabulary (cfg5) gives >> 1: the same kernel spins on its hot rows (measured 5e5 edges/s) while memory-side
         // atomics are indifferent to the skew (5.9e7 = their byte rate) -> atomics.
         const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
-        pol = workers == 1 ? 100 : ((!hs && m->V >= 262144 && fail < 0.25) ? 5 : 2);
+        // In between (a skewed head over a long tail — cfg5, and what real trip data looks like) the head rows alone are
+        // taken out of the lock protocol: policy 7.
+        pol = workers == 1 ? 100 : ((!hs && m->V >= 262144 && fail < 0.25) ? 5 : ((!hs && m->V >= 262144 && m->hot_rows_auto <= m->V / 8) ? 7 : 2));
     }
-    if (pol == 100 || (workers == 1 && pol != 5 && pol != 6 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
+    if (pol == 7) {
+        p.hot_rows = (int32_t)std::min<int64_t>(m->hot_rows_auto, m->V);
+        if (const char* e = getenv("DGE_HOT_ROWS")) { long long v = atoll(e); if (v >= 0) p.hot_rows = (int32_t)std::min<int64_t>(v, m->V); }     // tuning/ablation knob
+    }
+    if (pol == 100 || (workers == 1 && pol != 5 && pol != 6 && pol != 7 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
     if (pol == 3) pol = 0;
     size_t shmem = 0;
     if (hs) {
@@ -1407,6 +1480,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     DGE_HIP(hipEventRecord(ev.b, st));
     m->pending.push_back(ev);
     m->launches++;
+    m->last_policy = pol >= 10 ? pol - 10 : pol; m->last_workers = workers; m->last_hot_rows = p.hot_rows;
     DGE_HIP(hipGetLastError());
     return DGE_OK;
 }
@@ -1557,6 +1631,15 @@ extern "C" int dge_model_stats(const dge_model* mc, dge_train_stats* out) {
     DGE_HIP(hipMemcpy(c, m->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     out->pairs = (int64_t)c[0]; out->words = (int64_t)c[1];
     out->kernel_ms = m->kernel_ms; out->walk_kernel_ms = m->walk_ms; out->launches = m->launches;
+    return DGE_OK;
+}
+
+extern "C" int dge_model_schedule(const dge_model* m, int32_t* update_policy, int64_t* workers, int32_t* hot_rows) {
+    if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_schedule: null model");
+    if (m->last_policy < 0) DGE_FAIL(DGE_ERR_STATE, "dge_model_schedule: nothing has been trained yet");
+    if (update_policy) *update_policy = m->last_policy;
+    if (workers) *workers = m->last_workers;
+    if (hot_rows) *hot_rows = m->last_hot_rows;
     return DGE_OK;
 }
 

@@ -278,6 +278,12 @@ class SgnsModel:
         check(lib.dge_write_vec(self._h, arr, str(path).encode(), int(bool(header))))
 
     # --- multi-GPU exchange (include/dge.h, last section)
+    def schedule(self):
+        """What the latest launch resolved update_policy 0 / workers 0 to."""
+        pol, w, hot = C.c_int32(0), C.c_int64(0), C.c_int32(0)
+        check(lib.dge_model_schedule(self._h, C.byref(pol), C.byref(w), C.byref(hot)))
+        return {"update_policy": pol.value, "workers": w.value, "hot_rows": hot.value}
+
     def sync_size(self):
         n = C.c_int64(0); check(lib.dge_model_sync_size(self._h, C.byref(n))); return n.value
 

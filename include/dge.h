@@ -132,7 +132,7 @@ typedef struct dge_train_config {
     int32_t update_policy;   /* how concurrent workers update the tables (MI355X has 8 L2s that are not coherent):
                                 0 = auto: 5 when the vocabulary has >= 262144 rows and its negative-sampling
                                     distribution is flat enough for lock attempts to succeed (expected failure
-                                    rate < 0.25), else 2;
+                                    rate < 0.25); 7 when a head of at most V/8 rows carries the skew; else 2;
                                 1 = agent-scope row read-modify-write, write-through (last writer of a row wins);
                                 2 = agent-scope loads + memory-side float atomics (no update is lost);
                                 3 = plain cached accesses (debug only: every XCD trains a private stale copy);
@@ -140,7 +140,9 @@ typedef struct dge_train_config {
                                     commit (a re-lock can overtake the write-through: measured loss <= 4e-7 of the row
                                     updates at >= 65k rows; fastest);
                                 6 = as 5 with strict commit (one returning atomic per stored 128-B line: no update
-                                    is ever lost).
+                                    is ever lost);
+                                7 = as 5, but the head of the vocabulary (the rows many workers want at once; how many
+                                    is derived from the counts) stays out of the lock protocol and takes atomics as in 2.
                                 workers == 1 with policy 0/3 is the in-order schedule with plain accesses. */
     int32_t use_hs;          /* .useHierarchicSoftmax(b): 0 = negative sampling only (the north-star path);
                                 1 = the hierarchical-softmax term as well, before the negatives of each pair — what
@@ -193,6 +195,9 @@ int  dge_model_counts(dge_model* m, const int64_t** counts);
 int  dge_model_table(dge_model* m, const int32_t** table, int64_t* table_size);
 int  dge_model_stats(const dge_model* m, dge_train_stats* out);
 int  dge_model_reset_stats(dge_model* m);
+/* what the latest training launch resolved `update_policy` 0 / `workers` 0 to: the policy that ran (0 = in-order plain),
+ * the concurrent workers, and for policy 7 the head rows kept out of the lock protocol */
+int  dge_model_schedule(const dge_model* m, int32_t* update_policy, int64_t* workers, int32_t* hot_rows);
 /* WordVectorSerializer.writeWordVectors(w2v, path)  J/DeepWalk.java:82: "name v1 .. vD\n" per vocabulary
  * row, no header (header != 0 writes the LINE-style "V D" first line of miscs/taxi_all.txt:1).
  * names[v] is the string of vertex id v; null -> the decimal id. */

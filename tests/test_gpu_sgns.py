@@ -222,6 +222,33 @@ def test_locked_policies_match_the_in_order_result(dge, oracle):
                 assert cosine_rows(dm.syn1neg(), om.syn1neg).min() > tol
 
 
+def test_mixed_policy_head_rows_by_atomics(dge, oracle, monkeypatch):
+    """Policy 7: the head of the vocabulary takes memory-side atomics, the tail the commit locks.  Whatever the split —
+    nothing hot, half the rows, every row — one worker reproduces the sequential result to rounding and 16 workers stay
+    within Hogwild noise; no pair is lost."""
+    walks, NV = _walks(oracle, dge, n=1500)
+    for dim in (64, 128, 20, 256):
+        om = oracle.train_sgns(walks, NV, dim, 6, table_size=20011, arith=0)
+        for hot in (0, 7, om.V // 2, om.V):
+            monkeypatch.setenv("DGE_HOT_ROWS", str(hot))
+            for workers, tol in ((1, 1 - 1e-4), (16, 0.99)):
+                c = dge.make_config(dim, 6, NV, workers=workers, table_size=20011, update_policy=7)
+                dm = dge.SgnsModel.fit(walks, c, 0)
+                syn0, vid = dm.vectors()
+                assert dm.stats()["pairs"] == om.pairs and np.array_equal(vid, om.vocab_ids)
+                assert cosine_rows(syn0, om.syn0).min() > tol, (dim, hot, workers)
+                assert cosine_rows(dm.syn1neg(), om.syn1neg).min() > tol, (dim, hot, workers)
+    monkeypatch.delenv("DGE_HOT_ROWS")
+    # a 3-row vocabulary where every row is "hot" or none is: terminates either way
+    tiny = np.array([[0, 1, 2, 1, 0]] * 64, np.int32)
+    for hot in ("0", "3"):
+        monkeypatch.setenv("DGE_HOT_ROWS", hot)
+        dm = dge.SgnsModel.fit(tiny, dge.make_config(8, 5, 3, min_count=1, workers=16, table_size=101, update_policy=7), 0)
+        assert np.isfinite(dm.vectors()[0]).all() and dm.stats()["pairs"] > 0
+    with pytest.raises(dge.DgeError):
+        dge.SgnsModel.fit(tiny, dge.make_config(8, 5, 3, update_policy=4), 0)
+
+
 def test_long_sentences_take_the_memory_token_path(dge, oracle):
     """Sentences longer than 64 tokens (text corpora through DeepWalk.learnEmbedding) read their tokens from memory
     instead of registers; in-order result still bit-exact, locked policy still within rounding."""
