@@ -46,6 +46,12 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch-walks", type=int, default=0, help="walks per step per GPU (default: epoch/10)")
     ap.add_argument("--workers", type=int, default=0, help="SGNS walk workers (0 = fill the device)")
+    ap.add_argument("--multi-gpu", choices=["blocks", "allreduce"], default="blocks",
+                    help="N>1: 'blocks' = row-partitioned block schedule, exact (default); 'allreduce' = the earlier walk-shard + delta "
+                         "averaging scheme, kept for comparison (it under-trains by the factor N: DESIGN.md §7)")
+    ap.add_argument("--sim-ranks", type=int, default=0,
+                    help="single process: run rank 0's share of an N-rank block-schedule step (its N episodes over the N-fold batch, "
+                         "partition pack/unpack included, no network) to estimate per-rank throughput at N ranks")
     ap.add_argument("--dim", type=int, default=0, help="override the workload's embedding dimension (experiments)")
     ap.add_argument("--negative", type=int, default=-1, help="override the workload's negative count (experiments)")
     ap.add_argument("--hs", action="store_true", help="train the hierarchical-softmax term as well (dge_train_config.use_hs; not the headline path)")
@@ -81,7 +87,7 @@ def main():
 
     import embedding_amd as E
     from embedding_amd import synth
-    from embedding_amd.distributed import allreduce_counts, exchange_deltas, shard_plan
+    from embedding_amd.distributed import allreduce_counts, block_schedule_step, exchange_deltas, shard_plan
 
     def stage(msg):
         if rank == 0:
@@ -136,7 +142,20 @@ def main():
     B = args.batch_walks or max(1, epoch_walks // 10)
     B = min(B, shard)
     delta = None
-    exchange = N > 1 or args.force_exchange
+    NB = args.sim_ranks if (N == 1 and args.sim_ranks > 1) else N          # ranks of the block schedule
+    blocks = NB > 1 and args.multi_gpu == "blocks"
+    if blocks:
+        # weak scaling: the global batch is NB x the single-GPU batch; every rank samples ALL of it from its replica of the
+        # graph (walk i is the same walk on any rank) and trains its row blocks of it
+        del corpus
+        torch.cuda.empty_cache()
+        BG = B * NB
+        corpus = g.sample_walks_device(BG, L, seed=WALK_SEED, rng_mode=1, first_index=0)
+        pf = model.partition_floats(NB)
+        part_buf = torch.empty(pf, dtype=torch.float32, device=dev)
+        gather_buf = torch.empty(pf * (NB if N > 1 else 1), dtype=torch.float32, device=dev)
+        stage("block schedule: %d ranks, global batch %d walks, partition buffers %.0f MB" % (NB, BG, pf * 4 / 1e6))
+    exchange = (N > 1 and not blocks) or args.force_exchange
     if exchange and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": torch.device(dev)} if args.backend == "nccl" else {}))
@@ -145,7 +164,31 @@ def main():
         model.snapshot()
     setup_s = time.time() - t0
 
+    def step_blocks(i):
+        first = (i * BG) % max(epoch_walks - BG + 1, 1)        # global index of the batch's first walk
+        state = {"sampled": False}
+
+        def train_fn():
+            if not state["sampled"]:                           # episode 0 also samples the batch
+                state["sampled"] = True
+                model.walk_and_train(g, corpus, 0, BG, walk_seed=WALK_SEED, walk_index_base=first, epoch=0, words_before=0,
+                                     words_scale=1.0, total_walks=epoch_walks)
+            else:
+                model.train(corpus, 0, BG, walk_index_base=first, epoch=0, words_before=0, words_scale=1.0, total_walks=epoch_walks)
+
+        if N > 1:
+            block_schedule_step(model, train_fn, N, rank, part_buf, gather_buf)
+        else:                                                  # --sim-ranks: rank 0's episodes, exchange replaced by a local pack/unpack
+            for e in range(NB):
+                model.set_partition(NB, 0, e % NB)
+                train_fn()
+                model.export_partition(1, NB, e % NB, part_buf)
+                model.import_partition(1, NB, e % NB, part_buf)
+            model.set_partition(1)
+
     def step(i):
+        if blocks:
+            return step_blocks(i)
         row0 = (i * B) % max(shard - B + 1, 1)
         model.walk_and_train(g, corpus, row0, B, walk_seed=WALK_SEED, walk_index_base=shard0 + row0, epoch=0,
                              words_before=0, words_scale=float(N), total_walks=epoch_walks)
@@ -209,7 +252,9 @@ def main():
             "config": {"workload": wl["name"], "vertices": NV, "edges": int(n_edges), "timeslices": T, "dim": D,
                        "negatives": K, "walk_len": L, "window": L, "walks_per_step_per_gpu": B,
                        "pairs_per_step_per_gpu": st["pairs"] / args.steps, "vocabulary": int((counts >= 2).sum().item()),
-                       "sgns_workers": args.workers, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": "walk-shard x%d, RCCL all-reduce of deltas per step" % N if N > 1 else "1 GPU",
+                       "sgns_workers": args.workers, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, all-gather of syn1neg partitions" % N if blocks and N > 1
+                                       else "SIMULATED rank 0 of a %d-rank block schedule on one GPU (value = this rank's share only)" % NB if blocks
+                                       else "walk-shard x%d, RCCL all-reduce of deltas per step (comparison mode)" % N if N > 1 else "1 GPU"),
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None if (args.hs or args.dim or args.negative >= 0) else measured_traffic(args.workload, sched["update_policy"], pairs_per_launch),

@@ -75,6 +75,10 @@ SIGNATURES = {
     "dge_model_schedule": (_int, [_vp, _P(_i32), _P(_i64), _P(_i32)]),
     "dge_write_vec": (_int, [_vp, _vp, C.c_char_p, _int]),
     "dge_model_free": (None, [_vp]),
+    "dge_model_set_partition": (_int, [_vp, _i32, _i32, _i32]),
+    "dge_model_partition_floats": (_int, [_vp, _i32, _P(_i64)]),
+    "dge_model_export_partition": (_int, [_vp, _int, _i32, _i32, _vp]),
+    "dge_model_import_partition": (_int, [_vp, _int, _i32, _i32, _vp]),
     "dge_model_sync_size": (_int, [_vp, _P(_i64)]),
     "dge_model_snapshot": (_int, [_vp]),
     "dge_model_export_delta": (_int, [_vp, _vp]),

@@ -69,6 +69,7 @@ struct dge_model {
     double kernel_ms = 0, walk_ms = 0;
     int64_t launches = 0;
     int last_policy = -1; int64_t last_workers = 0; int32_t last_hot_rows = 0;   // what the latest launch ran with
+    int32_t part_n = 1, part_ctx = 0, part_tgt = 0;                              // block schedule (dge_model_set_partition)
 };
 
 // ------------------------------------------------------------------------------------------ vocabulary
@@ -166,7 +167,33 @@ struct TrainParams {
     int32_t hs_hot0, hs_n_hot; // inner nodes [hs_hot0, hs_hot0 + hs_n_hot) — the ones nearest the root — combine in LDS
     int32_t hs_drain;         // an LDS accumulator is drained to memory every hs_drain additions
     int32_t hot_rows;         // policy 7: vocabulary rows [0, hot_rows) — the most frequent — are never locked, they take atomics
+    // multi-GPU block schedule (dge_model_set_partition): only pairs whose context row is in partition part_ctx and whose
+    // centre row is in partition part_tgt (row % part_n) are trained; negatives are moved into partition part_tgt
+    int32_t part_n, part_ctx, part_tgt;
 };
+
+// PART: which of a walk's (<= 64, register-resident) tokens lie in partition `part`: bit j of the result = token j.
+// Lane j of the group holds tokens j, j+16, j+32, j+48; a ballot collects 16 of them at a time.
+__device__ __forceinline__ uint64_t part_token_mask(int32_t tk0, int32_t tk1, int32_t tk2, int32_t tk3, int32_t n, int32_t part) {
+    const int sh = threadIdx.x & 48;
+    uint64_t m = (uint64_t)((__ballot(tk0 >= 0 && tk0 % n == part) >> sh) & 0xFFFFull);
+    m |= (uint64_t)((__ballot(tk1 >= 0 && tk1 % n == part) >> sh) & 0xFFFFull) << 16;
+    m |= (uint64_t)((__ballot(tk2 >= 0 && tk2 % n == part) >> sh) & 0xFFFFull) << 32;
+    m |= (uint64_t)((__ballot(tk3 >= 0 && tk3 % n == part) >> sh) & 0xFFFFull) << 48;
+    return m;
+}
+__device__ __forceinline__ int first_bit_from(uint64_t m, int from, int none) {       // lowest set bit >= from, else `none`
+    const uint64_t r = from < 64 ? (m >> from) : 0ull;
+    return r ? from + (int)__builtin_ctzll(r) : none;
+}
+
+// a negative drawn from the whole table, moved to the row of partition `part` nearest below it: rows are ordered by
+// count, so the row keeps (almost exactly) the frequency rank it was drawn with
+__device__ __forceinline__ int32_t part_row(int32_t t, int32_t n, int32_t part, int64_t V) {
+    int32_t r = (t / n) * n + part;
+    if (r >= V) r -= n;
+    return r;
+}
 
 template <int DCH> struct Row { float4 v[DCH]; };
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -411,7 +438,7 @@ __device__ __forceinline__ int32_t walk_tok(bool in_regs, const int32_t* sen, in
     return __shfl(v, idx & 15, 16);
 }
 
-template <int DCH, int POL, bool BIG, bool HS>
+template <int DCH, int POL, bool BIG, bool HS, bool PART>
 __global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HS ? DGE_HS_WAVES : 4) : 1)
 k_sgns_train(TrainParams p) {
     using P = Policy<POL>;
@@ -442,6 +469,11 @@ k_sgns_train(TrainParams p) {
     const int L = p.L, W = p.W, K = p.K;
     const bool toks_in_regs = L <= 64;
     unsigned long long my_pairs = 0, my_words = 0;
+    // PART (block schedule): only centres in partition part_tgt and contexts in partition part_ctx are visited — found
+    // through two bit masks over the walk's tokens, so a block costs what its own pairs cost.  Every pair draws from
+    // its own stream (seeded from the centre's stream and the context position): the draws of a pair do not depend on
+    // which other pairs of the centre this block trains.
+    uint64_t ctx_mask = 0, tgt_mask = 0, pair_mask = 0, s_centre = 0;
 
     // ---- per-worker state: walk w, centre i, next context c (contexts are c..c_hi without i)
     int64_t w = (HOT && worker >= p.n_workers) ? p.n_rows - p.n_workers : worker - p.n_workers;   // surplus workers find no walk
@@ -471,7 +503,7 @@ k_sgns_train(TrainParams p) {
         bool new_centre = false, alive = true;
         while (c > c_hi) {
             DGE_CLOSE_CENTRE();
-            i++;
+            if (PART) i = first_bit_from(tgt_mask, i + 1, len); else i++;
             while (i >= len) {                             // next walk of this worker (empty walks are skipped)
                 w += p.n_workers;
                 if (w >= p.n_rows) { alive = false; break; }
@@ -485,6 +517,11 @@ k_sgns_train(TrainParams p) {
                         tk1 = lane + 16 < L ? sen[lane + 16] : -1;
                         tk2 = lane + 32 < L ? sen[lane + 32] : -1;
                         tk3 = lane + 48 < L ? sen[lane + 48] : -1;
+                    }
+                    if (PART) {
+                        ctx_mask = part_token_mask(tk0, tk1, tk2, tk3, p.part_n, p.part_ctx);
+                        tgt_mask = part_token_mask(tk0, tk1, tk2, tk3, p.part_n, p.part_tgt);
+                        i = first_bit_from(tgt_mask, 0, len);
                     }
                     // learning rate from the exact number of in-vocabulary tokens that precede this walk
                     const int64_t wbw = p.wb[w];
@@ -505,10 +542,17 @@ k_sgns_train(TrainParams p) {
             if (c_hi == i) c_hi--;
             if (c == i) c++;
             new_centre = true;
+            if (PART) {
+                s_centre = s;
+                pair_mask = ctx_mask & ~(1ull << i) & (c < 64 ? (~0ull << c) : 0ull);
+                if (c_hi < 63) pair_mask &= (1ull << (c_hi + 1)) - 1ull;
+                c = first_bit_from(pair_mask, 0, c_hi + 1);
+            }
             if (HS) { hs_o = p.hs_off[word]; hs_n = (int)(p.hs_off[word + 1] - hs_o); hs_bits = p.hs_codes[word]; }
         }
         if (!alive) break;
         const int32_t last = DGE_TOK(c);
+        if (PART) s = dge_mix64(s_centre + (uint64_t)c);
 
         // ------------------------------------------------------------------ one pair: l1 = syn0[last], target rows in syn1neg
         Row<DCH> l1, neu;
@@ -573,6 +617,7 @@ k_sgns_train(TrainParams p) {
             if (lane < kc) {
                 t = p.table[(sl >> 16) % (uint64_t)p.T];
                 if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                if (PART) t = part_row(t, p.part_n, p.part_tgt, p.V);
                 if (t == word) t = -1;
             }
             s = shfl16_u64(sl, kc - 1);
@@ -626,8 +671,13 @@ k_sgns_train(TrainParams p) {
             row_store<DCH, P::STORE_AUX, BIG>(l1, syn0, last, lane);
         }
         my_pairs++;
-        c++;
-        if (c == i) c++;
+        if (PART) {
+            pair_mask &= pair_mask - 1ull;
+            c = first_bit_from(pair_mask, 0, c_hi + 1);
+        } else {
+            c++;
+            if (c == i) c++;
+        }
     }
     DGE_CLOSE_CENTRE();
 #undef DGE_TOK
@@ -758,7 +808,7 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
 
 #define LK_NEG_LANES 13      /* lanes 0..12 draw negatives, lane 13 = pending centre flush, lane 14 = the pair's syn0 row */
 // 3 waves per SIMD is the measured optimum for D <= 128: 4 (128 VGPRs) spills 88 B per lane and runs 20 % slower, 2 runs 12 % slower
-template <int DCH, bool STRICT, bool BIG, bool HOTMIX>
+template <int DCH, bool STRICT, bool BIG, bool HOTMIX, bool PART>
 __global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? 3 : ((HOTMIX && DCH <= 4) ? 2 : 1))
 k_sgns_train_locked(TrainParams p) {
     __shared__ float s_exp[EXP_TABLE_SIZE];
@@ -800,6 +850,7 @@ k_sgns_train_locked(TrainParams p) {
     bool retry_pair = false;      // the pair's syn0 row was busy: same pair again on the next trip through the loop
     int32_t t_first = -1;         // this lane's slot of the pair's first chunk (kept across a retry: the draw is not repeated)
     int32_t last = 0;
+    uint64_t ctx_mask = 0, tgt_mask = 0, pair_mask = 0, s_centre = 0;     // PART: see k_sgns_train
 
 #define LK_TOK(idx) walk_tok(toks_in_regs, sen, (idx), tk0, tk1, tk2, tk3)
 #define LK_CLOSE_CENTRE()                                                                                              \
@@ -816,7 +867,7 @@ k_sgns_train_locked(TrainParams p) {
         bool new_centre = false, alive = true;
         while (!retry_pair && c > c_hi) {
             LK_CLOSE_CENTRE();
-            i++;
+            if (PART) i = first_bit_from(tgt_mask, i + 1, len); else i++;
             while (i >= len) {
                 w += p.n_workers;
                 if (w >= p.n_rows) { alive = false; break; }
@@ -830,6 +881,11 @@ k_sgns_train_locked(TrainParams p) {
                         tk1 = lane + 16 < L ? sen[lane + 16] : -1;
                         tk2 = lane + 32 < L ? sen[lane + 32] : -1;
                         tk3 = lane + 48 < L ? sen[lane + 48] : -1;
+                    }
+                    if (PART) {
+                        ctx_mask = part_token_mask(tk0, tk1, tk2, tk3, p.part_n, p.part_ctx);
+                        tgt_mask = part_token_mask(tk0, tk1, tk2, tk3, p.part_n, p.part_tgt);
+                        i = first_bit_from(tgt_mask, 0, len);
                     }
                     const int64_t wbw = p.wb[w];
                     const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
@@ -848,9 +904,18 @@ k_sgns_train_locked(TrainParams p) {
             if (c_hi == i) c_hi--;
             if (c == i) c++;
             new_centre = true;
+            if (PART) {
+                s_centre = s;
+                pair_mask = ctx_mask & ~(1ull << i) & (c < 64 ? (~0ull << c) : 0ull);
+                if (c_hi < 63) pair_mask &= (1ull << (c_hi + 1)) - 1ull;
+                c = first_bit_from(pair_mask, 0, c_hi + 1);
+            }
         }
         if (!alive) break;
-        if (!retry_pair) last = LK_TOK(c);
+        if (!retry_pair) {
+            last = LK_TOK(c);
+            if (PART) s = dge_mix64(s_centre + (uint64_t)c);
+        }
 
         Row<DCH> l1, neu;
         if (new_centre) {
@@ -873,6 +938,7 @@ k_sgns_train_locked(TrainParams p) {
                 if (lane < kc) {
                     t = p.table[(sl >> 16) % (uint64_t)p.T];
                     if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                    if (PART) t = part_row(t, p.part_n, p.part_tgt, p.V);
                     if (t == word) t = -1;
                 }
                 if (kc > 0) s = shfl16_u64(sl, kc - 1);
@@ -997,8 +1063,13 @@ k_sgns_train_locked(TrainParams p) {
             if (lane == 14) row_unlock<STRICT>(locks0, last);
         }
         my_pairs++;
-        c++;
-        if (c == i) c++;
+        if (PART) {
+            pair_mask &= pair_mask - 1ull;
+            c = first_bit_from(pair_mask, 0, c_hi + 1);
+        } else {
+            c++;
+            if (c == i) c++;
+        }
     }
     LK_CLOSE_CENTRE();
     if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows);
@@ -1372,14 +1443,18 @@ static int ensure_work(dge_model* m, int64_t n_rows, int32_t L) {
 template <int DCH, bool BIG>
 static void launch_train_b(const TrainParams& p, int pol, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st) {
     switch (pol) {
-        case 0: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 10: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, true>), dim3(blocks), dim3(threads), 0, st, p); break;    // + hierarchical softmax
-        case 12: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, true>), dim3(blocks), dim3(threads), shmem, st, p); break;
-        case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 7: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true>), dim3(blocks), dim3(threads), 0, st, p); break;
-        default: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 0: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 10: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;    // + hierarchical softmax
+        case 12: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, true, false>), dim3(blocks), dim3(threads), shmem, st, p); break;
+        case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 7: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        // block schedule of the multi-GPU path (dge_model_set_partition): in-order, atomics, commit locks
+        case 20: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 22: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 25: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
+        default: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
     }
 }
 template <int DCH>
@@ -1412,7 +1487,10 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.locks = m->d_locks;
     p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
     p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0;
+    p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt;
+    const bool part = m->part_n > 1;
     const bool hs = m->cfg.use_hs != 0;
+    if (part && hs) DGE_FAIL(DGE_ERR_STATE, "the block schedule (dge_model_set_partition) cannot carry the hierarchical-softmax term: a Huffman path crosses every partition");
 
     int64_t workers;
     if (m->cfg.workers == 0) {
@@ -1447,6 +1525,26 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     }
     if (pol == 100 || (workers == 1 && pol != 5 && pol != 6 && pol != 7 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
     if (pol == 3) pol = 0;
+    if (part && L > 64) DGE_FAIL(DGE_ERR_ARG, "the block schedule keeps a walk's tokens in registers: walks of up to 64 tokens, not %d", L);
+    if (part) {
+        // One block of the multi-GPU schedule: the live rows are V/part_n per table, so lock attempts collide part_n times
+        // as often as on the whole table.  Measured on cfg3 (bench.py --sim-ranks): at 4 ranks the commit-lock kernel
+        // still beats atomics with the full 12 288 workers (5.4e8 vs 3.9e8 edges/s per rank); at 8 ranks it collapses
+        // there (1.9e8) but leads again with 6-8 k workers (4.0e8 vs 3.6e8) -> auto keeps the expected failure rate of a
+        // try at <= 0.37 by shrinking the worker count, and falls back to atomics when that leaves under 6 144 workers.
+        if (pol == 0) pol = 20;
+        else if (m->cfg.update_policy == 0) {
+            const double per_worker = 5.0 * m->neg_collision * (double)m->part_n;
+            const int64_t w_max = per_worker > 0 ? (int64_t)(0.37 / per_worker) / 256 * 256 : workers;
+            if (m->V >= 262144 && w_max >= 6144) {
+                pol = 25;
+                if (m->cfg.workers == 0 && w_max < workers) { workers = w_max; p.n_workers = workers; }
+            } else pol = 22;
+        }
+        else if (pol == 2) pol = 22;
+        else if (pol == 5) pol = 25;
+        else DGE_FAIL(DGE_ERR_ARG, "the block schedule runs under update_policy 0 (auto), 2, 3 or 5, not %d", m->cfg.update_policy);
+    }
     size_t shmem = 0;
     if (hs) {
         pol = pol == 0 ? 10 : 12;               // dge_model_create admitted policies 0/2/3 only
@@ -1480,7 +1578,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     DGE_HIP(hipEventRecord(ev.b, st));
     m->pending.push_back(ev);
     m->launches++;
-    m->last_policy = pol >= 10 ? pol - 10 : pol; m->last_workers = workers; m->last_hot_rows = p.hot_rows;
+    m->last_policy = pol >= 20 ? pol - 20 : (pol >= 10 ? pol - 10 : pol); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
     DGE_HIP(hipGetLastError());
     return DGE_OK;
 }
@@ -1669,6 +1767,59 @@ extern "C" int dge_write_vec(dge_model* m, const char* const* names, const char*
     if (fclose(f) != 0) DGE_FAIL(DGE_ERR_IO, "dge_write_vec: write to %s failed", path);
     return DGE_OK;
 }
+
+// ------------------------------------------------------------------------------------------ multi-GPU block schedule
+// N ranks, rows split by row % N.  In episode e rank g trains the block (contexts in partition g, centres and negatives
+// in partition (g+e) % N) of the SAME global batch of walks: the N blocks of an episode touch disjoint rows of both
+// tables, after N episodes every pair has been trained exactly once, and nothing is ever averaged or summed — the
+// result is the single-GPU result with the pairs in another order.  syn0 partition g never leaves rank g during
+// training; after each episode the ranks exchange the syn1neg partitions they just trained (an all-gather of packed rows).
+__global__ void k_partition_pack(const float* __restrict__ table, float* __restrict__ buf, int64_t V, int32_t stride, int32_t n, int32_t part, int64_t rows_padded) {
+    const int64_t total = rows_padded * stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / stride * n + part;
+        buf[i] = r < V ? table[r * stride + i % stride] : 0.f;
+    }
+}
+__global__ void k_partition_unpack(float* __restrict__ table, const float* __restrict__ buf, int64_t V, int32_t stride, int32_t n, int32_t part, int64_t rows_padded) {
+    const int64_t total = rows_padded * stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / stride * n + part;
+        if (r < V) table[r * stride + i % stride] = buf[i];
+    }
+}
+
+extern "C" int dge_model_set_partition(dge_model* m, int32_t n_parts, int32_t ctx_part, int32_t tgt_part) {
+    if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_set_partition: null model");
+    if (n_parts <= 1) { m->part_n = 1; m->part_ctx = 0; m->part_tgt = 0; return DGE_OK; }
+    if (ctx_part < 0 || ctx_part >= n_parts || tgt_part < 0 || tgt_part >= n_parts) DGE_FAIL(DGE_ERR_ARG, "dge_model_set_partition: partition out of range");
+    if (m->V < n_parts) DGE_FAIL(DGE_ERR_ARG, "dge_model_set_partition: %d partitions for %lld vocabulary rows", n_parts, (long long)m->V);
+    m->part_n = n_parts; m->part_ctx = ctx_part; m->part_tgt = tgt_part;
+    return DGE_OK;
+}
+
+extern "C" int dge_model_partition_floats(const dge_model* m, int32_t n_parts, int64_t* n_floats) {
+    if (!m || !n_floats || n_parts <= 0) DGE_FAIL(DGE_ERR_ARG, "dge_model_partition_floats: bad argument");
+    *n_floats = (m->V + n_parts - 1) / n_parts * (int64_t)m->stride;
+    return DGE_OK;
+}
+
+static int partition_copy(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf, bool pack) {
+    if (!m || !d_buf || n_parts <= 0 || part < 0 || part >= n_parts || (table != 0 && table != 1)) DGE_FAIL(DGE_ERR_ARG, "dge_model_%s_partition: bad argument", pack ? "export" : "import");
+    DGE_HIP(hipSetDevice(m->device));
+    if (!pack) DGE_HIP(hipDeviceSynchronize());          // d_buf comes from the caller's collective, on the caller's stream
+    float* tab = table == 0 ? m->d_syn0 : m->d_syn1neg;
+    const int64_t rows = (m->V + n_parts - 1) / n_parts;
+    if (rows > 0) {
+        if (pack) hipLaunchKernelGGL(k_partition_pack, dim3(2048), dim3(256), 0, m->stream, tab, d_buf, m->V, m->stride, n_parts, part, rows);
+        else hipLaunchKernelGGL(k_partition_unpack, dim3(2048), dim3(256), 0, m->stream, tab, d_buf, m->V, m->stride, n_parts, part, rows);
+    }
+    DGE_HIP(hipGetLastError());
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    return DGE_OK;
+}
+extern "C" int dge_model_export_partition(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf) { return partition_copy(m, table, n_parts, part, d_buf, true); }
+extern "C" int dge_model_import_partition(dge_model* m, int table, int32_t n_parts, int32_t part, const float* d_buf) { return partition_copy(m, table, n_parts, part, const_cast<float*>(d_buf), false); }
 
 // ------------------------------------------------------------------------------------------ multi-GPU exchange
 extern "C" int dge_model_sync_size(const dge_model* m, int64_t* n_floats) {

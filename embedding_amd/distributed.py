@@ -1,10 +1,20 @@
 """Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
 
-The path shards by walk index with NO data-path collective: every rank owns a contiguous range of the epoch's walk
-indices (the strided RNG makes walk i the same walk on any rank).  The only exchanges are
-  * once, before training: the token counts of the shards are summed so that every rank builds the same vocabulary;
-  * at epoch (or step) boundaries: delta = tables - snapshot is summed over ranks and applied with scale 1/N.
-The reference is single-host; this layer is new.
+Walk SAMPLING shards by walk index with no collective: the strided RNG makes walk i the same walk on any rank, so any
+rank can produce any range of an epoch's walks from its replica of the graph.  Token counts are summed once so that
+every rank builds the same vocabulary.
+
+TRAINING uses the block schedule (`block_schedule_step`): vocabulary rows are split by row % N; in episode e rank g
+trains, over the SAME global batch of walks, the pairs whose context row is in partition g and whose centre row is in
+partition (g+e) % N, with negatives moved into that partition.  The N blocks of an episode are row-disjoint in both
+tables and after N episodes every pair was trained exactly once: the result is the single-GPU result with the pairs in
+another order — nothing is averaged.  Between episodes the ranks all-gather the syn1neg partitions they just trained
+(V/N rows each); syn0 partitions stay home until `gather_table`.
+
+The earlier scheme — every rank trains its own walk shard from a snapshot, deltas are all-reduced and applied with 1/N
+(`exchange_deltas`) — is kept for comparison only: measured (scripts/quality_exchange.py, profiles/r01_quality_exchange.txt)
+it under-trains by the factor N (each row moves 1/N as far per epoch; AUC 0.97 -> 0.91 at N=4, 0.48 at N=8), and summing
+instead of averaging overshoots (AUC 0.53 at N=4).  The reference is single-host; this layer is new.
 """
 
 
@@ -46,3 +56,55 @@ def exchange_deltas(model, buf, world, dist_mod=None):
         d.all_reduce(buf)
         _wait_device(buf)              # the collective runs on torch's stream; libdge reads buf on its own stream
     model.import_delta(buf, 1.0 / world)
+
+
+def block_schedule_step(model, train_fn, world, rank, part_buf=None, gather_buf=None, dist_mod=None):
+    """One global batch under the block schedule.  `train_fn()` trains the batch on `model` (it is called once per
+    episode, with the model's partition filter set); `model` needs set_partition / export_partition / import_partition /
+    partition_floats (embedding_amd.SgnsModel).  `part_buf` [partition_floats] and `gather_buf` [world * partition_floats]
+    are float32 tensors on the model's device (allocated here when not given).  Returns the buffers for reuse."""
+    if world <= 1:
+        model.set_partition(1)
+        train_fn()
+        return part_buf, gather_buf
+    import torch
+    import torch.distributed as dist
+    d = dist_mod or dist
+    pf = model.partition_floats(world)
+    if part_buf is None or gather_buf is None:
+        dev = getattr(model, "torch_device", None) or "cpu"
+        part_buf = torch.empty(pf, dtype=torch.float32, device=dev)
+        gather_buf = torch.empty(pf * world, dtype=torch.float32, device=dev)
+    for e in range(world):
+        tgt = (rank + e) % world
+        model.set_partition(world, rank, tgt)
+        train_fn()
+        # every rank publishes the syn1neg partition it just trained; rank r trained partition (r + e) % world
+        model.export_partition(1, world, tgt, part_buf)
+        d.all_gather_into_tensor(gather_buf, part_buf)
+        _wait_device(gather_buf)
+        for r in range(world):
+            if r != rank:
+                model.import_partition(1, world, (r + e) % world, gather_buf[r * pf:(r + 1) * pf])
+    model.set_partition(1)
+    return part_buf, gather_buf
+
+
+def gather_table(model, table, world, rank, part_buf=None, gather_buf=None, dist_mod=None):
+    """After training: every rank owns partition `rank` of `table` (0 = syn0); collect the others."""
+    if world <= 1:
+        return
+    import torch
+    import torch.distributed as dist
+    d = dist_mod or dist
+    pf = model.partition_floats(world)
+    if part_buf is None or gather_buf is None:
+        dev = getattr(model, "torch_device", None) or "cpu"
+        part_buf = torch.empty(pf, dtype=torch.float32, device=dev)
+        gather_buf = torch.empty(pf * world, dtype=torch.float32, device=dev)
+    model.export_partition(table, world, rank, part_buf)
+    d.all_gather_into_tensor(gather_buf, part_buf)
+    _wait_device(gather_buf)
+    for r in range(world):
+        if r != rank:
+            model.import_partition(table, world, r, gather_buf[r * pf:(r + 1) * pf])

@@ -167,6 +167,7 @@ class SgnsModel:
         self._h = handle
         self.device = device
         self.cfg = cfg
+        self.torch_device = "cuda:%d" % int(device)
 
     @classmethod
     def create(cls, cfg, d_counts, device=0):
@@ -283,6 +284,19 @@ class SgnsModel:
         pol, w, hot = C.c_int32(0), C.c_int64(0), C.c_int32(0)
         check(lib.dge_model_schedule(self._h, C.byref(pol), C.byref(w), C.byref(hot)))
         return {"update_policy": pol.value, "workers": w.value, "hot_rows": hot.value}
+
+    # ---- multi-GPU block schedule (include/dge.h: dge_model_set_partition)
+    def set_partition(self, n_parts, ctx_part=0, tgt_part=0):
+        check(lib.dge_model_set_partition(self._h, int(n_parts), int(ctx_part), int(tgt_part)))
+
+    def partition_floats(self, n_parts):
+        n = C.c_int64(0); check(lib.dge_model_partition_floats(self._h, int(n_parts), C.byref(n))); return n.value
+
+    def export_partition(self, table, n_parts, part, d_buf):
+        check(lib.dge_model_export_partition(self._h, int(table), int(n_parts), int(part), _dev_ptr(d_buf)))
+
+    def import_partition(self, table, n_parts, part, d_buf):
+        check(lib.dge_model_import_partition(self._h, int(table), int(n_parts), int(part), _dev_ptr(d_buf)))
 
     def sync_size(self):
         n = C.c_int64(0); check(lib.dge_model_sync_size(self._h, C.byref(n))); return n.value

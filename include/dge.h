@@ -205,6 +205,22 @@ int  dge_write_vec(dge_model* m, const char* const* names, const char* path, int
 void dge_model_free(dge_model* m);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multi-GPU block schedule (new; the reference is single-host).  Rows are split by row % n_parts.  With
+ * a partition set, dge_model_train / dge_model_walk_and_train only train the pairs whose context row
+ * (syn0) lies in ctx_part and whose centre row (syn1neg) lies in tgt_part, and move each drawn negative
+ * to the row of tgt_part nearest below it (rows are ordered by count: the frequency rank is kept).  Rank g of
+ * N runs episodes e = 0..N-1 with (ctx_part, tgt_part) = (g, (g+e) % N) over the same global batch of
+ * walks: the blocks of one episode are row-disjoint, after N episodes every pair was trained once.
+ * Between episodes the ranks exchange the syn1neg partitions they trained (export -> all-gather ->
+ * import); syn0 partitions are gathered once at the end.  n_parts <= 1 switches the filter off. */
+int  dge_model_set_partition(dge_model* m, int32_t n_parts, int32_t ctx_part, int32_t tgt_part);
+/* floats of one packed partition buffer: ceil(V / n_parts) rows x row stride (same for every partition) */
+int  dge_model_partition_floats(const dge_model* m, int32_t n_parts, int64_t* n_floats);
+/* table: 0 = syn0, 1 = syn1neg; d_buf is device memory of dge_model_partition_floats floats */
+int  dge_model_export_partition(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf);
+int  dge_model_import_partition(dge_model* m, int table, int32_t n_parts, int32_t part, const float* d_buf);
+
+/* ------------------------------------------------------------------------------------------------
  * Multi-GPU exchange at epoch boundaries (new; the reference is single-host).  Each rank trains its
  * walk shard from a common snapshot; delta = current - snapshot is summed across ranks (RCCL
  * all-reduce on the caller's communicator, e.g. torch.distributed) and applied with a scale.

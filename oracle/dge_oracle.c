@@ -527,22 +527,29 @@ int orc_huffman(const int64_t* counts, int64_t V, int32_t* codelen, int32_t* poi
 }
 
 static int64_t train_walk(const orc_train_config* cfg, orc_model* m, const int32_t* sen, int len,
-                          int64_t gidx_base, float alpha, float* neu1e) {
+                          int64_t gidx_base, float alpha, float* neu1e, int part_ctx, int part_tgt) {
     const int D = cfg->dim, W = cfg->window, K = cfg->negative;
     const int64_t V = m->V, T = m->table_size;
+    const int PN = cfg->part_n > 1 ? cfg->part_n : 1;
     int64_t pairs = 0;
     for (int i = 0; i < len; i++) {
         int32_t word = sen[i];
         if (word < 0) continue;
+        if (PN > 1 && word % PN != part_tgt) continue;       /* another block's centre */
         uint64_t s = orc_mix64(cfg->seed + (uint64_t)(gidx_base + i));
         s = s * W2V_MULT + 11;
         int b = (int)(s % (uint64_t)W);
+        const uint64_t s_centre = s;
         for (int a = b; a < W * 2 + 1 - b; a++) {
             if (a == W) continue;
             int c = i - W + a;
             if (c < 0 || c >= len) continue;
             int32_t last = sen[c];
             if (last < 0) continue;
+            if (PN > 1) {                                      /* block schedule: every pair draws from its own stream */
+                if (last % PN != part_ctx) continue;           /* another block's context */
+                s = orc_mix64(s_centre + (uint64_t)c);
+            }
             float* l1 = m->syn0 + (int64_t)last * D;
             for (int k = 0; k < D; k++) neu1e[k] = 0;
             if (cfg->use_hs)                       /* word2vec.c: HIERARCHICAL SOFTMAX, before the negative sampling */
@@ -568,6 +575,7 @@ static int64_t train_walk(const orc_train_config* cfg, orc_model* m, const int32
                     s = s * W2V_MULT + 11;
                     target = m->table[(s >> 16) % (uint64_t)T];
                     if (target == 0 && V > 1) target = (int64_t)(s % (uint64_t)(V - 1)) + 1;
+                    if (PN > 1) { target = target / PN * PN + part_tgt; if (target >= V) target -= PN; }
                     if (target == word) continue;
                     label = 0;
                 }
@@ -681,8 +689,11 @@ int orc_train_sgns(const int32_t* walks, int64_t n_walks, int32_t max_len,
     const int64_t all_words = (int64_t)cfg->epochs * m->total_words;
     int64_t pairs = 0;
     double t0 = now_s();
+    const int PN = cfg->part_n > 1 ? cfg->part_n : 1;
     if (V > 0)
-    for (int ep = 0; ep < cfg->epochs; ep++) {
+    for (int ep = 0; ep < cfg->epochs; ep++)
+    for (int blk = 0; blk < PN * PN; blk++) {
+        const int part_ctx = blk % PN, part_tgt = (blk % PN + blk / PN) % PN;     /* episode blk / PN, rank blk % PN */
         int nt = cfg->threads > 1 ? cfg->threads : 1;
 #ifdef _OPENMP
 #pragma omp parallel num_threads(nt) reduction(+ : pairs)
@@ -701,7 +712,7 @@ int orc_train_sgns(const int32_t* walks, int64_t n_walks, int32_t max_len,
                 int64_t done = (int64_t)ep * m->total_words + cfg->words_before + wb[w];
                 float alpha = alpha_for(cfg, done, all_words);
                 int64_t gbase = (((int64_t)ep * total_walks) + cfg->walk_index_base + w) * (int64_t)max_len;
-                pairs += train_walk(cfg, m, buf, len, gbase, alpha, neu1e);
+                pairs += train_walk(cfg, m, buf, len, gbase, alpha, neu1e, part_ctx, part_tgt);
             }
             free(neu1e);
         }

@@ -74,7 +74,9 @@ typedef struct orc_train_config {
     int64_t words_before;    /* in-vocab tokens of walks before walk_index_base */
     int32_t use_hs;          /* hierarchical-softmax term as well (DL4J's default when the builder does not disable it,
                                 J/DeepWalk.java:73-76; word2vec.c -hs 1): Huffman codes over the counts, table syn1 */
-    int32_t reserved;
+    int32_t part_n;          /* > 1: the multi-GPU block schedule (include/dge.h, dge_model_set_partition) run sequentially —
+                                per epoch, episodes e = 0..N-1, ranks g = 0..N-1: the block (contexts in partition g,
+                                centres and negatives in partition (g+e) % N) over all walks */
 } orc_train_config;
 
 typedef struct orc_model orc_model;

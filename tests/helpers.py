@@ -44,3 +44,37 @@ def cosine_rows(a, b):
     num = (a.astype(np.float64) * b.astype(np.float64)).sum(1)
     den = np.linalg.norm(a.astype(np.float64), axis=1) * np.linalg.norm(b.astype(np.float64), axis=1)
     return num / np.maximum(den, 1e-300)
+
+
+def simulate_block_schedule(models, train_fn):
+    """The multi-GPU block schedule (embedding_amd/distributed.py: block_schedule_step) with all ranks on ONE device:
+    models[g] plays rank g; the all-gather between episodes becomes direct export/import between the models."""
+    import torch
+    N = len(models)
+    pf = models[0].partition_floats(N)
+    bufs = [torch.empty(pf, dtype=torch.float32, device=models[0].torch_device) for _ in range(N)]
+    for e in range(N):
+        for g, m in enumerate(models):
+            m.set_partition(N, g, (g + e) % N)
+            train_fn(m)
+        for g, m in enumerate(models):
+            m.export_partition(1, N, (g + e) % N, bufs[g])
+        for g, m in enumerate(models):
+            for r in range(N):
+                if r != g:
+                    m.import_partition(1, N, (r + e) % N, bufs[r])
+    for g, m in enumerate(models):
+        m.set_partition(1)
+
+
+def simulate_gather_syn0(models):
+    import torch
+    N = len(models)
+    pf = models[0].partition_floats(N)
+    bufs = [torch.empty(pf, dtype=torch.float32, device=models[0].torch_device) for _ in range(N)]
+    for g, m in enumerate(models):
+        m.export_partition(0, N, g, bufs[g])
+    for g, m in enumerate(models):
+        for r in range(N):
+            if r != g:
+                m.import_partition(0, N, r, bufs[r])

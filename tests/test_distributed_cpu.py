@@ -24,6 +24,77 @@ class FakeModel:
         self.snap = self.cur.copy()
 
 
+class FakeBlockModel:
+    """numpy stand-in for the block schedule: 'training' a block adds 1 to every syn0 row of the context partition and to
+    every syn1neg row of the target partition, and records the block — a row touched by two ranks in one episode, or a
+    block trained twice, shows up as a count != the expected one."""
+
+    def __init__(self, V, stride):
+        self.V, self.stride = V, stride
+        self.tab = [np.zeros((V, stride), np.float32), np.zeros((V, stride), np.float32)]
+        self.part = (1, 0, 0)
+        self.blocks = []
+
+    def set_partition(self, n, ctx=0, tgt=0):
+        self.part = (n, ctx, tgt)
+
+    def partition_floats(self, n):
+        return (self.V + n - 1) // n * self.stride
+
+    def train(self):
+        n, ctx, tgt = self.part
+        self.blocks.append((ctx, tgt))
+        self.tab[0][ctx::n] += 1
+        self.tab[1][tgt::n] += 1
+
+    def export_partition(self, table, n, part, buf):
+        rows = self.tab[table][part::n]
+        out = np.zeros(((self.V + n - 1) // n, self.stride), np.float32); out[:len(rows)] = rows
+        buf.copy_(__import__("torch").from_numpy(out.reshape(-1)))
+
+    def import_partition(self, table, n, part, buf):
+        rows = len(self.tab[table][part::n])
+        self.tab[table][part::n] = buf.numpy().reshape(-1, self.stride)[:rows]
+
+
+def _block_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from embedding_amd.distributed import block_schedule_step, gather_table
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = FakeBlockModel(11, 4)                      # 11 rows: partitions of unequal size (padding in the packed buffers)
+    bufs = (None, None)
+    for _ in range(2):                             # two global batches
+        bufs = block_schedule_step(m, m.train, world, rank, *bufs)
+    gather_table(m, 0, world, rank)
+    np.savez(os.path.join(out_dir, "b%d.npz" % rank), syn0=m.tab[0], syn1neg=m.tab[1], blocks=np.array(m.blocks), part=np.array(m.part))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_block_schedule_gloo(tmp_path, world):
+    """Every (context partition, centre partition) block is trained exactly once per batch, by exactly one rank; the blocks
+    of one episode are row-disjoint; all ranks end with identical tables."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_block_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(str(tmp_path / ("b%d.npz" % i))) for i in range(world)]
+    seen = []
+    for i in range(world):
+        blocks = [tuple(b) for b in r[i]["blocks"]]
+        assert len(blocks) == 2 * world and all(b[0] == i for b in blocks)          # a rank only ever trains its own syn0 partition
+        seen += blocks[:world]
+        assert tuple(r[i]["part"]) == (1, 0, 0)                                      # the filter is switched off afterwards
+    assert sorted(seen) == [(a, b) for a in range(world) for b in range(world)]
+    for e in range(world):                                                            # one episode: target partitions are all different
+        assert sorted(tuple(r[i]["blocks"][e])[1] for i in range(world)) == list(range(world))
+    # each syn1neg row was trained `world` times per batch (once per context partition), each syn0 row likewise
+    for i in range(world):
+        assert np.array_equal(r[i]["syn1neg"], np.full((11, 4), 2.0 * world, np.float32))
+        assert np.array_equal(r[i]["syn0"], np.full((11, 4), 2.0 * world, np.float32))
+
+
 def _worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist

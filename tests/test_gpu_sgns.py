@@ -519,3 +519,62 @@ def test_hierarchical_softmax_lds_combining_conserves_updates(dge, oracle, monke
         # the sign of f ~ 0, shows there — hence the wider bound when the root is never refreshed during the run)
         assert cosine_rows(a[busy], b[busy]).min() > 0.998, drain
         assert np.abs(na[busy] / nb[busy] - 1).max() < tol, drain
+
+
+# ------------------------------------------------------------------------------------------ multi-GPU block schedule
+@pytest.mark.parametrize("n_ranks,dim,negative", [(2, 32, 5), (3, 64, 5), (4, 20, 3), (2, 128, 20)])
+def test_block_schedule_bit_exact_with_oracle(dge, oracle, n_ranks, dim, negative):
+    """N ranks (N models on this one GPU), in-order workers: after the N episodes and the partition exchanges every rank
+    holds exactly the tables the oracle produces when it runs the same N*N blocks one after the other — the blocks of an
+    episode are row-disjoint, so running them on N devices at once changes nothing.  Every pair is trained exactly once."""
+    import torch
+    from helpers import simulate_block_schedule, simulate_gather_syn0
+    walks, NV = _walks(oracle, dge, n=400 if dim >= 128 else 800)
+    om = oracle.train_sgns(walks, NV, dim, 6, negative=negative, table_size=20011, arith=1, part_n=n_ranks)
+    o1 = oracle.train_sgns(walks, NV, dim, 6, negative=negative, table_size=20011, arith=1)
+    assert om.pairs == o1.pairs
+    corpus = dge.WalkCorpus.from_host(walks, 0)
+    counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0")
+    corpus.count_tokens(NV, counts)
+    cfg = dge.make_config(dim, 6, NV, negative=negative, workers=1, table_size=20011)
+    ms = [dge.SgnsModel.create(cfg, counts, 0) for _ in range(n_ranks)]
+    simulate_block_schedule(ms, lambda m: m.train(corpus))
+    simulate_gather_syn0(ms)
+    assert sum(m.stats()["pairs"] for m in ms) == om.pairs
+    for m in ms:
+        assert np.array_equal(bits(m.vectors()[0]), bits(om.syn0))
+        assert np.array_equal(bits(m.syn1neg()), bits(om.syn1neg))
+    # and the block order costs nothing statistically: as close to the plain sequential run as another pair order is
+    assert float(np.median(cosine_rows(ms[0].vectors()[0], o1.syn0))) > 0.8
+
+
+def test_block_schedule_hogwild_policies(dge, oracle):
+    """Device-filling workers inside each block, atomics (auto at this size) and commit locks: same pair count, vectors
+    within Hogwild noise of the oracle's sequential block run.  Policies that cannot run a block are refused."""
+    import torch
+    from helpers import simulate_block_schedule, simulate_gather_syn0
+    walks, NV = _walks(oracle, dge, R=400, T=6, n=30000)
+    om = oracle.train_sgns(walks, NV, 32, 6, table_size=20011, arith=1, part_n=2)
+    corpus = dge.WalkCorpus.from_host(walks, 0)
+    counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0")
+    corpus.count_tokens(NV, counts)
+    for pol, workers, tol in ((0, 0, 0.9), (2, 64, 0.99), (5, 64, 0.99)):
+        cfg = dge.make_config(32, 6, NV, workers=workers, table_size=20011, update_policy=pol)
+        ms = [dge.SgnsModel.create(cfg, counts, 0) for _ in range(2)]
+        simulate_block_schedule(ms, lambda m: m.train(corpus))
+        simulate_gather_syn0(ms)
+        assert sum(m.stats()["pairs"] for m in ms) == om.pairs
+        assert np.array_equal(bits(ms[0].vectors()[0]), bits(ms[1].vectors()[0]))
+        assert float(np.median(cosine_rows(ms[0].vectors()[0], om.syn0))) > tol, pol
+        assert ms[0].schedule()["update_policy"] == (2 if pol == 0 else pol)
+    for bad in (1, 6, 7):
+        m = dge.SgnsModel.create(dge.make_config(32, 6, NV, workers=64, table_size=20011, update_policy=bad), counts, 0)
+        m.set_partition(2, 0, 1)
+        with pytest.raises(dge.DgeError):
+            m.train(corpus)
+    m = dge.SgnsModel.create(dge.make_config(32, 6, NV, table_size=20011, use_hs=True), counts, 0)
+    m.set_partition(2, 0, 1)
+    with pytest.raises(dge.DgeError):
+        m.train(corpus)
+    with pytest.raises(dge.DgeError):
+        m.set_partition(2, 2, 0)
