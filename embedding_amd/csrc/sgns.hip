@@ -1887,6 +1887,7 @@ struct RcclApi {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, dge_unique_id, int) = nullptr;     // ncclUniqueId is a 128-byte struct passed by value
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -1900,9 +1901,10 @@ int rccl_load() {
     g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(void**, int, dge_unique_id, int))dlsym(h, "ncclCommInitRank");
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) DGE_FAIL(DGE_ERR_DEVICE, "librccl lacks an expected symbol");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy) DGE_FAIL(DGE_ERR_DEVICE, "librccl lacks an expected symbol");
     g_rccl.lib = h;
     return DGE_OK;
 }
@@ -1956,3 +1958,25 @@ extern "C" int dge_model_allreduce_deltas(dge_model* m, dge_comm* c) {
     DGE_HIP(hipStreamSynchronize(m->stream));
     return dge_model_import_delta(m, c->d_buf, 1.0f / (float)c->nranks);
 }
+
+// block schedule, the exchange after episode `episode` (or, with table 0 and episode 0, the final gather of syn0): rank g
+// publishes partition (g + episode) % nranks of `table` and takes the partitions the other ranks publish
+extern "C" int dge_model_exchange_partitions(dge_model* m, dge_comm* c, int table, int32_t episode) {
+    if (!m || !c || (table != 0 && table != 1) || episode < 0) DGE_FAIL(DGE_ERR_ARG, "dge_model_exchange_partitions: bad argument");
+    if (c->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_exchange_partitions: communicator and model live on different devices");
+    DGE_HIP(hipSetDevice(m->device));
+    int64_t pf = 0;
+    int rc = dge_model_partition_floats(m, c->nranks, &pf);
+    if (rc) return rc;
+    const int64_t need = pf * ((int64_t)c->nranks + 1);
+    if (c->buf_floats < need) { dge_dev_free(c->d_buf); c->d_buf = nullptr; if ((rc = dge_dev_alloc(&c->d_buf, (size_t)need + 64))) return rc; c->buf_floats = need; }
+    float* mine = c->d_buf; float* all = c->d_buf + pf;
+    if ((rc = dge_model_export_partition(m, table, c->nranks, (c->rank + episode) % c->nranks, mine))) return rc;
+    int n = g_rccl.AllGather(mine, all, (size_t)pf, /*ncclFloat32*/ 7, c->nccl, m->stream);
+    if (n) return rccl_fail(n, "ncclAllGather");
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    for (int r = 0; r < c->nranks; r++)
+        if (r != c->rank && (rc = dge_model_import_partition(m, table, c->nranks, (r + episode) % c->nranks, all + (int64_t)r * pf))) return rc;
+    return DGE_OK;
+}
+

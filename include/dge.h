@@ -239,7 +239,10 @@ typedef struct dge_unique_id { char bytes[128]; } dge_unique_id;          /* = n
 int  dge_comm_unique_id(dge_unique_id* out);
 int  dge_comm_create(dge_comm** out, const dge_unique_id* id, int rank, int nranks, int device);
 void dge_comm_free(dge_comm* c);
-int  dge_model_allreduce_deltas(dge_model* m, dge_comm* c);                /* needs dge_model_snapshot before the shard */
+int  dge_model_allreduce_deltas(dge_model* m, dge_comm* c);
+/* block schedule with RCCL called from the library: after episode `episode` rank g publishes partition
+ * (g + episode) % nranks of `table` (1 = syn1neg) and imports the other ranks'; table 0, episode 0 = final gather of syn0 */
+int  dge_model_exchange_partitions(dge_model* m, dge_comm* c, int table, int32_t episode);                /* needs dge_model_snapshot before the shard */
 
 /* ------------------------------------------------------------------------------------------------
  * Quality metric ("next" row of the scope table): pairwiseEstimator of P/embeddingEvaluation_tract.py:169-196 — for every
