@@ -510,7 +510,7 @@ k_sgns_train(TrainParams p) {
                 len = (int)p.len[w];
                 i = 0;
                 if (len > 0) {
-                    my_words += (unsigned long long)len;
+                    if (!PART || p.part_ctx == p.part_tgt) my_words += (unsigned long long)len;      // (block schedule: once per batch, in episode 0)
                     sen = p.sen + w * L;
                     if (toks_in_regs) {
                         tk0 = lane < L ? sen[lane] : -1;
@@ -874,7 +874,7 @@ k_sgns_train_locked(TrainParams p) {
                 len = (int)p.len[w];
                 i = 0;
                 if (len > 0) {
-                    my_words += (unsigned long long)len;
+                    if (!PART || p.part_ctx == p.part_tgt) my_words += (unsigned long long)len;      // (block schedule: once per batch, in episode 0)
                     sen = p.sen + w * L;
                     if (toks_in_regs) {
                         tk0 = lane < L ? sen[lane] : -1;

@@ -108,3 +108,40 @@ def gather_table(model, table, world, rank, part_buf=None, gather_buf=None, dist
     for r in range(world):
         if r != rank:
             model.import_partition(table, world, r, gather_buf[r * pf:(r + 1) * pf])
+
+
+def fit_distributed(graph, n_walks, walk_len, cfg, world, rank, walk_seed, batch_walks=None, device=None, dist_mod=None):
+    """w2v.fit() (J/DeepWalk.java:79) on `world` GPUs: vocabulary from the whole epoch corpus, then cfg.epochs passes of the
+    block schedule over batches of `batch_walks` walks.  `graph` is this rank's replica (DeviceGraph with alias tables built);
+    walks are sampled with the strided RNG, so walk i is the same on every rank and for every world size.  Returns the
+    SgnsModel with complete tables on every rank."""
+    import torch
+    from .engine import SgnsModel
+    dev = graph.device if device is None else device
+    tdev = "cuda:%d" % int(dev)
+    # vocabulary: every rank counts a contiguous share of the epoch's walks, the counts are summed
+    lo, hi = n_walks * rank // world, n_walks * (rank + 1) // world
+    counts = torch.zeros(cfg.n_vertices, dtype=torch.int64, device=tdev)
+    if hi > lo:
+        share = graph.sample_walks_device(hi - lo, walk_len, seed=walk_seed, rng_mode=1, first_index=lo)
+        share.count_tokens(cfg.n_vertices, counts)
+        share.close()
+    allreduce_counts(counts, dist_mod)
+    model = SgnsModel.create(cfg, counts, dev)
+    nb = int(batch_walks or max(1, n_walks // 10))
+    corpus = graph.sample_walks_device(min(nb, n_walks), walk_len, seed=walk_seed, rng_mode=1, first_index=0)
+    bufs = (None, None)
+    for ep in range(cfg.epochs):
+        words_before = 0
+        for b0 in range(0, n_walks, nb):
+            n = min(nb, n_walks - b0)
+            if b0 or ep:
+                graph.sample_walks_into(corpus, 0, n, walk_seed, b0)
+            model.reset_stats()
+            bufs = block_schedule_step(model, lambda: model.train(corpus, 0, n, walk_index_base=b0, epoch=ep, words_before=words_before,
+                                                                  total_walks=n_walks), world, rank, *bufs, dist_mod=dist_mod)
+            words_before += model.stats()["words"]
+    gather_table(model, 0, world, rank, *bufs, dist_mod=dist_mod)
+    corpus.close()
+    return model
+

@@ -1,0 +1,81 @@
+"""GPU: the multi-rank pipeline of embedding_amd/distributed.py end to end — two processes over gloo sharing this one
+GPU (torch.distributed all-reduce / all-gather on device tensors, the C-ABI partition export/import, the block schedule).
+Real multi-GPU runs use the same code with backend nccl (= RCCL over xGMI); reference call site: J/DeepWalk.java:79."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import bits, cosine_rows, layered_graph
+
+pytestmark = pytest.mark.gpu
+
+R, T, N_WALKS, DIM = 40, 6, 1200, 32
+
+
+def _graph(dge):
+    src, dst, w, sources = layered_graph(R=R, T=T, deg=5, seed=0)
+    g = dge.DeviceGraph(0)
+    g.add_edges(src, dst, w); g.set_sources(sources); g.build_alias(True)
+    return g
+
+
+def _rank(rank, world, port, out_dir, batch_walks, workers):
+    import torch.distributed as dist
+    import embedding_amd as dge
+    from embedding_amd.distributed import fit_distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = _graph(dge)
+    cfg = dge.make_config(DIM, T, R * T, workers=workers, table_size=20011)
+    m = fit_distributed(g, N_WALKS, T, cfg, world, rank, walk_seed=11, batch_walks=batch_walks)
+    syn0, vid = m.vectors()
+    np.savez(os.path.join(out_dir, "d%d.npz" % rank), syn0=syn0, syn1neg=m.syn1neg(), vid=vid, pairs=m.stats()["pairs"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(tmp_path, batch_walks, workers):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rank, args=(2, port, str(tmp_path), batch_walks, workers), nprocs=2, join=True)
+    return [np.load(str(tmp_path / ("d%d.npz" % i))) for i in range(2)]
+
+
+def test_two_rank_fit_is_the_oracles_block_run(dge, oracle, tmp_path):
+    """One batch = the whole epoch, in-order workers: both ranks end bit-identical to the oracle's sequential run of the 2x2 blocks."""
+    r = _run(tmp_path, N_WALKS, 1)
+    walks = _graph(dge).sample_walks(N_WALKS, T, seed=11, rng_mode=1)
+    om = oracle.train_sgns(walks, R * T, DIM, T, table_size=20011, arith=1, part_n=2)
+    for d in r:
+        assert np.array_equal(d["vid"], om.vocab_ids)
+        assert np.array_equal(bits(d["syn0"]), bits(om.syn0)) and np.array_equal(bits(d["syn1neg"]), bits(om.syn1neg))
+
+
+def test_two_rank_fit_in_batches_matches_one_process(dge, oracle, tmp_path):
+    """Several batches per epoch (exact learning-rate bookkeeping across batches): the two processes reproduce, bit for bit,
+    the same schedule run with two models inside one process; device-filling workers stay within Hogwild noise of it."""
+    import torch
+    from helpers import simulate_block_schedule, simulate_gather_syn0
+    g = _graph(dge)
+    cfg = dge.make_config(DIM, T, R * T, workers=1, table_size=20011)
+    corpus = g.sample_walks_device(N_WALKS, T, seed=11, rng_mode=1)
+    counts = torch.zeros(R * T, dtype=torch.int64, device="cuda:0"); corpus.count_tokens(R * T, counts)
+    ms = [dge.SgnsModel.create(cfg, counts, 0) for _ in range(2)]
+    nb, wb = 500, 0
+    for b0 in range(0, N_WALKS, nb):
+        n = min(nb, N_WALKS - b0)
+        for m in ms:
+            m.reset_stats()
+        simulate_block_schedule(ms, lambda m: m.train(corpus, b0, n, walk_index_base=b0, words_before=wb, total_walks=N_WALKS))
+        wb += ms[0].stats()["words"]
+    simulate_gather_syn0(ms)
+    want0, want1 = ms[0].vectors()[0], ms[0].syn1neg()
+    r = _run(tmp_path, nb, 1)
+    for d in r:
+        assert np.array_equal(bits(d["syn0"]), bits(want0)) and np.array_equal(bits(d["syn1neg"]), bits(want1))
+    (tmp_path / "hog").mkdir()
+    h = _run(tmp_path / "hog", nb, 64)
+    assert np.array_equal(bits(h[0]["syn0"]), bits(h[1]["syn0"]))
+    assert float(np.median(cosine_rows(h[0]["syn0"], want0))) > 0.99
