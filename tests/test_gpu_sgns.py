@@ -571,6 +571,15 @@ def test_block_schedule_hogwild_policies(dge, oracle):
         assert np.array_equal(bits(ms[0].vectors()[0]), bits(ms[1].vectors()[0]))
         assert float(np.median(cosine_rows(ms[0].vectors()[0], om.syn0))) > tol, pol
         assert ms[0].schedule()["update_policy"] == (2 if pol == 0 else pol)
+    # a 4-row vocabulary in 2 partitions (2 live rows per table and block), 16 lock-taking workers: terminates, trains every pair
+    tiny = np.array([[0, 1, 2, 3, 1, 0]] * 64 + [[3, 2, 1, 0, 2, 3]] * 64, np.int32)
+    tc = dge.WalkCorpus.from_host(tiny, 0)
+    tcounts = torch.zeros(4, dtype=torch.int64, device="cuda:0"); tc.count_tokens(4, tcounts)
+    ot = oracle.train_sgns(tiny, 4, 8, 6, min_count=1, table_size=101, arith=1, part_n=2)
+    for pol in (2, 5):
+        ms = [dge.SgnsModel.create(dge.make_config(8, 6, 4, min_count=1, workers=16, table_size=101, update_policy=pol), tcounts, 0) for _ in range(2)]
+        simulate_block_schedule(ms, lambda m: m.train(tc))
+        assert sum(m.stats()["pairs"] for m in ms) == ot.pairs and np.isfinite(ms[0].syn1neg()).all()
     for bad in (1, 6, 7):
         m = dge.SgnsModel.create(dge.make_config(32, 6, NV, workers=64, table_size=20011, update_policy=bad), counts, 0)
         m.set_partition(2, 0, 1)
