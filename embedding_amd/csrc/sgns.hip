@@ -24,6 +24,9 @@
 #define EXP_TABLE_SIZE 1000
 #define MAX_EXP 6
 #define NEG_BATCH 5
+#ifndef DGE_HOTMIX_WAVES
+#define DGE_HOTMIX_WAVES 2
+#endif
 #ifndef DGE_HS_WAVES
 #define DGE_HS_WAVES 4
 #endif
@@ -809,7 +812,7 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
 #define LK_NEG_LANES 13      /* lanes 0..12 draw negatives, lane 13 = pending centre flush, lane 14 = the pair's syn0 row */
 // 3 waves per SIMD is the measured optimum for D <= 128: 4 (128 VGPRs) spills 88 B per lane and runs 20 % slower, 2 runs 12 % slower
 template <int DCH, bool STRICT, bool BIG, bool HOTMIX, bool PART>
-__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? 3 : ((HOTMIX && DCH <= 4) ? 2 : 1))
+__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HOTMIX ? DGE_HOTMIX_WAVES : 3) : ((HOTMIX && DCH <= 4) ? 2 : 1))
 k_sgns_train_locked(TrainParams p) {
     __shared__ float s_exp[EXP_TABLE_SIZE];
     __shared__ float s_dh[16 * 2 * DCH * 64];
@@ -982,6 +985,7 @@ k_sgns_train_locked(TrainParams p) {
                     const unsigned got = (gotl >> base) & ((1u << NEG_BATCH) - 1u) & pending;
                     const bool gotf = flush_pending && ((gotl >> 13) & 1u);
                     Row<DCH> rr[NEG_BATCH], fr;
+                    float hot_g[NEG_BATCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
                     if (got_l1) rowA_load<DCH, 16, BIG>(l1, syn0, (gotl >> 14) & 1u ? last : 0, lane);
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16, BIG>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : word, lane);
@@ -994,15 +998,14 @@ k_sgns_train_locked(TrainParams p) {
                             float g = sgns_g(f, 0.0f, alpha, s_exp);
                             row_axpy(neu, g, rr[q]);
                             if (HOTMIX && tg[q] < hot_rows) {
-                                rowA_atomic_axpy<DCH>(syn1neg, tg[q], lane, g, l1);
+                                hot_g[q] = g;              // the atomics go out after this round's locks have dropped (below)
                             } else {
                                 row_axpy(rr[q], g, l1);
                                 rowA_store<DCH, 16, BIG>(rr[q], syn1neg, tg[q], lane);
                             }
                         }
-                    if (gotf && HOTMIX && pend_row < hot_rows) {
-                        ldsA_atomic_add<DCH>(syn1neg, pend_row, lane, my_dh + (cur_buf ^ 1) * DCH * 64);
-                    } else if (gotf) {
+                    const bool hot_flush = HOTMIX && gotf && pend_row < hot_rows;
+                    if (gotf && !hot_flush) {
                         const float* d = my_dh + (cur_buf ^ 1) * DCH * 64 + lane;
 #pragma unroll
                         for (int q = 0; q < DCH; q++) {
@@ -1027,6 +1030,14 @@ k_sgns_train_locked(TrainParams p) {
                         row_commit_wait(acc);
                     }
                     if (won && lane != 14) row_unlock<STRICT>(locks1, t);
+                    if (HOTMIX) {
+                        // head rows: memory-side atomics, issued behind the commit so that the wait above (which drains every
+                        // outstanding memory operation of the wave) never sits on them while row locks are held
+#pragma unroll
+                        for (int q = 0; q < NEG_BATCH; q++)
+                            if (((got >> q) & 1u) && tg[q] < hot_rows) rowA_atomic_axpy<DCH>(syn1neg, tg[q], lane, hot_g[q], l1);
+                        if (hot_flush) ldsA_atomic_add<DCH>(syn1neg, pend_row, lane, my_dh + (cur_buf ^ 1) * DCH * 64);
+                    }
                     pending &= ~got;
                     if (gotf) { flush_pending = false; pend_row = -1; if (lane == 13) t = -1; }
                     if (pending) __builtin_amdgcn_s_sleep(2);
@@ -1499,7 +1510,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
         const bool auto_locked = !hs && m->cfg.update_policy == 0 && m->V >= 262144 && (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision < 0.25;
         const bool auto_mixed = !hs && m->cfg.update_policy == 0 && !auto_locked && m->V >= 262144 && m->hot_rows_auto <= m->V / 8;
-        const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || m->cfg.update_policy == 7 || auto_locked || auto_mixed) ? 3 : 4;   // what the kernel's VGPR budget keeps resident
+        const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || m->cfg.update_policy == 7 || auto_locked || auto_mixed) ? ((m->cfg.update_policy == 7 || auto_mixed) ? DGE_HOTMIX_WAVES : 3) : 4;   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)m->n_cus * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);

@@ -7,6 +7,10 @@ import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 import embedding_amd as E
 
+# "zipf": the same graph, but a vertex's flow that LEAVES its community goes to a region drawn with P(rank r) ~ 1/(r+1)
+# (popular regions, as in cfg5) instead of a uniform one -> a skewed vocabulary, where auto selects the mixed policy 7.
+ZIPF = len(sys.argv) > 1 and sys.argv[1] == "zipf"
+
 R, T, L, D, K = 41667, 24, 24, 128, 5
 NV = R * T
 dev = "cuda:0"
@@ -18,6 +22,10 @@ reg = src % R
 inside = torch.rand(Etot, generator=g0, device=dev) < 0.8
 local = (reg // 64) * 64 + torch.randint(0, 64, (Etot,), generator=g0, device=dev, dtype=torch.int32)
 anyw = torch.randint(0, R, (Etot,), generator=g0, device=dev, dtype=torch.int32)
+if ZIPF:
+    ur = torch.rand(Etot, generator=g0, device=dev, dtype=torch.float32)
+    anyw = (torch.exp(ur * float(np.log(R + 1.0))) - 1.0).to(torch.int64).clamp_(0, R - 1).to(torch.int32)
+    del ur
 dreg = torch.where(inside, local.clamp_(max=R - 1), anyw)
 dst = (((src // R + 1) % T) * R + dreg).to(torch.int32)
 w = (1.0 + torch.floor(-20.0 * torch.log(torch.rand(Etot, generator=g0, device=dev, dtype=torch.float64).clamp_(min=1e-12))))
@@ -42,10 +50,20 @@ def auc(m):
     pos = (s0[b] * s1[a]).sum(1); neg = (s0[rb] * s1[a]).sum(1)
     return float((pos > neg).float().mean() + 0.5 * (pos == neg).float().mean()), float(pos.mean()), float(neg.mean())
 
-for pol in (2, 5, 6, 1, 3):
+for pol in ((2, 7, 0) if ZIPF else (2, 5, 6, 1, 3)):
     cfg = E.make_config(D, L, NV, negative=K, workers=0, update_policy=pol)
     m = E.SgnsModel.create(cfg, counts, 0)
     t = time.time(); m.train(corpus); st = m.stats(); dt = time.time() - t
     print("policy", pol, "pairs %.3e" % st["pairs"], "kernel %.2fs" % (st["kernel_ms"] / 1e3), "-> %.3e edges/s" % (st["pairs"] / (st["kernel_ms"] / 1e3)),
-          "| AUC %.4f pos %.3f neg %.3f" % auc(m), flush=True)
+          "| AUC %.4f pos %.3f neg %.3f" % auc(m), "| ran as", m.schedule(), flush=True)
     m.close()
+
+if ZIPF and len(sys.argv) > 2 and sys.argv[2] == "sweep":       # head size of the mixed policy (DGE_HOT_ROWS overrides the rule)
+    import os
+    for hot in (1000, 3000, 7000, 30000, 100000):
+        os.environ["DGE_HOT_ROWS"] = str(hot)
+        m = E.SgnsModel.create(E.make_config(D, L, NV, negative=K, workers=0, update_policy=7), counts, 0)
+        m.train(corpus); st = m.stats()
+        print("policy 7 head", hot, "-> %.3e edges/s" % (st["pairs"] / (st["kernel_ms"] / 1e3)), "| AUC %.4f" % auc(m)[0], flush=True)
+        m.close()
+
