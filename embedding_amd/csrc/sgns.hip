@@ -173,6 +173,7 @@ struct TrainParams {
     // multi-GPU block schedule (dge_model_set_partition): only pairs whose context row is in partition part_ctx and whose
     // centre row is in partition part_tgt (row % part_n) are trained; negatives are moved into partition part_tgt
     int32_t part_n, part_ctx, part_tgt;
+    int32_t syn0_free;        // HOTMIX kernels: the pair's syn0 row is never locked either (read agent-scope, updated with atomics)
 };
 
 // PART: which of a walk's (<= 64, register-resident) tokens lie in partition `part`: bit j of the result = token j.
@@ -969,7 +970,7 @@ k_sgns_train_locked(TrainParams p) {
                     const bool others_ok = have_l1 || !l1_only;
                     const bool want = (others_ok && myq >= 0 && myq < NEG_BATCH && lane < kc && ((pending >> myq) & 1u)) ||
                                       (others_ok && lane == 13 && flush_pending) || (lane == 14 && !have_l1);
-                    const bool lockfree = HOTMIX && want && t < hot_rows;          // a head row: no lock, atomics
+                    const bool lockfree = HOTMIX && want && (t < hot_rows || (lane == 14 && p.syn0_free));     // a head row: no lock, atomics
                     const bool won = (want && !lockfree) ? row_trylock(lane == 14 ? locks0 : locks1, t) : false;
                     const unsigned long long bal = __ballot(won || lockfree);
                     const unsigned gotl = (unsigned)(bal >> (threadIdx.x & 48)) & 0xFFFFu;
@@ -1066,7 +1067,7 @@ k_sgns_train_locked(TrainParams p) {
         for (int q = 0; q < DCH; q++) {
             l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
         }
-        if (HOTMIX && last < hot_rows) {
+        if (HOTMIX && (last < hot_rows || p.syn0_free)) {
             rowA_atomic_axpy<DCH>(syn0, last, lane, 1.0f, neu);
         } else {
             rowA_store<DCH, 16, BIG>(l1, syn0, last, lane);
@@ -1465,6 +1466,7 @@ static void launch_train_b(const TrainParams& p, int pol, unsigned blocks, unsig
         case 20: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 22: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 25: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 27: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true, true>), dim3(blocks), dim3(threads), 0, st, p); break;
         default: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
     }
 }
@@ -1498,7 +1500,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.locks = m->d_locks;
     p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
     p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0;
-    p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt;
+    p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt; p.syn0_free = 0;
     const bool part = m->part_n > 1;
     const bool hs = m->cfg.use_hs != 0;
     if (part && hs) DGE_FAIL(DGE_ERR_STATE, "the block schedule (dge_model_set_partition) cannot carry the hierarchical-softmax term: a Huffman path crosses every partition");
@@ -1539,22 +1541,25 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     if (part && L > 64) DGE_FAIL(DGE_ERR_ARG, "the block schedule keeps a walk's tokens in registers: walks of up to 64 tokens, not %d", L);
     if (part) {
         // One block of the multi-GPU schedule: the live rows are V/part_n per table, so lock attempts collide part_n times
-        // as often as on the whole table.  Measured on cfg3 (bench.py --sim-ranks): at 4 ranks the commit-lock kernel
-        // still beats atomics with the full 12 288 workers (5.4e8 vs 3.9e8 edges/s per rank); at 8 ranks it collapses
-        // there (1.9e8) but leads again with 6-8 k workers (4.0e8 vs 3.6e8) -> auto keeps the expected failure rate of a
-        // try at <= 0.37 by shrinking the worker count, and falls back to atomics when that leaves under 6 144 workers.
+        // as often as on the whole table (measured on cfg3 with bench.py --sim-ranks, profiles/r01_block_schedule_sim.txt).
         if (pol == 0) pol = 20;
         else if (m->cfg.update_policy == 0) {
             const double per_worker = 5.0 * m->neg_collision * (double)m->part_n;
             const int64_t w_max = per_worker > 0 ? (int64_t)(0.37 / per_worker) / 256 * 256 : workers;
-            if (m->V >= 262144 && w_max >= 6144) {
-                pol = 25;
-                if (m->cfg.workers == 0 && w_max < workers) { workers = w_max; p.n_workers = workers; }
+            if (m->V >= 262144 && w_max >= workers) pol = 25;                  // cfg3: up to 4 ranks
+            else if (m->V >= 262144 && w_max >= 4096) {
+                // more ranks: also take the pair's syn0 row out of the lock protocol (it is held for the whole pair: at
+                // 8 ranks 10 % of the live syn0 rows are locked at any time and every tenth pair is aborted and retried);
+                // its update goes out as atomics behind the last unlock.  8 192 workers (2 resident blocks a CU): 4.6e8 edges/s
+                // per rank against 3.7e8 with the syn0 locks and 3.6e8 with atomics everywhere.
+                pol = 27; p.hot_rows = 0; p.syn0_free = 1;
+                if (m->cfg.workers == 0) { workers = std::min<int64_t>(workers, (int64_t)m->n_cus * 2 * 16); p.n_workers = workers; }
             } else pol = 22;
         }
         else if (pol == 2) pol = 22;
         else if (pol == 5) pol = 25;
-        else DGE_FAIL(DGE_ERR_ARG, "the block schedule runs under update_policy 0 (auto), 2, 3 or 5, not %d", m->cfg.update_policy);
+        else if (pol == 7) { pol = 27; p.hot_rows = 0; p.syn0_free = 1; }      // locks on syn1neg only (see the auto rule above)
+        else DGE_FAIL(DGE_ERR_ARG, "the block schedule runs under update_policy 0 (auto), 2, 3, 5 or 7, not %d", m->cfg.update_policy);
     }
     size_t shmem = 0;
     if (hs) {

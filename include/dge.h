@@ -212,7 +212,8 @@ void dge_model_free(dge_model* m);
  * N runs episodes e = 0..N-1 with (ctx_part, tgt_part) = (g, (g+e) % N) over the same global batch of
  * walks: the blocks of one episode are row-disjoint, after N episodes every pair was trained once.
  * Between episodes the ranks exchange the syn1neg partitions they trained (export -> all-gather ->
- * import); syn0 partitions are gathered once at the end.  n_parts <= 1 switches the filter off. */
+ * import); syn0 partitions are gathered once at the end.  n_parts <= 1 switches the filter off.
+ * Policies under a partition: 0 (auto), 2, 3, 5, and 7 = row locks on syn1neg only, the pair's syn0 row by atomics. */
 int  dge_model_set_partition(dge_model* m, int32_t n_parts, int32_t ctx_part, int32_t tgt_part);
 /* floats of one packed partition buffer: ceil(V / n_parts) rows x row stride (same for every partition) */
 int  dge_model_partition_floats(const dge_model* m, int32_t n_parts, int64_t* n_floats);

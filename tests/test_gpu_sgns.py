@@ -562,7 +562,7 @@ def test_block_schedule_hogwild_policies(dge, oracle):
     corpus = dge.WalkCorpus.from_host(walks, 0)
     counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0")
     corpus.count_tokens(NV, counts)
-    for pol, workers, tol in ((0, 0, 0.9), (2, 64, 0.99), (5, 64, 0.99)):
+    for pol, workers, tol in ((0, 0, 0.9), (2, 64, 0.99), (5, 64, 0.99), (7, 64, 0.99)):     # 7 = locks on syn1neg only
         cfg = dge.make_config(32, 6, NV, workers=workers, table_size=20011, update_policy=pol)
         ms = [dge.SgnsModel.create(cfg, counts, 0) for _ in range(2)]
         simulate_block_schedule(ms, lambda m: m.train(corpus))
@@ -576,11 +576,11 @@ def test_block_schedule_hogwild_policies(dge, oracle):
     tc = dge.WalkCorpus.from_host(tiny, 0)
     tcounts = torch.zeros(4, dtype=torch.int64, device="cuda:0"); tc.count_tokens(4, tcounts)
     ot = oracle.train_sgns(tiny, 4, 8, 6, min_count=1, table_size=101, arith=1, part_n=2)
-    for pol in (2, 5):
+    for pol in (2, 5, 7):
         ms = [dge.SgnsModel.create(dge.make_config(8, 6, 4, min_count=1, workers=16, table_size=101, update_policy=pol), tcounts, 0) for _ in range(2)]
         simulate_block_schedule(ms, lambda m: m.train(tc))
         assert sum(m.stats()["pairs"] for m in ms) == ot.pairs and np.isfinite(ms[0].syn1neg()).all()
-    for bad in (1, 6, 7):
+    for bad in (1, 6):
         m = dge.SgnsModel.create(dge.make_config(32, 6, NV, workers=64, table_size=20011, update_policy=bad), counts, 0)
         m.set_partition(2, 0, 1)
         with pytest.raises(dge.DgeError):
