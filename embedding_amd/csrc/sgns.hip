@@ -5,12 +5,16 @@
 // skip-gram negative-sampling update with DL4J's pair enumeration, as restated in oracle/dge_oracle.c
 // (SURVEY.md §3.3, row a9).
 //
-// HBM layout: syn0, syn1neg  float32 [V x stride], stride = round_up(dim, 64) floats (zero padded) so that a row
-// is 1..8 chunks of 256 B; a 16-lane group moves a chunk as four 64-B segments (lane j owns elements 64c+16m+j).
+// HBM layout: syn0, syn1neg (and syn1 with use_hs)  float32 [V x stride], stride = round_up(dim, 64) floats (zero padded)
+// so that a row is 1..8 chunks of 256 B.
 // Work decomposition: one 16-lane group ("worker") per walk; 4 workers per wave.  A worker owns D/16 floats of
-// every row it touches in registers, dot products are 16-lane xor-butterflies (DPP-sized), and the K negative
-// rows of a pair are in flight together.  Updates are plain stores (Hogwild, like the reference's 8 DL4J
-// workers); workers == 1 gives the in-order schedule the oracle follows.
+// every row it touches in registers, dot products are 16-lane xor-butterflies, and the K negative rows of a pair are in
+// flight together.  workers == 1 gives the in-order schedule the oracle follows, bit for bit.
+// Two trainer kernels (dge_train_config.update_policy):
+//   k_sgns_train         rows move 4 B per lane (lane j owns elements 64c+16m+j): in-order plain accesses, or Hogwild
+//                        with agent-scope loads and memory-side float atomics; also carries the hierarchical softmax.
+//   k_sgns_train_locked  rows move 16 B per lane under per-row commit locks (the default on large vocabularies);
+//                        HOTMIX: the vocabulary's head takes atomics instead; PART: one block of the multi-GPU schedule.
 #include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <stdlib.h>
@@ -1518,7 +1522,6 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
     } else workers = m->cfg.workers;
     p.n_workers = workers;
-    // update policy (see Policy<> and dge_train_config.update_policy)
     // update policy (see Policy<>, k_sgns_train_locked and dge_train_config.update_policy)
     int pol = m->cfg.update_policy;
     if (pol == 0) {
