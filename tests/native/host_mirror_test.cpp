@@ -107,6 +107,16 @@ int main(int argc, char** argv) {
         }
         CHECK(lines == 36);                                           // shared "h-id" vocabulary: 3 layers x 12 spatial regions (the 6 flow regions are a subset)
     }
+    {   // the same with the hierarchical-softmax term DL4J's builder default leaves on (J/DeepWalk.java:73-76)
+        DeepWalk::useHierarchicSoftmax = true;
+        const std::string vec_hs = tmp + "/taxi-deepwalk-hs.vec";
+        dge_train_stats st = DeepWalk::learnEmbedding({seq, tmp + "/taxi-spatial.seq"}, vec_hs, 20, 0, 1);
+        DeepWalk::useHierarchicSoftmax = false;
+        CHECK(st.pairs > 0);
+        std::ifstream a(vec), b(vec_hs); std::string la, lb; int lines = 0, differ = 0;
+        while (std::getline(a, la) && std::getline(b, lb)) { lines++; if (la != lb) differ++; }
+        CHECK(lines == 36 && differ > 0);                             // same vocabulary, different vectors
+    }
     std::printf("HOST MIRROR OK\n");
     return 0;
 }
