@@ -93,6 +93,8 @@ int  dge_graph_sample_next(const dge_graph* g, int32_t v, double x, int32_t* nex
  *            nextDouble() per decision — what the reference produces after
  *            `LayeredGraph.rnd = new Random(seed)`.  first_index = draws already consumed.
  *   rng_mode 1 ("strided"): walk i owns draws [i*max_len, (i+1)*max_len) of that same stream.
+ *   draws_consumed: mode 0 = draws this call took from the stream (add it to first_index for the next call);
+ *            mode 1 = n_walks*max_len, the span of the stream the call owns.
  *            first_index = global index of the first walk (shards / batches).
  *            Both modes give identical walks on graphs where no walk dead-ends.
  * A dead end yields a shorter walk (pad -1), never an error (J/LayeredGraph.java:247-248).

@@ -61,3 +61,60 @@ def test_random_configuration_bit_exact(dge, oracle, seed):
     assert np.array_equal(bits(dm.syn1neg()), bits(om.syn1neg)), (seed, mode, cfg)
     if mode == "hs" and om.V > 1:
         assert np.array_equal(bits(dm.syn1()), bits(om.syn1)), (seed, mode, cfg)
+
+
+def _graph_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    V = int(rng.integers(3, 300))
+    E = int(rng.integers(V, 12 * V))
+    hubby = rng.random() < 0.4
+    src = (np.minimum(rng.zipf(1.3, E) - 1, V - 1) if hubby else rng.integers(0, V, E)).astype(np.int32)      # hubs: hundreds of out-edges
+    dst = rng.integers(0, V, E).astype(np.int32)                                                             # self loops and duplicates included
+    wkind = rng.integers(0, 3)
+    w = (rng.integers(1, 60, E).astype(np.float64) if wkind == 0 else rng.random(E) + 1e-3 if wkind == 1 else np.full(E, 2.0))
+    top_k = int(rng.integers(1, 4)) if rng.random() < 0.3 else None
+    if top_k is not None:                                       # the prune needs every vertex to keep >= k out-edges
+        extra = np.repeat(np.arange(V, dtype=np.int32), top_k)
+        src = np.concatenate([src, extra]); dst = np.concatenate([dst, rng.integers(0, V, len(extra)).astype(np.int32)])
+        w = np.concatenate([w, rng.integers(1, 60, len(extra)).astype(np.float64)])
+        p = rng.permutation(len(src)); src, dst, w = src[p], dst[p], w[p]
+    elif rng.random() < 0.5:                                    # dead ends: some vertices lose all their out-edges
+        dead = rng.random(V) < 0.15
+        keep = ~dead[src]
+        if keep.sum() >= 2:
+            src, dst, w = src[keep], dst[keep], w[keep]
+    n_src = int(rng.integers(1, V + 1))
+    present = np.unique(np.concatenate([src, dst]))
+    sources = rng.choice(present, size=min(n_src, len(present)), replace=False).astype(np.int32)
+    return src, dst, w, sources, dict(exact=bool(rng.random() < 0.5), stream_sum=bool(rng.random() < 0.3), L=int(rng.choice([1, 2, 5, 8, 24, 33])),
+                                     n=int(rng.integers(1, 3000)), seed=int(rng.integers(-2**40, 2**40)), first=int(rng.integers(0, 10**6)),
+                                     top_k=top_k)
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_graph_alias_and_walks_bit_exact(dge, oracle, seed):
+    """Edge store -> (top-k prune) -> alias tables -> walks in both RNG layouts, on random multigraphs with hubs, self loops,
+    duplicate edges, dead ends, arbitrary source sets (J/LayeredGraph.java:54-82,104-116,195-252; J/SpatialGraph.java:29-35)."""
+    from helpers import build_both
+    src, dst, w, sources, c = _graph_case(seed)
+    if c["top_k"] is not None:                                  # the prune needs EVERY vertex to have at least k out-edges (the
+        deg = np.bincount(src, minlength=int(max(src.max(), dst.max())) + 1)        # reference's subList(0, k) throws otherwise)
+        if (deg < c["top_k"]).any():
+            c["top_k"] = None
+    og, dg = build_both(oracle, dge, src, dst, w, sources, exact=c["exact"], stream_sum=c["stream_sum"], top_k=c["top_k"])
+    assert dg.num_vertices == og.num_vertices and dg.num_edges == og.num_edges
+    for v in np.unique(np.concatenate([src[:20], dst[:5], sources[:5]])):
+        a, b = og.get_alias(int(v)), dg.get_alias(int(v))
+        assert np.array_equal(a["nbr"], b["nbr"]) and np.array_equal(a["alias"], b["alias"]), (seed, v)
+        assert np.array_equal(bits(a["prob"]), bits(b["prob"])) and a["out_degree"] == b["out_degree"], (seed, v)
+    sa, sb = og.get_source_alias(), dg.get_source_alias()
+    assert np.array_equal(sa["alias"], sb["alias"]) and np.array_equal(bits(sa["prob"]), bits(sb["prob"])) and sa["weight_sum"] == sb["weight_sum"]
+    for mode in (1, 0):
+        first = c["first"] if mode == 1 else 0
+        wo, do = og.sample_walks(c["n"], c["L"], seed=c["seed"], rng_mode=mode, first_index=first, return_draws=True)
+        wd, dd = dg.sample_walks(c["n"], c["L"], seed=c["seed"], rng_mode=mode, first_index=first, return_draws=True)
+        assert np.array_equal(wo, wd), (seed, mode, c)
+        if mode == 0:                                           # the java stream continues where this call stopped
+            assert do == dd, (seed, c)
+        else:                                                   # strided: the call owns n*L draws of the stream
+            assert dd == c["n"] * c["L"], (seed, c)
