@@ -10,6 +10,9 @@ import embedding_amd as E
 # "zipf": the same graph, but a vertex's flow that LEAVES its community goes to a region drawn with P(rank r) ~ 1/(r+1)
 # (popular regions, as in cfg5) instead of a uniform one -> a skewed vocabulary, where auto selects the mixed policy 7.
 ZIPF = len(sys.argv) > 1 and sys.argv[1] == "zipf"
+# "blocks N": the multi-GPU block schedule with N ranks simulated on this GPU (N models), 10 global batches per epoch,
+# against the one-GPU run of the same epoch.
+BLOCKS = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] == "blocks" else 0
 
 R, T, L, D, K = 41667, 24, 24, 128, 5
 NV = R * T
@@ -49,6 +52,28 @@ def auc(m):
     ok2 = rb >= 0; a, b, rb = a[ok2], b[ok2], rb[ok2]
     pos = (s0[b] * s1[a]).sum(1); neg = (s0[rb] * s1[a]).sum(1)
     return float((pos > neg).float().mean() + 0.5 * (pos == neg).float().mean()), float(pos.mean()), float(neg.mean())
+
+if BLOCKS:
+    sys.path.insert(0, 'tests')
+    from helpers import simulate_block_schedule, simulate_gather_syn0
+    cfg = E.make_config(D, L, NV, negative=K, workers=0)
+    m = E.SgnsModel.create(cfg, counts, 0)
+    nb = n // 10
+    wb = 0
+    for b in range(10):
+        m.reset_stats(); m.train(corpus, b * nb, nb, walk_index_base=b * nb, words_before=wb, total_walks=n); wb += m.stats()["words"]
+    print("one GPU, 10 batches          | AUC %.4f pos %.3f neg %.3f" % auc(m), "| ran as", m.schedule(), flush=True)
+    m.close()
+    ms = [E.SgnsModel.create(cfg, counts, 0) for _ in range(BLOCKS)]
+    wb = 0; t = time.time()
+    for b in range(10):
+        for mm in ms:
+            mm.reset_stats()
+        simulate_block_schedule(ms, lambda mm: mm.train(corpus, b * nb, nb, walk_index_base=b * nb, words_before=wb, total_walks=n))
+        wb += ms[0].stats()["words"]
+    simulate_gather_syn0(ms)
+    print("%d ranks, block schedule      | AUC %.4f pos %.3f neg %.3f" % ((BLOCKS,) + auc(ms[0])), "| ran as", ms[0].schedule(), "| %.0f s for all ranks on one GPU" % (time.time() - t), flush=True)
+    sys.exit(0)
 
 for pol in ((2, 7, 0) if ZIPF else (2, 5, 6, 1, 3)):
     cfg = E.make_config(D, L, NV, negative=K, workers=0, update_policy=pol)
