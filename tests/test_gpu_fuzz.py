@@ -28,9 +28,12 @@ def _case(seed):
     return ids, NV, cfg, mode
 
 
-@pytest.mark.parametrize("seed", list(range(40)))
-def test_random_configuration_bit_exact(dge, oracle, seed):
+@pytest.mark.parametrize("seed", list(range(40)) + [-s for s in range(1, 17)])
+def test_random_configuration_bit_exact(dge, oracle, seed, monkeypatch):
     import torch
+    if seed < 0:                      # the same cases again through the per-row-descriptor addressing of >= 4 GiB tables
+        monkeypatch.setenv("DGE_FORCE_BIG", "1")
+        seed = -seed
     ids, NV, cfg, mode = _case(seed)
     if mode == "hs" and cfg["negative"] == 0 and cfg["dim"] > 256:
         cfg["dim"] = 64
