@@ -190,6 +190,20 @@ __device__ __forceinline__ uint64_t part_token_mask(int32_t tk0, int32_t tk1, in
     m |= (uint64_t)((__ballot(tk3 >= 0 && tk3 % n == part) >> sh) & 0xFFFFull) << 48;
     return m;
 }
+// PART: a block visits every walk of the batch for a few of its pairs (at 8 ranks: 6 of 383), so the next walk's length,
+// word offset and tokens are fetched while the current walk is trained
+__device__ __forceinline__ void walk_fetch(const TrainParams& p, int64_t w, int L, int lane, int& len, int64_t& wb,
+                                           int32_t& t0, int32_t& t1, int32_t& t2, int32_t& t3) {
+    len = 0; wb = 0; t0 = t1 = t2 = t3 = -1;
+    if (w < p.n_rows) {
+        len = (int)p.len[w]; wb = p.wb[w];
+        const int32_t* sen = p.sen + w * L;
+        if (lane < L) t0 = sen[lane];
+        if (lane + 16 < L) t1 = sen[lane + 16];
+        if (lane + 32 < L) t2 = sen[lane + 32];
+        if (lane + 48 < L) t3 = sen[lane + 48];
+    }
+}
 __device__ __forceinline__ int first_bit_from(uint64_t m, int from, int none) {       // lowest set bit >= from, else `none`
     const uint64_t r = from < 64 ? (m >> from) : 0ull;
     return r ? from + (int)__builtin_ctzll(r) : none;
@@ -482,9 +496,11 @@ k_sgns_train(TrainParams p) {
     // its own stream (seeded from the centre's stream and the context position): the draws of a pair do not depend on
     // which other pairs of the centre this block trains.
     uint64_t ctx_mask = 0, tgt_mask = 0, pair_mask = 0, s_centre = 0;
+    int nx_len = 0; int64_t nx_wb = 0; int32_t nx0 = -1, nx1 = -1, nx2 = -1, nx3 = -1;
 
     // ---- per-worker state: walk w, centre i, next context c (contexts are c..c_hi without i)
     int64_t w = (HOT && worker >= p.n_workers) ? p.n_rows - p.n_workers : worker - p.n_workers;   // surplus workers find no walk
+    if (PART) walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
     int len = 0, i = 0, c = 1, c_hi = 0;
     int32_t tk0 = -1, tk1 = -1, tk2 = -1, tk3 = -1;       // the walk's tokens: lane j holds tokens j, j+16, j+32, j+48
     const int32_t* sen = p.sen;
@@ -515,12 +531,16 @@ k_sgns_train(TrainParams p) {
             while (i >= len) {                             // next walk of this worker (empty walks are skipped)
                 w += p.n_workers;
                 if (w >= p.n_rows) { alive = false; break; }
-                len = (int)p.len[w];
+                int64_t wb_next = 0;
+                if (PART) {                                // prefetched while the previous walk was trained
+                    len = nx_len; wb_next = nx_wb; tk0 = nx0; tk1 = nx1; tk2 = nx2; tk3 = nx3;
+                    walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
+                } else len = (int)p.len[w];
                 i = 0;
                 if (len > 0) {
                     if (!PART || p.part_ctx == p.part_tgt) my_words += (unsigned long long)len;      // (block schedule: once per batch, in episode 0)
                     sen = p.sen + w * L;
-                    if (toks_in_regs) {
+                    if (!PART && toks_in_regs) {
                         tk0 = lane < L ? sen[lane] : -1;
                         tk1 = lane + 16 < L ? sen[lane + 16] : -1;
                         tk2 = lane + 32 < L ? sen[lane + 32] : -1;
@@ -532,7 +552,7 @@ k_sgns_train(TrainParams p) {
                         i = first_bit_from(tgt_mask, 0, len);
                     }
                     // learning rate from the exact number of in-vocabulary tokens that precede this walk
-                    const int64_t wbw = p.wb[w];
+                    const int64_t wbw = PART ? wb_next : p.wb[w];
                     const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
                     alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
                     if (alpha < p.min_alpha) alpha = p.min_alpha;
@@ -859,6 +879,8 @@ k_sgns_train_locked(TrainParams p) {
     int32_t t_first = -1;         // this lane's slot of the pair's first chunk (kept across a retry: the draw is not repeated)
     int32_t last = 0;
     uint64_t ctx_mask = 0, tgt_mask = 0, pair_mask = 0, s_centre = 0;     // PART: see k_sgns_train
+    int nx_len = 0; int64_t nx_wb = 0; int32_t nx0 = -1, nx1 = -1, nx2 = -1, nx3 = -1;
+    if (PART) walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
 
 #define LK_TOK(idx) walk_tok(toks_in_regs, sen, (idx), tk0, tk1, tk2, tk3)
 #define LK_CLOSE_CENTRE()                                                                                              \
@@ -879,12 +901,16 @@ k_sgns_train_locked(TrainParams p) {
             while (i >= len) {
                 w += p.n_workers;
                 if (w >= p.n_rows) { alive = false; break; }
-                len = (int)p.len[w];
+                int64_t wb_next = 0;
+                if (PART) {                                // prefetched while the previous walk was trained
+                    len = nx_len; wb_next = nx_wb; tk0 = nx0; tk1 = nx1; tk2 = nx2; tk3 = nx3;
+                    walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
+                } else len = (int)p.len[w];
                 i = 0;
                 if (len > 0) {
                     if (!PART || p.part_ctx == p.part_tgt) my_words += (unsigned long long)len;      // (block schedule: once per batch, in episode 0)
                     sen = p.sen + w * L;
-                    if (toks_in_regs) {
+                    if (!PART && toks_in_regs) {
                         tk0 = lane < L ? sen[lane] : -1;
                         tk1 = lane + 16 < L ? sen[lane + 16] : -1;
                         tk2 = lane + 32 < L ? sen[lane + 32] : -1;
@@ -895,7 +921,7 @@ k_sgns_train_locked(TrainParams p) {
                         tgt_mask = part_token_mask(tk0, tk1, tk2, tk3, p.part_n, p.part_tgt);
                         i = first_bit_from(tgt_mask, 0, len);
                     }
-                    const int64_t wbw = p.wb[w];
+                    const int64_t wbw = PART ? wb_next : p.wb[w];
                     const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
                     alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
                     if (alpha < p.min_alpha) alpha = p.min_alpha;
