@@ -257,7 +257,7 @@ def main():
                                        else "walk-shard x%d, RCCL all-reduce of deltas per step (comparison mode)" % N if N > 1 else "1 GPU"),
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None if (args.hs or args.dim or args.negative >= 0) else measured_traffic(args.workload, sched["update_policy"], pairs_per_launch),
+                         "traffic": None if (args.dim or args.negative >= 0 or NB > 1) else measured_traffic(args.workload, "hs" if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch),
                          "kernel": kernel_name, "schedule": sched,
                          "ms_per_launch": ms_per_launch,
                          "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
@@ -275,7 +275,7 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(workload, policy, pairs_per_launch):
+def measured_traffic(workload, policy, pairs_per_launch):       # policy: "policy5", "policy7", "hs", ...
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE / WRITE_SIZE per pair of the same workload and policy, corrected as profiles/README.md describes).
     bench.py cannot collect counters itself; None when no profile of this configuration is committed."""
@@ -284,7 +284,7 @@ def measured_traffic(workload, policy, pairs_per_launch):
         return None
     try:
         t = json.load(open(path))
-        e = t.get("%s/policy%d" % (workload, policy))
+        e = t.get("%s/%s" % (workload, policy))
         return None if e is None else e["bytes_per_pair"] * pairs_per_launch
     except (ValueError, KeyError):
         return None
