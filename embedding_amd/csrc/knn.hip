@@ -5,8 +5,10 @@
 //
 // One workgroup = 64 query rows.  The strip of similarities S[64 x n] = Xq . X^T is produced tile by tile (64 columns)
 // with the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (4 waves = 2x2 sub-tiles of 32x32; the query fragment of
-// a wave stays in registers for the whole strip, the column tile is staged in LDS), and is consumed immediately: one lane
-// per query row scans the tile and keeps that row's k best (distance ascending, index ascending among equals) in LDS.
+// a wave stays in registers for the whole strip, the column tile is staged in LDS), and is consumed immediately: all 256
+// threads test the tile's 64 x 64 similarities against each row's current k-th best (a threshold that only tightens, so
+// nothing that belongs in the list is missed), and one lane per query row then inserts the few columns that passed, in
+// column order, into that row's k best (distance ascending, index ascending among equals) in LDS.
 // Nothing of size n^2 ever reaches HBM.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -35,8 +37,9 @@ k_knn_strip(const float* __restrict__ x, const float* __restrict__ inv_norm, int
     const int Dp = DH * 2;
     float* Bs = lds;                              // [64][Dp + 1]   column tile, row-major per column vector
     float* Ss = Bs + 64 * (Dp + 1);               // [64][65]       similarities of the tile
-    float* Ld = Ss + 64 * 65;                     // [64][k]        running best distances
-    int32_t* Li = (int32_t*)(Ld + 64 * KNN_MAX_K);   // [64][k]     their indices
+    float* Ld = Ss + 64 * 65;                     // [64][k]        running best distances (pitch k: two workgroups fit a CU and overlap their phases)
+    int32_t* Li = (int32_t*)(Ld + 64 * k);        // [64][k]        their indices
+    uint32_t* Ms = (uint32_t*)(Li + 64 * k);      // [64][4]     per row and 16-column quarter: columns that beat the row's threshold
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
     const int q0 = blockIdx.x * 64;
 
@@ -51,7 +54,7 @@ k_knn_strip(const float* __restrict__ x, const float* __restrict__ inv_norm, int
             a[j] = (row < n && kk < D) ? x[(size_t)row * D + kk] * sc : 0.0f;
         }
     }
-    for (int i = t; i < 64 * KNN_MAX_K; i += 256) { Ld[i] = 3.0f; Li[i] = -1; }     // 3 > any cosine distance
+    for (int i = t; i < 64 * k; i += 256) { Ld[i] = 3.0f; Li[i] = -1; }     // 3 > any cosine distance
 
     for (int c0 = 0; c0 < n; c0 += 64) {
         __syncthreads();                                          // previous tile fully consumed
@@ -69,13 +72,31 @@ k_knn_strip(const float* __restrict__ x, const float* __restrict__ inv_norm, int
         for (int v = 0; v < 16; v++)
             Ss[(wr * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3)) * 65 + wc * 32 + (lane & 31)] = acc[v];
         __syncthreads();
-        if (t < 64 && q0 + t < n) {                               // one lane per query row keeps the row's k best
+        {   // filter: thread (row r, quarter qd) tests 16 columns against the row's k-th best as it stands before this tile
+            const int r = t & 63, qd = t >> 6, q = q0 + r;
+            uint32_t m = 0;
+            if (q < n) {
+                const bool qzero = inv_norm[q] == 0.0f;
+                const float thr = Ld[r * k + k - 1];
+                for (int cc = 0; cc < 16; cc++) {
+                    const int c = qd * 16 + cc, col = c0 + c;
+                    if (col >= n || col == q) continue;
+                    const float d = (qzero || inv_norm[col] == 0.0f) ? 2.0f : 1.0f - Ss[r * 65 + c];
+                    if (d < thr) m |= 1u << cc;
+                }
+            }
+            Ms[r * 4 + qd] = m;
+        }
+        __syncthreads();
+        if (t < 64 && q0 + t < n) {                               // one lane per query row inserts what passed, in column order
             const int q = q0 + t;
             const bool qzero = inv_norm[q] == 0.0f;
-            float* ld = Ld + t * KNN_MAX_K; int32_t* li = Li + t * KNN_MAX_K;
-            for (int c = 0; c < 64; c++) {
+            float* ld = Ld + t * k; int32_t* li = Li + t * k;
+            uint64_t mask = (uint64_t)Ms[t * 4] | ((uint64_t)Ms[t * 4 + 1] << 16) | ((uint64_t)Ms[t * 4 + 2] << 32) | ((uint64_t)Ms[t * 4 + 3] << 48);
+            while (mask) {
+                const int c = __builtin_ctzll(mask);
+                mask &= mask - 1;
                 const int col = c0 + c;
-                if (col >= n || col == q) continue;
                 float d = (qzero || inv_norm[col] == 0.0f) ? 2.0f : 1.0f - Ss[t * 65 + c];
                 if (!(d < ld[k - 1])) continue;                   // ties keep the earlier (smaller) index: stable order
                 int p = k - 1;
@@ -87,13 +108,13 @@ k_knn_strip(const float* __restrict__ x, const float* __restrict__ inv_norm, int
     __syncthreads();
     for (int i = t; i < 64 * k; i += 256) {
         const int r = i / k, j = i - r * k;
-        if (q0 + r < n) { out_idx[(size_t)(q0 + r) * k + j] = Li[r * KNN_MAX_K + j]; out_dist[(size_t)(q0 + r) * k + j] = Ld[r * KNN_MAX_K + j]; }
+        if (q0 + r < n) { out_idx[(size_t)(q0 + r) * k + j] = Li[r * k + j]; out_dist[(size_t)(q0 + r) * k + j] = Ld[r * k + j]; }
     }
 }
 
 template <int DH>
 static void launch_knn(const float* x, const float* inv, int n, int D, int k, int32_t* oi, float* od, hipStream_t st) {
-    const size_t lds = (size_t)(64 * (2 * DH + 1) + 64 * 65 + 64 * KNN_MAX_K * 2) * sizeof(float);
+    const size_t lds = (size_t)(64 * (2 * DH + 1) + 64 * 65 + 64 * k * 2 + 64 * 4) * sizeof(float);
     (void)hipFuncSetAttribute((const void*)k_knn_strip<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_knn_strip<DH>), dim3((n + 63) / 64), dim3(256), lds, st, x, inv, n, D, k, oi, od);
 }
