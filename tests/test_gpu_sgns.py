@@ -376,6 +376,23 @@ def test_cfg3_sized_epoch_slice_properties(dge):
     assert st["kernel_ms"] > 0 and st["pairs"] / (st["kernel_ms"] * 1e-3) > 1e8             # and it is the fast path
 
 
+@pytest.mark.parametrize("negative,dim", [(64, 32), (100, 20), (33, 128)])
+def test_many_negatives_bit_exact(dge, oracle, negative, dim):
+    """K far beyond one 16-lane draw round (and beyond the lock kernel's 13-lane chunks, with many duplicate draws per pair)."""
+    walks, NV = _walks(oracle, dge, n=300)
+    om, dm = _fit_both(oracle, dge, walks, NV, arith=1, dim=dim, negative=negative)
+    assert dm.stats()["pairs"] == om.pairs
+    assert np.array_equal(bits(dm.vectors()[0]), bits(om.syn0)) and np.array_equal(bits(dm.syn1neg()), bits(om.syn1neg))
+    # the lock kernel: one worker follows the sequential result to rounding (its positive target comes last); 16 workers on this
+    # 194-row vocabulary touch a third of all rows per pair, so only termination, the pair count and finiteness are checked
+    o0 = oracle.train_sgns(walks, NV, dim, 6, negative=negative, table_size=20011, arith=0)
+    for workers in (1, 16):
+        d5 = dge.SgnsModel.fit(walks, dge.make_config(dim, 6, NV, negative=negative, workers=workers, table_size=20011, update_policy=5), 0)
+        assert d5.stats()["pairs"] == om.pairs and np.isfinite(d5.vectors()[0]).all()
+        if workers == 1:
+            assert cosine_rows(d5.vectors()[0], o0.syn0).min() > 1 - 1e-3
+
+
 @pytest.mark.parametrize("negative", [0, 1, 13, 14, 27])
 def test_locked_kernel_negative_count_edges(dge, oracle, negative):
     """The commit-lock kernel draws negatives in chunks of 13 lanes and batches of 5 rows: K = 0 (only the syn0 row is
