@@ -177,6 +177,7 @@ struct TrainParams {
     // multi-GPU block schedule (dge_model_set_partition): only pairs whose context row is in partition part_ctx and whose
     // centre row is in partition part_tgt (row % part_n) are trained; negatives are moved into partition part_tgt
     int32_t part_n, part_ctx, part_tgt;
+    int32_t big_seg_shift;    // BIG: 0, or (tests) a smaller segment size than the 4 GiB window allows
     int32_t syn0_free;        // HOTMIX kernels: the pair's syn0 row is never locked either (read agent-scope, updated with atomics)
 };
 
@@ -271,25 +272,33 @@ __device__ __forceinline__ float group16_sum(float p) {
 
 // one table seen through a buffer descriptor: byte offset of (row, lane) = row*stride*4 + lane*16 (< 4 GiB)
 // Tables of 4 GiB and more (cfg5: 10 M rows x 256 floats = 10 GB) do not fit one descriptor's 32-bit window: their
-// accesses build a descriptor per ROW (base + row*row_bytes, one row long).  That descriptor differs between the four
-// groups of a wave, so the compiler serialises the instruction per distinct row (a "waterfall" of <= 4 trips); the
-// common case keeps the single table-wide descriptor (template parameter BIG of the kernels).
+// accesses build the descriptor of the row's SEGMENT (a power-of-two number of rows that fits a 4 GiB window).  That
+// descriptor can differ between the four groups of a wave, so the compiler serialises the instruction per distinct
+// segment (a "waterfall"); the common case keeps the single table-wide descriptor (template parameter BIG of the kernels).
 struct TableView {
     __amdgpu_buffer_rsrc_t rsrc;
     float* base;
     uint32_t row_bytes;
+    uint32_t seg_shift;       // BIG: rows per segment = 1 << seg_shift (the largest power of two whose rows fit a 4 GiB window)
     bool big;
 };
-__device__ __forceinline__ TableView make_view(float* base, int64_t rows, int stride) {
+__device__ __forceinline__ TableView make_view(float* base, int64_t rows, int stride, int seg_shift_override = 0) {
     TableView t;
     t.base = base;
     t.row_bytes = (uint32_t)stride * 4u;
     t.big = (uint64_t)rows * (uint64_t)stride * 4ull >= 0xFFFFFFFFull;
     t.rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, t.big ? 0 : (int)(uint32_t)(rows * stride * 4), 0x00020000);   // unused when BIG
+    t.seg_shift = 31u - (uint32_t)__builtin_clz(0xFFFFFFFFu / t.row_bytes);
+    if (seg_shift_override > 0 && (uint32_t)seg_shift_override < t.seg_shift) t.seg_shift = (uint32_t)seg_shift_override;   // tests: tiny segments
     return t;
 }
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_view(const TableView& t, int32_t row) {
-    return __builtin_amdgcn_make_buffer_rsrc(t.base + (size_t)row * (t.row_bytes / 4), 0, (int)t.row_bytes, 0x00020000);
+// BIG: the descriptor of the 4 GiB-window segment that holds `row`, and the row's byte offset inside it.  The four groups
+// of a wave mostly land in the same segment (a 10 GB table has three), so the per-descriptor serialisation the compiler
+// emits ("waterfall") runs once or twice instead of once per distinct row.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_view(const TableView& t, int32_t row, uint32_t& row_off) {
+    const uint32_t seg = (uint32_t)row >> t.seg_shift;
+    row_off = ((uint32_t)row & ((1u << t.seg_shift) - 1u)) * t.row_bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(t.base + ((size_t)seg << t.seg_shift) * (t.row_bytes / 4), 0, (int)(uint32_t)(t.row_bytes << t.seg_shift), 0x00020000);
 }
 
 // Lane j of a 16-lane group owns elements {64c + 16m + j : m = 0..3} of chunk c (kept as v[c].{x,y,z,w}): every
@@ -298,8 +307,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_view(const TableView& t, i
 template <int DCH, int AUX, bool BIG>
 __device__ __forceinline__ void row_load(Row<DCH>& r, const TableView& t, int32_t row, int lane) {
     if (BIG) {
-        const __amdgpu_buffer_rsrc_t rs = row_view(t, row);
-        const uint32_t o = (uint32_t)lane * 4u;
+        uint32_t ro;
+        const __amdgpu_buffer_rsrc_t rs = row_view(t, row, ro);
+        const uint32_t o = ro + (uint32_t)lane * 4u;
 #pragma unroll
         for (int c = 0; c < DCH; c++) {
             r.v[c].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + c * 256u), 0, AUX));
@@ -321,8 +331,9 @@ __device__ __forceinline__ void row_load(Row<DCH>& r, const TableView& t, int32_
 template <int DCH, int AUX, bool BIG>
 __device__ __forceinline__ void row_store(const Row<DCH>& r, const TableView& t, int32_t row, int lane) {
     if (BIG) {
-        const __amdgpu_buffer_rsrc_t rs = row_view(t, row);
-        const uint32_t o = (uint32_t)lane * 4u;
+        uint32_t ro;
+        const __amdgpu_buffer_rsrc_t rs = row_view(t, row, ro);
+        const uint32_t o = ro + (uint32_t)lane * 4u;
 #pragma unroll
         for (int c = 0; c < DCH; c++) {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].x), rs, (int)(o + c * 256u), 0, AUX);
@@ -479,9 +490,9 @@ k_sgns_train(TrainParams p) {
     }
     if (!HOT && worker >= p.n_workers) return;    // (the HOT kernel keeps every thread for its final block-wide drain)
 
-    const TableView syn0 = make_view(p.syn0, p.V, p.stride);
-    const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride);
-    const TableView syn1 = make_view(HS ? p.syn1 : p.syn1neg, p.V, p.stride);
+    const TableView syn0 = make_view(p.syn0, p.V, p.stride, p.big_seg_shift);
+    const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride, p.big_seg_shift);
+    const TableView syn1 = make_view(HS ? p.syn1 : p.syn1neg, p.V, p.stride, p.big_seg_shift);
     int64_t hs_o = 0; int hs_n = 0; uint64_t hs_bits = 0;   // Huffman path of the open centre
 
     // lane j turns the pair's LCG state s into the state after j+1 draws: s*mA + cA
@@ -743,10 +754,11 @@ __device__ __forceinline__ float row_probe_lines(const TableView& t, int32_t row
 template <int DCH, int AUX, bool BIG>
 __device__ __forceinline__ void rowA_load(Row<DCH>& r, const TableView& t, int32_t row, int lane) {
     if (BIG) {
-        const __amdgpu_buffer_rsrc_t rs = row_view(t, row);
+        uint32_t ro;
+        const __amdgpu_buffer_rsrc_t rs = row_view(t, row, ro);
 #pragma unroll
         for (int c = 0; c < DCH; c++) {
-            const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((uint32_t)lane * 16u + c * 256u), 0, AUX));
+            const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + (uint32_t)lane * 16u + c * 256u), 0, AUX));
             r.v[c] = make_float4(f.x, f.y, f.z, f.w);
         }
         return;
@@ -763,12 +775,13 @@ __device__ __forceinline__ void rowA_load(Row<DCH>& r, const TableView& t, int32
 template <int DCH, int AUX, bool BIG>
 __device__ __forceinline__ void rowA_store(const Row<DCH>& r, const TableView& t, int32_t row, int lane) {
     if (BIG) {
-        const __amdgpu_buffer_rsrc_t rs = row_view(t, row);
+        uint32_t ro;
+        const __amdgpu_buffer_rsrc_t rs = row_view(t, row, ro);
 #pragma unroll
         for (int c = 0; c < DCH; c++) {
             v4f f;
             f.x = r.v[c].x; f.y = r.v[c].y; f.z = r.v[c].z; f.w = r.v[c].w;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), rs, (int)((uint32_t)lane * 16u + c * 256u), 0, AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), rs, (int)(ro + (uint32_t)lane * 16u + c * 256u), 0, AUX);
         }
         return;
     }
@@ -849,8 +862,8 @@ k_sgns_train_locked(TrainParams p) {
     const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (worker >= p.n_workers) return;
 
-    const TableView syn0 = make_view(p.syn0, p.V, p.stride);
-    const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride);
+    const TableView syn0 = make_view(p.syn0, p.V, p.stride, p.big_seg_shift);
+    const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride, p.big_seg_shift);
     int* const locks1 = p.locks;
     int* const locks0 = p.locks + p.V + 1;
     const int32_t hot_rows = HOTMIX ? p.hot_rows : 0;
@@ -1531,6 +1544,8 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
     p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0;
     p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt; p.syn0_free = 0;
+    p.big_seg_shift = 0;
+    if (const char* e = getenv("DGE_BIG_SEG_SHIFT")) p.big_seg_shift = atoi(e);          // tests: several segments on a small table
     const bool part = m->part_n > 1;
     const bool hs = m->cfg.use_hs != 0;
     if (part && hs) DGE_FAIL(DGE_ERR_STATE, "the block schedule (dge_model_set_partition) cannot carry the hierarchical-softmax term: a Huffman path crosses every partition");

@@ -33,6 +33,7 @@ def test_random_configuration_bit_exact(dge, oracle, seed, monkeypatch):
     import torch
     if seed < 0:                      # the same cases again through the per-row-descriptor addressing of >= 4 GiB tables
         monkeypatch.setenv("DGE_FORCE_BIG", "1")
+        monkeypatch.setenv("DGE_BIG_SEG_SHIFT", "3")     # 8 rows per descriptor segment: rows of one pair spread over many segments
         seed = -seed
     ids, NV, cfg, mode = _case(seed)
     if mode == "hs" and cfg["negative"] == 0 and cfg["dim"] > 256:

@@ -269,6 +269,7 @@ def test_tables_beyond_4_gib(dge, oracle, monkeypatch):
     of the table are the ones that move, everything else keeps its initial value."""
     walks, NV = _walks(oracle, dge, n=300)
     monkeypatch.setenv("DGE_FORCE_BIG", "1")
+    monkeypatch.setenv("DGE_BIG_SEG_SHIFT", "4")         # 16 rows per descriptor segment instead of 4 GiB worth
     for dim in (64, 128):
         om, dm = _fit_both(oracle, dge, walks, NV, arith=1, dim=dim)
         assert np.array_equal(bits(dm.vectors()[0]), bits(om.syn0)) and np.array_equal(bits(dm.syn1neg()), bits(om.syn1neg))
