@@ -1621,7 +1621,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
 
-    // per-row descriptors (TableView) for tables of 4 GiB and more; DGE_FORCE_BIG=1 selects that code path on small
+    // per-segment descriptors (TableView) for tables of 4 GiB and more; DGE_FORCE_BIG=1 selects that code path on small
     // tables too so that the parity tests can cover it
     const bool big = (uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull || getenv("DGE_FORCE_BIG") != nullptr;
     EventPair ev; ev.kind = 0;
