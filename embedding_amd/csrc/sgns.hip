@@ -28,6 +28,9 @@
 #define EXP_TABLE_SIZE 1000
 #define MAX_EXP 6
 #define NEG_BATCH 5
+#ifndef DGE_LOCKED_WAVES
+#define DGE_LOCKED_WAVES 3
+#endif
 #ifndef DGE_HOTMIX_WAVES
 #define DGE_HOTMIX_WAVES 2
 #endif
@@ -850,7 +853,7 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
 #define LK_NEG_LANES 13      /* lanes 0..12 draw negatives, lane 13 = pending centre flush, lane 14 = the pair's syn0 row */
 // 3 waves per SIMD is the measured optimum for D <= 128: 4 (128 VGPRs) spills 88 B per lane and runs 20 % slower, 2 runs 12 % slower
 template <int DCH, bool STRICT, bool BIG, bool HOTMIX, bool PART>
-__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HOTMIX ? DGE_HOTMIX_WAVES : (DCH == 1 ? 4 : 3)) : ((HOTMIX && DCH <= 4) ? 2 : 1))
+__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HOTMIX ? DGE_HOTMIX_WAVES : (DCH == 1 ? 4 : DGE_LOCKED_WAVES)) : ((HOTMIX && DCH <= 4) ? 2 : 1))
 k_sgns_train_locked(TrainParams p) {
     __shared__ float s_exp[EXP_TABLE_SIZE];
     __shared__ float s_dh[16 * 2 * DCH * 64];
@@ -993,48 +996,49 @@ k_sgns_train_locked(TrainParams p) {
             }
             if (lane == 13) t = pend_row;
             if (lane == 14) t = last;
-            int base = 0;
-            do {
-                int32_t tg[NEG_BATCH];
-#pragma unroll
-                for (int q = 0; q < NEG_BATCH; q++) {
-                    int32_t v = __shfl(t, (base + q) & 15, 16);
-                    tg[q] = (base + q < kc) ? v : -1;
+            // One lock round per CHUNK: every still-untrained row of the chunk (and the pending centre flush, and the pair's
+            // syn0 row) is asked for at once; the rows that were won are then trained NEG_BATCH at a time — loads of a batch
+            // in flight together, no wait between batches — and one commit wait ends the round before the locks drop.  With
+            // K <= NEG_BATCH this is one batch per round; with K = 20 it is two lock/commit round trips per pair instead of five.
+            unsigned pend13 = (unsigned)(__ballot(lane < kc && t >= 0) >> (threadIdx.x & 48)) & 0x1FFFu;
+            bool flush_pending = pend_row >= 0;
+            while (pend13 || !have_l1) {
+                // a pair that already lost the race for its syn0 row once asks for that row ALONE until it has it:
+                // otherwise the many waiting workers of a hot row keep grabbing (and dropping) the syn1neg rows the
+                // row's current holder needs, and the holder starves (seen as a hang on a 3-row vocabulary)
+                const bool others_ok = have_l1 || !l1_only;
+                const bool want = (others_ok && lane < kc && ((pend13 >> lane) & 1u)) ||
+                                  (others_ok && lane == 13 && flush_pending) || (lane == 14 && !have_l1);
+                const bool lockfree = HOTMIX && want && (t < hot_rows || (lane == 14 && p.syn0_free));     // a head row: no lock, atomics
+                const bool won = (want && !lockfree) ? row_trylock(lane == 14 ? locks0 : locks1, t) : false;
+                const unsigned long long bal = __ballot(won || lockfree);
+                const unsigned gotl = (unsigned)(bal >> (threadIdx.x & 48)) & 0xFFFFu;
+                if (!have_l1 && !((gotl >> 14) & 1u)) {
+                    // the pair's syn0 row is busy (possibly held by another group of THIS wave, which can only drop it
+                    // once this group stops looping): drop whatever this round won and leave the pair for the next
+                    // trip through the outer loop — no waiting while holding, no spinning under divergence
+                    if (won) row_unlock<STRICT>(lane == 14 ? locks0 : locks1, t);
+                    abort_pair = true;
+                    break;
                 }
-                unsigned pending = 0;
+                const bool got_l1 = !have_l1;
+                const unsigned got13 = gotl & 0x1FFFu & pend13;
+                const bool gotf = flush_pending && ((gotl >> 13) & 1u);
+                Row<DCH> fr;
+                float my_hot_g = 0.f;                      // HOTMIX: lane j keeps the step of the chunk's j-th row when that is a head row
+                if (got_l1) rowA_load<DCH, 16, BIG>(l1, syn0, (gotl >> 14) & 1u ? last : 0, lane);
+                if (flush_pending) rowA_load<DCH, 16, BIG>(fr, syn1neg, gotf ? pend_row : word, lane);
+                have_l1 = true;
+                float acc = 0.f;                           // STRICT: the commit probes' returns
+                for (int base = 0; base < kc; base += NEG_BATCH) {
+                    const unsigned got = (got13 >> base) & ((1u << NEG_BATCH) - 1u);
+                    if (!got) continue;
+                    int32_t tg[NEG_BATCH];
+                    Row<DCH> rr[NEG_BATCH];
 #pragma unroll
-                for (int q = 0; q < NEG_BATCH; q++) pending |= (tg[q] >= 0 ? 1u : 0u) << q;
-                bool flush_pending = base == 0 && pend_row >= 0;
-                while (pending || !have_l1) {
-                    const int myq = lane - base;
-                    // a pair that already lost the race for its syn0 row once asks for that row ALONE until it has it:
-                    // otherwise the many waiting workers of a hot row keep grabbing (and dropping) the syn1neg rows the
-                    // row's current holder needs, and the holder starves (seen as a hang on a 3-row vocabulary)
-                    const bool others_ok = have_l1 || !l1_only;
-                    const bool want = (others_ok && myq >= 0 && myq < NEG_BATCH && lane < kc && ((pending >> myq) & 1u)) ||
-                                      (others_ok && lane == 13 && flush_pending) || (lane == 14 && !have_l1);
-                    const bool lockfree = HOTMIX && want && (t < hot_rows || (lane == 14 && p.syn0_free));     // a head row: no lock, atomics
-                    const bool won = (want && !lockfree) ? row_trylock(lane == 14 ? locks0 : locks1, t) : false;
-                    const unsigned long long bal = __ballot(won || lockfree);
-                    const unsigned gotl = (unsigned)(bal >> (threadIdx.x & 48)) & 0xFFFFu;
-                    if (!have_l1 && !((gotl >> 14) & 1u)) {
-                        // the pair's syn0 row is busy (possibly held by another group of THIS wave, which can only drop it
-                        // once this group stops looping): drop whatever this round won and leave the pair for the next
-                        // trip through the outer loop — no waiting while holding, no spinning under divergence
-                        if (won) row_unlock<STRICT>(lane == 14 ? locks0 : locks1, t);
-                        abort_pair = true;
-                        break;
-                    }
-                    const bool got_l1 = !have_l1;
-                    const unsigned got = (gotl >> base) & ((1u << NEG_BATCH) - 1u) & pending;
-                    const bool gotf = flush_pending && ((gotl >> 13) & 1u);
-                    Row<DCH> rr[NEG_BATCH], fr;
-                    float hot_g[NEG_BATCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
-                    if (got_l1) rowA_load<DCH, 16, BIG>(l1, syn0, (gotl >> 14) & 1u ? last : 0, lane);
+                    for (int q = 0; q < NEG_BATCH; q++) tg[q] = __shfl(t, (base + q) & 15, 16);
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16, BIG>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : word, lane);
-                    if (flush_pending) rowA_load<DCH, 16, BIG>(fr, syn1neg, gotf ? pend_row : word, lane);
-                    have_l1 = true;
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++)
                         if ((got >> q) & 1u) {
@@ -1042,25 +1046,14 @@ k_sgns_train_locked(TrainParams p) {
                             float g = sgns_g(f, 0.0f, alpha, s_exp);
                             row_axpy(neu, g, rr[q]);
                             if (HOTMIX && tg[q] < hot_rows) {
-                                hot_g[q] = g;              // the atomics go out after this round's locks have dropped (below)
+                                if (lane == base + q) my_hot_g = g;   // the atomics go out after this round's locks have dropped (below)
                             } else {
                                 row_axpy(rr[q], g, l1);
                                 rowA_store<DCH, 16, BIG>(rr[q], syn1neg, tg[q], lane);
                             }
                         }
-                    const bool hot_flush = HOTMIX && gotf && pend_row < hot_rows;
-                    if (gotf && !hot_flush) {
-                        const float* d = my_dh + (cur_buf ^ 1) * DCH * 64 + lane;
-#pragma unroll
-                        for (int q = 0; q < DCH; q++) {
-                            fr.v[q].x += d[q * 64]; fr.v[q].y += d[q * 64 + 16]; fr.v[q].z += d[q * 64 + 32]; fr.v[q].w += d[q * 64 + 48];
-                        }
-                        rowA_store<DCH, 16, BIG>(fr, syn1neg, pend_row, lane);
-                    }
-                    {   // every stored row is committed line by line (lane = 4*slot + line for DCH 2), then the locks drop
-                        float acc = 0.f;
+                    if (STRICT) {   // every stored row is committed line by line (lane = 4*slot + line for DCH 2) before the locks drop
                         const int n_lines = DCH * 2;
-                        if (STRICT) {
 #pragma unroll
                         for (int rep = 0; rep < (NEG_BATCH * DCH * 2 + 15) / 16; rep++) {
                             const int idx = lane + rep * 16, q = idx / n_lines, ln = idx - q * n_lines;
@@ -1069,25 +1062,34 @@ k_sgns_train_locked(TrainParams p) {
                             for (int qq = 0; qq < NEG_BATCH; qq++) if (qq == q && ((got >> qq) & 1u)) row = tg[qq];
                             if (row >= 0) acc += __hip_atomic_fetch_add(syn1neg.base + (size_t)row * (syn1neg.row_bytes / 4) + ln * 32, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                        if (gotf) acc += row_probe_lines(syn1neg, pend_row, lane, n_lines);
-                        }
-                        row_commit_wait(acc);
                     }
-                    if (won && lane != 14) row_unlock<STRICT>(locks1, t);
-                    if (HOTMIX) {
-                        // head rows: memory-side atomics, issued behind the commit so that the wait above (which drains every
-                        // outstanding memory operation of the wave) never sits on them while row locks are held
-#pragma unroll
-                        for (int q = 0; q < NEG_BATCH; q++)
-                            if (((got >> q) & 1u) && tg[q] < hot_rows) rowA_atomic_axpy<DCH>(syn1neg, tg[q], lane, hot_g[q], l1);
-                        if (hot_flush) ldsA_atomic_add<DCH>(syn1neg, pend_row, lane, my_dh + (cur_buf ^ 1) * DCH * 64);
-                    }
-                    pending &= ~got;
-                    if (gotf) { flush_pending = false; pend_row = -1; if (lane == 13) t = -1; }
-                    if (pending) __builtin_amdgcn_s_sleep(2);
                 }
-                base += NEG_BATCH;
-            } while (base < kc && !abort_pair);
+                const bool hot_flush = HOTMIX && gotf && pend_row < hot_rows;
+                if (gotf && !hot_flush) {
+                    const float* d = my_dh + (cur_buf ^ 1) * DCH * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < DCH; q++) {
+                        fr.v[q].x += d[q * 64]; fr.v[q].y += d[q * 64 + 16]; fr.v[q].z += d[q * 64 + 32]; fr.v[q].w += d[q * 64 + 48];
+                    }
+                    rowA_store<DCH, 16, BIG>(fr, syn1neg, pend_row, lane);
+                    if (STRICT) acc += row_probe_lines(syn1neg, pend_row, lane, DCH * 2);
+                }
+                row_commit_wait(acc);
+                if (won && lane != 14) row_unlock<STRICT>(locks1, t);
+                if (HOTMIX) {
+                    // head rows: memory-side atomics, issued behind the commit so that the wait above (which drains every
+                    // outstanding memory operation of the wave) never sits on them while row locks are held
+                    for (int j = 0; j < kc; j++) {
+                        const int32_t tj = __shfl(t, j, 16);
+                        const float gj = __shfl(my_hot_g, j, 16);
+                        if (((got13 >> j) & 1u) && tj < hot_rows) rowA_atomic_axpy<DCH>(syn1neg, tj, lane, gj, l1);
+                    }
+                    if (hot_flush) ldsA_atomic_add<DCH>(syn1neg, pend_row, lane, my_dh + (cur_buf ^ 1) * DCH * 64);
+                }
+                pend13 &= ~got13;
+                if (gotf) { flush_pending = false; pend_row = -1; if (lane == 13) t = -1; }
+                if (pend13) __builtin_amdgcn_s_sleep(2);
+            }
             kd += LK_NEG_LANES;
         } while (kd < K && !abort_pair);
         if (abort_pair) { retry_pair = true; __builtin_amdgcn_s_sleep(8); continue; }
@@ -1557,7 +1559,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
         const bool auto_locked = !hs && m->cfg.update_policy == 0 && m->V >= 262144 && (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision < 0.25;
         const bool auto_mixed = !hs && m->cfg.update_policy == 0 && !auto_locked && m->V >= 262144 && m->hot_rows_auto <= m->V / 8;
-        const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || m->cfg.update_policy == 7 || auto_locked || auto_mixed) ? ((m->cfg.update_policy == 7 || auto_mixed) ? DGE_HOTMIX_WAVES : (m->stride == 64 ? 4 : 3)) : 4;   // (rows of one chunk leave room for a 4th wave per SIMD in the lock kernel; a 5th under atomics gains nothing: cfg2 7.6e8 either way)   // what the kernel's VGPR budget keeps resident
+        const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || m->cfg.update_policy == 7 || auto_locked || auto_mixed) ? ((m->cfg.update_policy == 7 || auto_mixed) ? DGE_HOTMIX_WAVES : (m->stride == 64 ? 4 : DGE_LOCKED_WAVES)) : 4;   // (rows of one chunk leave room for a 4th wave per SIMD in the lock kernel; a 5th under atomics gains nothing: cfg2 7.6e8 either way)   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)m->n_cus * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
