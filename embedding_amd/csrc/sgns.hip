@@ -737,7 +737,7 @@ k_sgns_train(TrainParams p) {
 // instruction).  Measured on cfg3 (ablations in DESIGN.md §5.1): the write-through stores of the 4-byte-per-lane layout
 // that the float atomics need cost more than everything else in the pair; with 16-byte stores and 2 small atomic
 // requests per row (take / drop the lock) the pair is bounded by its HBM traffic again.
-// Lock order: the pair's syn0 row first (together with the first batch of syn1neg try-locks; if it is not won,
+// Lock order: the pair's syn0 row first (together with the first chunk of syn1neg try-locks; if it is not won,
 // everything won in that round is dropped again and the round is repeated), then syn1neg rows in try-lock rounds that
 // never wait while holding a syn1neg lock: no hold-and-wait cycle exists.
 // STRICT (policy 6): a row is committed with one returning atomic per 128-B line before its lock drops — no update is ever
