@@ -331,6 +331,23 @@ __device__ __forceinline__ void row_load(Row<DCH>& r, const TableView& t, int32_
         r.v[c].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, (int)(off + c * 256u + 192u), 0, AUX));
     }
 }
+// A batch slot without a row (a filler of a partial batch, a row whose lock was not won): the load is issued at an offset
+// beyond the descriptor's range, which the hardware answers with zeros WITHOUT touching memory — the instruction stream
+// stays branch-free and the filler costs no traffic (loading the centre's row instead cost cfg5 12 %, K = 20 at D = 256 19 %).
+#define DGE_OOB_OFFSET 0xFFFFFFF0u
+template <int DCH, int AUX, bool BIG>
+__device__ __forceinline__ void row_load_opt(Row<DCH>& r, const TableView& t, int32_t row, bool valid, int lane) {
+    uint32_t ro = 0;
+    const __amdgpu_buffer_rsrc_t rs = BIG ? row_view(t, valid ? row : 0, ro) : t.rsrc;
+    const uint32_t off = BIG ? ro + (uint32_t)lane * 4u : (uint32_t)row * t.row_bytes + (uint32_t)lane * 4u;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        r.v[c].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(valid ? off + c * 256u : DGE_OOB_OFFSET), 0, AUX));
+        r.v[c].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(valid ? off + c * 256u + 64u : DGE_OOB_OFFSET), 0, AUX));
+        r.v[c].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(valid ? off + c * 256u + 128u : DGE_OOB_OFFSET), 0, AUX));
+        r.v[c].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(valid ? off + c * 256u + 192u : DGE_OOB_OFFSET), 0, AUX));
+    }
+}
 template <int DCH, int AUX, bool BIG>
 __device__ __forceinline__ void row_store(const Row<DCH>& r, const TableView& t, int32_t row, int lane) {
     if (BIG) {
@@ -621,7 +638,7 @@ k_sgns_train(TrainParams p) {
                         tg[q] = (base + q < kc) ? v : -1;
                     }
 #pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX, BIG>(rr[q], syn1, tg[q] >= 0 ? tg[q] : 0, lane);
+                    for (int q = 0; q < NEG_BATCH; q++) row_load_opt<DCH, P::LOAD_AUX, BIG>(rr[q], syn1, tg[q], tg[q] >= 0, lane);
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++)
                         if (tg[q] >= 0) {
@@ -682,7 +699,7 @@ k_sgns_train(TrainParams p) {
                     // centre's own row, always valid), only the arithmetic and the store are guarded
                     Row<DCH> rr[NEG_BATCH];
 #pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX, BIG>(rr[q], syn1neg, tg[q] >= 0 ? tg[q] : word, lane);
+                    for (int q = 0; q < NEG_BATCH; q++) row_load_opt<DCH, P::LOAD_AUX, BIG>(rr[q], syn1neg, tg[q], tg[q] >= 0, lane);
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++)
                         if (tg[q] >= 0) {
@@ -775,6 +792,18 @@ __device__ __forceinline__ void rowA_load(Row<DCH>& r, const TableView& t, int32
         r.v[c] = make_float4(f.x, f.y, f.z, f.w);
     }
 }
+// (a batch slot without a row loads at DGE_OOB_OFFSET: no traffic)
+template <int DCH, int AUX, bool BIG>
+__device__ __forceinline__ void rowA_load_opt(Row<DCH>& r, const TableView& t, int32_t row, bool valid, int lane) {
+    uint32_t ro = 0;
+    const __amdgpu_buffer_rsrc_t rs = BIG ? row_view(t, valid ? row : 0, ro) : t.rsrc;
+    const uint32_t off = BIG ? ro + (uint32_t)lane * 16u : (uint32_t)row * t.row_bytes + (uint32_t)lane * 16u;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(valid ? off + c * 256u : DGE_OOB_OFFSET), 0, AUX));
+        r.v[c] = make_float4(f.x, f.y, f.z, f.w);
+    }
+}
 template <int DCH, int AUX, bool BIG>
 __device__ __forceinline__ void rowA_store(const Row<DCH>& r, const TableView& t, int32_t row, int lane) {
     if (BIG) {
@@ -851,6 +880,9 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
 }
 
 #define LK_NEG_LANES 13      /* lanes 0..12 draw negatives, lane 13 = pending centre flush, lane 14 = the pair's syn0 row */
+#ifndef LK_CHUNK
+#define LK_CHUNK 10          /* negatives per lock round: a multiple of NEG_BATCH, so no batch of a full chunk loads filler rows */
+#endif
 // 3 waves per SIMD is the measured optimum for D <= 128: 4 (128 VGPRs) spills 88 B per lane and runs 20 % slower, 2 runs 12 % slower
 template <int DCH, bool STRICT, bool BIG, bool HOTMIX, bool PART>
 __global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HOTMIX ? (PART ? 2 : DGE_HOTMIX_WAVES) : (DCH == 1 ? 4 : DGE_LOCKED_WAVES)) : ((HOTMIX && DCH <= 4) ? 2 : 1))
@@ -979,7 +1011,7 @@ k_sgns_train_locked(TrainParams p) {
         const bool l1_only = retry_pair;
         int kd = 0;
         do {    // chunks of up to 13 negatives (at least one pass so that the syn0 row is locked and loaded even when K == 0)
-            const int kc = min(LK_NEG_LANES, K - kd);
+            const int kc = min(LK_CHUNK, K - kd);
             int32_t t = -1;
             if (retry_pair && kd == 0) {
                 t = t_first;
@@ -1027,7 +1059,7 @@ k_sgns_train_locked(TrainParams p) {
                 Row<DCH> fr;
                 float my_hot_g = 0.f;                      // HOTMIX: lane j keeps the step of the chunk's j-th row when that is a head row
                 if (got_l1) rowA_load<DCH, 16, BIG>(l1, syn0, (gotl >> 14) & 1u ? last : 0, lane);
-                if (flush_pending) rowA_load<DCH, 16, BIG>(fr, syn1neg, gotf ? pend_row : word, lane);
+                if (flush_pending) rowA_load_opt<DCH, 16, BIG>(fr, syn1neg, pend_row, gotf, lane);
                 have_l1 = true;
                 float acc = 0.f;                           // STRICT: the commit probes' returns
                 for (int base = 0; base < kc; base += NEG_BATCH) {
@@ -1038,7 +1070,7 @@ k_sgns_train_locked(TrainParams p) {
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++) tg[q] = __shfl(t, (base + q) & 15, 16);
 #pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16, BIG>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : word, lane);
+                    for (int q = 0; q < NEG_BATCH; q++) rowA_load_opt<DCH, 16, BIG>(rr[q], syn1neg, tg[q], ((got >> q) & 1u) != 0, lane);
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++)
                         if ((got >> q) & 1u) {
@@ -1090,7 +1122,7 @@ k_sgns_train_locked(TrainParams p) {
                 if (gotf) { flush_pending = false; pend_row = -1; if (lane == 13) t = -1; }
                 if (pend13) __builtin_amdgcn_s_sleep(2);
             }
-            kd += LK_NEG_LANES;
+            kd += LK_CHUNK;
         } while (kd < K && !abort_pair);
         if (abort_pair) { retry_pair = true; __builtin_amdgcn_s_sleep(8); continue; }
         retry_pair = false;
