@@ -1070,11 +1070,7 @@ k_sgns_train_locked(TrainParams p) {
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++) tg[q] = __shfl(t, (base + q) & 15, 16);
 #pragma unroll
-#ifdef DGE_NO_OOB
-                    for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16, BIG>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : word, lane);
-#else
                     for (int q = 0; q < NEG_BATCH; q++) rowA_load_opt<DCH, 16, BIG>(rr[q], syn1neg, tg[q], ((got >> q) & 1u) != 0, lane);
-#endif
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++)
                         if ((got >> q) & 1u) {
