@@ -180,6 +180,7 @@ struct TrainParams {
     // multi-GPU block schedule (dge_model_set_partition): only pairs whose context row is in partition part_ctx and whose
     // centre row is in partition part_tgt (row % part_n) are trained; negatives are moved into partition part_tgt
     int32_t part_n, part_ctx, part_tgt;
+    int32_t filler_row;       // a row index whose offset is outside every table descriptor (see row_load): loads of it cost no traffic
     int32_t big_seg_shift;    // BIG: 0, or (tests) a smaller segment size than the 4 GiB window allows
     int32_t syn0_free;        // HOTMIX kernels: the pair's syn0 row is never locked either (read agent-scope, updated with atomics)
 };
@@ -331,23 +332,12 @@ __device__ __forceinline__ void row_load(Row<DCH>& r, const TableView& t, int32_
         r.v[c].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, (int)(off + c * 256u + 192u), 0, AUX));
     }
 }
-// A batch slot without a row (a filler of a partial batch, a row whose lock was not won): the load is issued at an offset
-// beyond the descriptor's range, which the hardware answers with zeros WITHOUT touching memory — the instruction stream
-// stays branch-free and the filler costs no traffic (loading the centre's row instead cost cfg5 12 %, K = 20 at D = 256 19 %).
-#define DGE_OOB_OFFSET 0xFFFFFFF0u
-template <int DCH, int AUX, bool BIG>
-__device__ __forceinline__ void row_load_opt(Row<DCH>& r, const TableView& t, int32_t row, bool valid, int lane) {
-    uint32_t ro = 0;
-    const __amdgpu_buffer_rsrc_t rs = BIG ? row_view(t, valid ? row : 0, ro) : t.rsrc;
-    const uint32_t off = BIG ? ro + (uint32_t)lane * 4u : (uint32_t)row * t.row_bytes + (uint32_t)lane * 4u;
-#pragma unroll
-    for (int c = 0; c < DCH; c++) {
-        r.v[c].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(valid ? off + c * 256u : DGE_OOB_OFFSET), 0, AUX));
-        r.v[c].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(valid ? off + c * 256u + 64u : DGE_OOB_OFFSET), 0, AUX));
-        r.v[c].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(valid ? off + c * 256u + 128u : DGE_OOB_OFFSET), 0, AUX));
-        r.v[c].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(valid ? off + c * 256u + 192u : DGE_OOB_OFFSET), 0, AUX));
-    }
-}
+// A batch slot without a row (a filler of a partial batch, a row whose lock was not won) loads the row `filler_row`: an index
+// whose byte offset lies beyond the table descriptor's range, which the hardware answers with zeros WITHOUT touching memory
+// (loading the centre's row instead cost cfg5 4 % and K = 20 at D = 256 12 %).  It is a ROW index, chosen once per launch, so the
+// loads keep the plain address arithmetic of a real row: selecting an out-of-range OFFSET per load instruction, or branching
+// between the two forms, made the common full batch 8-50 % slower.  Tables of 4 GiB and more (segment descriptors) keep the
+// centre's row as filler.
 template <int DCH, int AUX, bool BIG>
 __device__ __forceinline__ void row_store(const Row<DCH>& r, const TableView& t, int32_t row, int lane) {
     if (BIG) {
@@ -638,7 +628,7 @@ k_sgns_train(TrainParams p) {
                         tg[q] = (base + q < kc) ? v : -1;
                     }
 #pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) row_load_opt<DCH, P::LOAD_AUX, BIG>(rr[q], syn1, tg[q], tg[q] >= 0, lane);
+                    for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX, BIG>(rr[q], syn1, tg[q] >= 0 ? tg[q] : (BIG ? 0 : p.filler_row), lane);
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++)
                         if (tg[q] >= 0) {
@@ -699,7 +689,7 @@ k_sgns_train(TrainParams p) {
                     // centre's own row, always valid), only the arithmetic and the store are guarded
                     Row<DCH> rr[NEG_BATCH];
 #pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) row_load_opt<DCH, P::LOAD_AUX, BIG>(rr[q], syn1neg, tg[q], tg[q] >= 0, lane);
+                    for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX, BIG>(rr[q], syn1neg, tg[q] >= 0 ? tg[q] : (BIG ? word : p.filler_row), lane);
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++)
                         if (tg[q] >= 0) {
@@ -789,18 +779,6 @@ __device__ __forceinline__ void rowA_load(Row<DCH>& r, const TableView& t, int32
         // NOTE (hipcc 7.2): bit-casting the ELEMENTS of the loaded <4 x i32> lets the optimiser narrow the load to one
         // dword (wrong data in y/z/w); casting the whole vector keeps the dwordx4.
         const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(t.rsrc, (int)(off + c * 256u), 0, AUX));
-        r.v[c] = make_float4(f.x, f.y, f.z, f.w);
-    }
-}
-// (a batch slot without a row loads at DGE_OOB_OFFSET: no traffic)
-template <int DCH, int AUX, bool BIG>
-__device__ __forceinline__ void rowA_load_opt(Row<DCH>& r, const TableView& t, int32_t row, bool valid, int lane) {
-    uint32_t ro = 0;
-    const __amdgpu_buffer_rsrc_t rs = BIG ? row_view(t, valid ? row : 0, ro) : t.rsrc;
-    const uint32_t off = BIG ? ro + (uint32_t)lane * 16u : (uint32_t)row * t.row_bytes + (uint32_t)lane * 16u;
-#pragma unroll
-    for (int c = 0; c < DCH; c++) {
-        const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(valid ? off + c * 256u : DGE_OOB_OFFSET), 0, AUX));
         r.v[c] = make_float4(f.x, f.y, f.z, f.w);
     }
 }
@@ -1059,7 +1037,7 @@ k_sgns_train_locked(TrainParams p) {
                 Row<DCH> fr;
                 float my_hot_g = 0.f;                      // HOTMIX: lane j keeps the step of the chunk's j-th row when that is a head row
                 if (got_l1) rowA_load<DCH, 16, BIG>(l1, syn0, (gotl >> 14) & 1u ? last : 0, lane);
-                if (flush_pending) rowA_load_opt<DCH, 16, BIG>(fr, syn1neg, pend_row, gotf, lane);
+                if (flush_pending) rowA_load<DCH, 16, BIG>(fr, syn1neg, gotf ? pend_row : (BIG ? word : p.filler_row), lane);
                 have_l1 = true;
                 float acc = 0.f;                           // STRICT: the commit probes' returns
                 for (int base = 0; base < kc; base += NEG_BATCH) {
@@ -1070,7 +1048,7 @@ k_sgns_train_locked(TrainParams p) {
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++) tg[q] = __shfl(t, (base + q) & 15, 16);
 #pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) rowA_load_opt<DCH, 16, BIG>(rr[q], syn1neg, tg[q], ((got >> q) & 1u) != 0, lane);
+                    for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16, BIG>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : (BIG ? word : p.filler_row), lane);
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++)
                         if ((got >> q) & 1u) {
@@ -1579,6 +1557,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0;
     p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt; p.syn0_free = 0;
     p.big_seg_shift = 0;
+    p.filler_row = (int32_t)(0xFFFFFFF0u / ((uint32_t)m->stride * 4u)) - 1;      // offset + the largest in-row displacement stays below 2^32
     if (const char* e = getenv("DGE_BIG_SEG_SHIFT")) p.big_seg_shift = atoi(e);          // tests: several segments on a small table
     const bool part = m->part_n > 1;
     const bool hs = m->cfg.use_hs != 0;
