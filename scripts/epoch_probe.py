@@ -32,6 +32,8 @@ dst = (((src // R + 1) % T) * R + dreg).to(torch.int32)
 w = (1.0 + torch.floor(-20.0 * torch.log(torch.rand(Etot, generator=g0, device=dev, dtype=torch.float64).clamp_(min=1e-12))))
 g = E.DeviceGraph(0); g.add_edges_device(src.contiguous(), dst.contiguous(), w.contiguous()); del src, dst, w, reg, inside, local, anyw, dreg
 g.set_sources(np.arange(R, dtype=np.int32)); g.build_alias(False)
+if 'release' in sys.argv:
+    torch.cuda.empty_cache()          # hand torch's cached blocks back to the driver before libdge allocates its tables
 n = 10 * NV
 corpus = g.sample_walks_device(n, L, seed=5)
 counts = torch.zeros(NV, dtype=torch.int64, device=dev); corpus.count_tokens(NV, counts)

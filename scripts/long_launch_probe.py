@@ -1,3 +1,5 @@
+"""Investigation aid: per-launch kernel times of one epoch (10 launches of 1 M walks) under policy 5 on the bench graph, inside one
+process — stable to 0.3 % within a process, +-5 % between processes on one box."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 import embedding_amd as E
