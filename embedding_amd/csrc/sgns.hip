@@ -51,6 +51,7 @@ struct dge_model {
     int64_t total_words = 0;
     double neg_collision = 1.0;                 // sum of squared negative-sampling probabilities: P(two draws hit one row)
     int64_t hot_rows_auto = 0;                  // head rows that policy 7 keeps out of the lock protocol (see dge_model_create)
+    int64_t hot_rows_serial = 0;                // head rows whose own pairs, serialised by the row's lock, would outlast a launch
     int n_cus = 256;
     float *d_syn0 = nullptr, *d_syn1neg = nullptr, *d_snap = nullptr;
     // hierarchical softmax (cfg.use_hs): inner-node table and the Huffman paths in CSR form
@@ -1433,6 +1434,14 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
                 tail += q * q + pp * pp; H--;
             }
             m->hot_rows_auto = H;
+            // A second, sharper reason to keep a row out of the lock protocol: the pair holds its syn0 row's lock for its whole
+            // duration, so the pairs whose context is row i run one after the other — p_i * pairs of them, while the launch as a
+            // whole lasts pairs / W pair-times.  A row with W * p_i near 1 therefore becomes the critical path of the launch
+            // (measured: ONE vertex with 1e-4 of all tokens in an otherwise flat 1 M-row vocabulary — W * p = 1.2 — slows the lock
+            // kernel by 20-25 %; the bench graph's busiest row has 0.36).  Rows beyond 0.5 go to the atomics side.
+            int64_t Hs = 0;
+            while (Hs < V && W0 * (double)m->h_counts[(size_t)Hs] / (double)tw > 0.5) Hs++;
+            m->hot_rows_serial = Hs;
         }
         double d1 = 0.0;
         for (int64_t i = 0; i < V; i++) { d1 = (i == 0) ? pow((double)m->h_counts[0], power) / twp : d1 + pow((double)m->h_counts[(size_t)i], power) / twp; cum[(size_t)i] = d1; }
@@ -1569,7 +1578,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // (Hogwild's premise is sparse collisions: measured, a 2.3k-row table keeps 0.99 cosine to the in-order
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
         const bool auto_locked = !hs && m->cfg.update_policy == 0 && m->V >= 262144 && (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision < 0.25;
-        const bool auto_mixed = !hs && m->cfg.update_policy == 0 && !auto_locked && m->V >= 262144 && m->hot_rows_auto <= m->V / 8;
+        const bool auto_mixed = !hs && m->cfg.update_policy == 0 && m->V >= 262144 && ((!auto_locked && m->hot_rows_auto <= m->V / 8) || (auto_locked && m->hot_rows_serial > 0));
         const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || m->cfg.update_policy == 7 || auto_locked || auto_mixed) ? ((m->cfg.update_policy == 7 || auto_mixed) ? (m->stride <= 128 ? DGE_HOTMIX_WAVES : 2) : (m->stride == 64 ? 4 : DGE_LOCKED_WAVES)) : 4;   // (rows of one chunk leave room for a 4th wave per SIMD in the lock kernel; a 5th under atomics gains nothing: cfg2 7.6e8 either way)   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)m->n_cus * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
@@ -1587,10 +1596,12 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
         // In between (a skewed head over a long tail — cfg5, and what real trip data looks like) the head rows alone are
         // taken out of the lock protocol: policy 7.
-        pol = workers == 1 ? 100 : ((!hs && m->V >= 262144 && fail < 0.25) ? 5 : ((!hs && m->V >= 262144 && m->hot_rows_auto <= m->V / 8) ? 7 : 2));
+        pol = workers == 1 ? 100 : ((!hs && m->V >= 262144 && fail < 0.25) ? (m->hot_rows_serial > 0 ? 7 : 5) : ((!hs && m->V >= 262144 && m->hot_rows_auto <= m->V / 8) ? 7 : 2));
     }
     if (pol == 7) {
-        p.hot_rows = (int32_t)std::min<int64_t>(m->hot_rows_auto, m->V);
+        const double fail_all = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
+        // a flat vocabulary with a few busy rows: only those; a skewed one: the whole head
+        p.hot_rows = (int32_t)std::min<int64_t>((m->cfg.update_policy == 0 && fail_all < 0.25) ? m->hot_rows_serial : std::max(m->hot_rows_auto, m->hot_rows_serial), m->V);
         if (const char* e = getenv("DGE_HOT_ROWS")) { long long v = atoll(e); if (v >= 0) p.hot_rows = (int32_t)std::min<int64_t>(v, m->V); }     // tuning/ablation knob
     }
     if (pol == 100 || (workers == 1 && pol != 5 && pol != 6 && pol != 7 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses

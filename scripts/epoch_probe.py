@@ -30,6 +30,9 @@ anyw = torch.randint(0, R, (Etot,), generator=g0, device=dev, dtype=torch.int32)
 dreg = torch.where(inside, local.clamp_(max=R - 1), anyw)
 dst = (((src // R + 1) % T) * R + dreg).to(torch.int32)
 w = (1.0 + torch.floor(-20.0 * torch.log(torch.rand(Etot, generator=g0, device=dev, dtype=torch.float64).clamp_(min=1e-12))))
+if 'synth' in sys.argv:                 # the bench's own generator instead
+    from embedding_amd import synth
+    G = synth.flow_graph_torch(R, T, 100, dev); src, dst, w = G["src"], G["dst"], G["w"]; del G
 g = E.DeviceGraph(0); g.add_edges_device(src.contiguous(), dst.contiguous(), w.contiguous()); del src, dst, w, reg, inside, local, anyw, dreg
 g.set_sources(np.arange(R, dtype=np.int32)); g.build_alias(False)
 if 'release' in sys.argv:
@@ -37,11 +40,13 @@ if 'release' in sys.argv:
 n = 10 * NV
 corpus = g.sample_walks_device(n, L, seed=5)
 counts = torch.zeros(NV, dtype=torch.int64, device=dev); corpus.count_tokens(NV, counts)
-for pol in (5, 3):
+cf = counts.double()
+print("tokens %d, vocabulary(>=2) %d, max count %d, mean %.1f, std %.1f, top-10 counts %s" % (int(cf.sum()), int((counts >= 2).sum()), int(cf.max()), float(cf.mean()), float(cf.std()), torch.sort(counts, descending=True)[0][:10].tolist()), flush=True)
+for pol in (0, 5, 3):
     cfg = E.make_config(D, L, NV, negative=K, workers=0, update_policy=pol, epochs=(1000 if 'flat' in sys.argv else 1))
     m = E.SgnsModel.create(cfg, counts, 0)
     nb = n // 10; out = []
     for b in range(10):
         m.reset_stats(); m.train(corpus, b * nb, nb, walk_index_base=b * nb, total_walks=n); out.append(m.stats()["kernel_ms"])
-    print("community" if COMM else "random", "policy", pol, "per-launch ms:", " ".join("%.0f" % x for x in out), flush=True)
+    print("community" if COMM else "random", "policy", pol, "pairs/launch %d" % m.stats()["pairs"], (m.schedule() if pol == 0 else ""), "per-launch ms:", " ".join("%.0f" % x for x in out), flush=True)
     m.close()

@@ -75,7 +75,7 @@ if BLOCKS:
     print("%d ranks, block schedule      | AUC %.4f pos %.3f neg %.3f" % ((BLOCKS,) + auc(ms[0])), "| ran as", ms[0].schedule(), "| %.0f s for all ranks on one GPU" % (time.time() - t), flush=True)
     sys.exit(0)
 
-for pol in ((2, 7, 0) if ZIPF else (2, 5, 6, 1, 3)):
+for pol in ((2, 7, 0) if ZIPF else (0, 2, 5, 6, 1, 3)):
     cfg = E.make_config(D, L, NV, negative=K, workers=0, update_policy=pol)
     m = E.SgnsModel.create(cfg, counts, 0)
     t = time.time(); m.train(corpus); st = m.stats(); dt = time.time() - t
