@@ -63,3 +63,19 @@ def test_cpp_host_mirror_compiles_against_the_abi(tmp_path, dge):
     subprocess.check_call(["g++", "-O0", "-std=c++17", "-Wall", os.path.join(ROOT, "tests", "native", "host_mirror_test.cpp"), "-o", exe,
                            "-L" + libdir, "-l:libdge.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     assert os.path.exists(exe)
+
+
+def test_bench_workloads_and_traffic_table():
+    """bench.py's workload table names BASELINE.json's configurations, and profiles/traffic.json answers for the schedules the
+    default runs resolve to (the roofline.traffic field of the bench line)."""
+    import importlib.util, json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    assert {"cfg1", "cfg2", "cfg3", "cfg5"} <= set(bench.WORKLOADS)
+    w = bench.WORKLOADS["cfg3"]
+    assert w["R"] * w["T"] == 1000008 and w["dim"] == 128 and w["negative"] == 5 and w["L"] == 24      # the configuration the metric is quoted on
+    assert bench.measured_traffic("cfg3", "policy5", 1000.0) == 7319.0 * 1000.0
+    assert bench.measured_traffic("cfg5", "policy7", 1.0) > 45056 and bench.measured_traffic("cfg3", "hs", 1.0) > 0
+    assert bench.measured_traffic("cfg3", "policy99", 1.0) is None
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "edges" in base["metric"].lower() or "edges" in json.dumps(base).lower()
