@@ -1610,6 +1610,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     if (part) {
         // One block of the multi-GPU schedule: the live rows are V/part_n per table, so lock attempts collide part_n times
         // as often as on the whole table (measured on cfg3 with bench.py --sim-ranks, profiles/r01_block_schedule_sim.txt).
+        p.hot_rows = 0;                         // (the head/tail split of policy 7 is not used inside a block)
         if (pol == 0) pol = 20;
         else if (m->cfg.update_policy == 0) {
             const double per_worker = 5.0 * m->neg_collision * (double)m->part_n;
