@@ -134,7 +134,9 @@ typedef struct dge_train_config {
     int32_t update_policy;   /* how concurrent workers update the tables (MI355X has 8 L2s that are not coherent):
                                 0 = auto: 5 when the vocabulary has >= 262144 rows and its negative-sampling
                                     distribution is flat enough for lock attempts to succeed (expected failure
-                                    rate < 0.25); 7 when a head of at most V/8 rows carries the skew; else 2;
+                                    rate < 0.25) and no single row is busy enough to serialise its pairs behind its lock
+                                    (workers x p_row <= 0.5); 7 when such rows exist or a head of at most V/8 rows carries the
+                                    skew; else 2;
                                 1 = agent-scope row read-modify-write, write-through (last writer of a row wins);
                                 2 = agent-scope loads + memory-side float atomics (no update is lost);
                                 3 = plain cached accesses (debug only: every XCD trains a private stale copy);
