@@ -62,7 +62,22 @@ def main():
     ap.add_argument("--force-exchange", action="store_true", help="run the delta exchange even with one rank (plumbing check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (debugging the multi-rank plumbing)")
+    ap.add_argument("--rendezvous-check", action="store_true",
+                    help="ranks only meet (init_process_group, all-reduce, barrier) and rank 0 prints {\"n_gpus\": N, ...}: checks the "
+                         "launcher on a box without a GPU; nothing is measured")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` (the driver's command shape) with no torchrun environment: start the N ranks here.  The
+    # parent touches neither torch nor HIP, it waits for the children and exits with their status; rank 0 of the children
+    # prints the JSON line on the inherited stdout.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus (or run `python bench.py --gpus N`, "
+                 "which starts the ranks itself)" % (args.gpus, world_env))
+    if args.rendezvous_check:
+        return rendezvous_check(args)
 
     import numpy as np
     import torch
@@ -70,10 +85,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    N = world
+    N = world_env
     if args.backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)      # several ranks on one card (debug only)
     torch.cuda.set_device(local_rank)
@@ -273,6 +285,44 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """Start `n` ranks of this script under torch.distributed.run on this node (one per GPU, rendezvous on 127.0.0.1 at a free
+    port) and return their exit status.  Called before anything imports torch: the parent process never initialises a GPU."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_check(args):
+    """--rendezvous-check: the ranks meet over the chosen backend and count themselves; no GPU work, nothing measured."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    backend = args.backend if (args.backend == "gloo" or torch.cuda.is_available()) else "gloo"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    one = torch.ones(1, dtype=torch.int64, device="cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(one)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "SGNS training edges/sec", "value": None, "unit": "edges/s", "n_gpus": int(one.item()),
+                          "rendezvous": "ok", "backend": backend}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def measured_traffic(workload, policy, pairs_per_launch):       # policy: "policy5", "policy7", "hs", ...

@@ -910,6 +910,20 @@ k_sgns_train_locked(TrainParams p) {
     if (PART) walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
 
 #define LK_TOK(idx) walk_tok(toks_in_regs, sen, (idx), tk0, tk1, tk2, tk3)
+    // positive target (label 1): the centre's row lives in registers for all its contexts, its accumulated delta in LDS
+#define LK_POSITIVE()                                                                                                  \
+    do {                                                                                                               \
+        const float f_ = row_dot(l1, h);                                                                               \
+        const float g_ = sgns_g(f_, 1.0f, alpha, s_exp);                                                               \
+        row_axpy(neu, g_, h);                                                                                          \
+        row_axpy(h, g_, l1);                                                                                           \
+        float* d_ = my_dh + cur_buf * DCH * 64 + lane;                                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < DCH; q_++) {                                                           \
+            d_[q_ * 64] = fmaf(g_, l1.v[q_].x, d_[q_ * 64]); d_[q_ * 64 + 16] = fmaf(g_, l1.v[q_].y, d_[q_ * 64 + 16]); \
+            d_[q_ * 64 + 32] = fmaf(g_, l1.v[q_].z, d_[q_ * 64 + 32]); d_[q_ * 64 + 48] = fmaf(g_, l1.v[q_].w, d_[q_ * 64 + 48]); \
+        }                                                                                                              \
+        h_dirty = true;                                                                                                \
+    } while (0)
 #define LK_CLOSE_CENTRE()                                                                                              \
     do {                                                                                                               \
         if (h_dirty) {                                                                                                 \
@@ -980,7 +994,13 @@ k_sgns_train_locked(TrainParams p) {
 
         Row<DCH> l1, neu;
         if (new_centre) {
-            rowA_load<DCH, 16, BIG>(h, syn1neg, word, lane);       // unlocked read: stale by at most the updates in flight
+            // the previous centre's delta is still parked in LDS; when it belongs to THIS row (the same token twice in a walk)
+            // it goes out first, so that one worker alone reads exactly what the sequential loop would
+            if (pend_row == word) {
+                flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows);
+                pend_row = -1;
+            }
+            rowA_load<DCH, 16, BIG>(h, syn1neg, word, lane);       // unlocked read: stale by at most the OTHER workers' updates in flight
             float* d = my_dh + cur_buf * DCH * 64 + lane;
 #pragma unroll
             for (int q = 0; q < DCH; q++) { d[q * 64] = 0.f; d[q * 64 + 16] = 0.f; d[q * 64 + 32] = 0.f; d[q * 64 + 48] = 0.f; }
@@ -1018,7 +1038,8 @@ k_sgns_train_locked(TrainParams p) {
                 // otherwise the many waiting workers of a hot row keep grabbing (and dropping) the syn1neg rows the
                 // row's current holder needs, and the holder starves (seen as a hang on a 3-row vocabulary)
                 const bool others_ok = have_l1 || !l1_only;
-                const bool want = (others_ok && lane < kc && ((pend13 >> lane) & 1u)) ||
+                // (a negative that drew the row whose flush is still pending lets the flush go first: word2vec order)
+                const bool want = (others_ok && lane < kc && ((pend13 >> lane) & 1u) && !(flush_pending && t == pend_row)) ||
                                   (others_ok && lane == 13 && flush_pending) || (lane == 14 && !have_l1);
                 const bool lockfree = HOTMIX && want && (t < hot_rows || (lane == 14 && p.syn0_free));     // a head row: no lock, atomics
                 const bool won = (want && !lockfree) ? row_trylock(lane == 14 ? locks0 : locks1, t) : false;
@@ -1040,6 +1061,7 @@ k_sgns_train_locked(TrainParams p) {
                 if (got_l1) rowA_load<DCH, 16, BIG>(l1, syn0, (gotl >> 14) & 1u ? last : 0, lane);
                 if (flush_pending) rowA_load<DCH, 16, BIG>(fr, syn1neg, gotf ? pend_row : (BIG ? word : p.filler_row), lane);
                 have_l1 = true;
+                bool do_pos = got_l1;                      // the positive target comes first (word2vec order), once l1 is here
                 float acc = 0.f;                           // STRICT: the commit probes' returns
                 for (int base = 0; base < kc; base += NEG_BATCH) {
                     const unsigned got = (got13 >> base) & ((1u << NEG_BATCH) - 1u);
@@ -1050,6 +1072,7 @@ k_sgns_train_locked(TrainParams p) {
                     for (int q = 0; q < NEG_BATCH; q++) tg[q] = __shfl(t, (base + q) & 15, 16);
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16, BIG>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : (BIG ? word : p.filler_row), lane);
+                    if (do_pos) { do_pos = false; LK_POSITIVE(); }     // behind the batch's loads: they are in flight meanwhile
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++)
                         if ((got >> q) & 1u) {
@@ -1075,6 +1098,7 @@ k_sgns_train_locked(TrainParams p) {
                         }
                     }
                 }
+                if (do_pos) LK_POSITIVE();                 // (no row of the chunk was won in this round, or K == 0)
                 const bool hot_flush = HOTMIX && gotf && pend_row < hot_rows;
                 if (gotf && !hot_flush) {
                     const float* d = my_dh + (cur_buf ^ 1) * DCH * 64 + lane;
@@ -1106,19 +1130,6 @@ k_sgns_train_locked(TrainParams p) {
         if (abort_pair) { retry_pair = true; __builtin_amdgcn_s_sleep(8); continue; }
         retry_pair = false;
 
-        {   // positive target: the centre's row lives in registers, its delta in LDS
-            float f = row_dot(l1, h);
-            float g = sgns_g(f, 1.0f, alpha, s_exp);
-            row_axpy(neu, g, h);
-            row_axpy(h, g, l1);
-            float* d = my_dh + cur_buf * DCH * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < DCH; q++) {
-                d[q * 64] = fmaf(g, l1.v[q].x, d[q * 64]); d[q * 64 + 16] = fmaf(g, l1.v[q].y, d[q * 64 + 16]);
-                d[q * 64 + 32] = fmaf(g, l1.v[q].z, d[q * 64 + 32]); d[q * 64 + 48] = fmaf(g, l1.v[q].w, d[q * 64 + 48]);
-            }
-            h_dirty = true;
-        }
 #pragma unroll
         for (int q = 0; q < DCH; q++) {
             l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
@@ -1142,6 +1153,7 @@ k_sgns_train_locked(TrainParams p) {
     LK_CLOSE_CENTRE();
     if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows);
 #undef LK_TOK
+#undef LK_POSITIVE
 #undef LK_CLOSE_CENTRE
     if (lane == 0) {
         if (my_pairs) atomicAdd(&p.counters[0], my_pairs);

@@ -30,3 +30,17 @@ def test_bench_emits_one_json_line_with_the_contract_fields():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "edges/s" and c["sample"]
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2` with no torchrun environment starts its two ranks itself; over gloo they share this box's one card and run the
+    block schedule for real (RCCL needs one GPU per rank: that run is the driver's).  n_gpus must equal --gpus."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "tiny", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert "block schedule x2" in d["config"]["parallelism"]

@@ -124,11 +124,13 @@ def test_random_graph_alias_and_walks_bit_exact(dge, oracle, seed):
             assert dd == c["n"] * c["L"], (seed, c)
 
 
-@pytest.mark.parametrize("seed", list(range(100, 112)))
+@pytest.mark.parametrize("seed", list(range(100, 124)))
 def test_random_configuration_lock_kernels_one_worker(dge, oracle, seed, monkeypatch):
     """The same random configurations through the commit-lock kernel (policy 5), its strict form (6) and the mixed policy (7, with a
-    random head size), one worker each: they track the sequential result closely (not bit for bit: their positive target comes last,
-    the head rows of policy 7 are updated by atomics), with the exact pair count."""
+    random head size), ONE worker each: with nobody else on the tables the lock kernels run the sequential word2vec schedule — positive
+    target first, a parked centre delta flushed before its row is read again — so they agree with the oracle to rounding (not bit for bit:
+    the centre's delta is summed in LDS and added once, the head rows of policy 7 are updated by float atomics): north_star's 1e-4 cosine
+    on EVERY row of both tables, with the exact pair count.  (SGNS half of the oracle: a restatement, parity unpinned — DESIGN.md §3.)"""
     ids, NV, cfg, _ = _case(seed)
     om = oracle.train_sgns(ids, NV, cfg["dim"], cfg["window"], negative=cfg["negative"], min_count=cfg["min_count"], epochs=cfg["epochs"],
                            seed=cfg["seed"], table_size=cfg["table_size"], arith=0)
@@ -144,9 +146,5 @@ def test_random_configuration_lock_kernels_one_worker(dge, oracle, seed, monkeyp
         if om.V:
             from helpers import cosine_rows
             assert np.isfinite(syn0).all()
-            # not bit-exact by design: the positive target is trained after the negatives, and the centre's row lives in registers
-            # for all its contexts; the drift shows on rows trained tens of thousands of times (9-row vocabularies) and in 2-D cosines
             c0 = cosine_rows(syn0, om.syn0); c1 = cosine_rows(dm.syn1neg() + 1e-30, om.syn1neg + 1e-30)
-            assert np.median(c0) > 1 - 1e-3 and np.median(c1) > 1 - 1e-3, (seed, pol, cfg)
-            if cfg["dim"] > 2:
-                assert c0.min() > 0.97 and c1.min() > 0.97, (seed, pol, cfg)
+            assert c0.min() > 1 - 1e-4 and c1.min() > 1 - 1e-4, ("1 - cosine: syn0 %.3g, syn1neg %.3g" % (1 - c0.min(), 1 - c1.min()), seed, pol, cfg)

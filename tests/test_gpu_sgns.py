@@ -207,7 +207,7 @@ def test_commit_lock_protocol_conservation(dge):
 
 
 def test_locked_policies_match_the_in_order_result(dge, oracle):
-    """Policies 5 and 6 (layout with 16 B per lane, positive target last) against the oracle: one worker reproduces the
+    """Policies 5 and 6 (layout with 16 B per lane, the centre's delta summed in LDS) against the oracle: one worker reproduces the
     sequential word2vec result to rounding, 16 workers stay within Hogwild noise."""
     walks, NV = _walks(oracle, dge, n=1500)
     for dim in (64, 128, 20, 256):
@@ -384,14 +384,15 @@ def test_many_negatives_bit_exact(dge, oracle, negative, dim):
     om, dm = _fit_both(oracle, dge, walks, NV, arith=1, dim=dim, negative=negative)
     assert dm.stats()["pairs"] == om.pairs
     assert np.array_equal(bits(dm.vectors()[0]), bits(om.syn0)) and np.array_equal(bits(dm.syn1neg()), bits(om.syn1neg))
-    # the lock kernel: one worker follows the sequential result to rounding (its positive target comes last); 16 workers on this
+    # the lock kernel: one worker follows the sequential result to rounding; 16 workers on this
     # 194-row vocabulary touch a third of all rows per pair, so only termination, the pair count and finiteness are checked
     o0 = oracle.train_sgns(walks, NV, dim, 6, negative=negative, table_size=20011, arith=0)
     for workers in (1, 16):
         d5 = dge.SgnsModel.fit(walks, dge.make_config(dim, 6, NV, negative=negative, workers=workers, table_size=20011, update_policy=5), 0)
         assert d5.stats()["pairs"] == om.pairs and np.isfinite(d5.vectors()[0]).all()
         if workers == 1:
-            assert cosine_rows(d5.vectors()[0], o0.syn0).min() > 1 - 1e-3
+            c0 = cosine_rows(d5.vectors()[0], o0.syn0).min(); c1 = cosine_rows(d5.syn1neg() + 1e-30, o0.syn1neg + 1e-30).min()
+            assert c0 > 1 - 1e-4 and c1 > 1 - 1e-4, (1 - c0, 1 - c1)
 
 
 @pytest.mark.parametrize("negative", [0, 1, 13, 14, 27])
