@@ -42,6 +42,10 @@ SIGNATURES = {
     "dge_graph_add_edges": (_int, [_vp, _vp, _vp, _vp, _i64]),
     "dge_graph_add_edges_device": (_int, [_vp, _vp, _vp, _vp, _i64]),
     "dge_graph_set_sources": (_int, [_vp, _vp, _i64, _int]),
+    "dge_graph_reserve_vertices": (_int, [_vp, _i32]),
+    "dge_graph_set_out_degree": (_int, [_vp, _vp, _i32]),
+    "dge_graph_set_source_weight_sum": (_int, [_vp, _dbl]),
+    "dge_graph_get_csr": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64]),
     "dge_graph_keep_top_k": (_int, [_vp, _i32]),
     "dge_graph_build_alias": (_int, [_vp, _int]),
     "dge_graph_num_vertices": (_int, [_vp, _P(_i32)]),

@@ -81,6 +81,8 @@ struct dge_graph {
     int64_t S = 0;
     int32_t* d_srcv = nullptr;
     double src_weight_sum = 0.0;
+    int src_stream_sum = 0;          // how set_sources summed (0 running +=, 1 DoubleStream.sum())
+    bool src_sum_fixed = false;      // the host assigned sourceWeightSum itself (dge_graph_set_source_weight_sum)
     double* d_src_w = nullptr;
     double* d_src_prob = nullptr;
     int32_t* d_src_alias = nullptr;

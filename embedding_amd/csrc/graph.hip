@@ -462,7 +462,70 @@ extern "C" int dge_graph_set_sources(dge_graph* g, const int32_t* v, int64_t n, 
     DGE_HIP(hipMemcpyAsync(&g->src_weight_sum, d_sum.p, sizeof(double), hipMemcpyDeviceToHost, g->stream));
     DGE_HIP(hipStreamSynchronize(g->stream));
     g->S = n;
+    g->src_stream_sum = stream_sum ? 1 : 0; g->src_sum_fixed = false;
     g->alias_built = false;
+    return DGE_OK;
+}
+
+extern "C" int dge_graph_reserve_vertices(dge_graph* g, int32_t n) {
+    if (!g || n < 0) DGE_FAIL(DGE_ERR_ARG, "dge_graph_reserve_vertices: bad argument");
+    if (n - 1 > g->max_id) {
+        if (g->csr_built && g->E != g->n_coo) DGE_FAIL(DGE_ERR_STATE, "dge_graph_reserve_vertices: the store was pruned by keep_top_k");
+        DGE_HIP(hipSetDevice(g->device));
+        g->max_id = n - 1;
+        free_csr(g);
+    }
+    return DGE_OK;
+}
+
+// Vertex.outDegree is a public field of the reference (J/LayeredGraph.java:35; J/SpatialGraph.java:33 assigns it): a host that
+// keeps that field hands its values over instead of having the running sums recomputed
+extern "C" int dge_graph_set_out_degree(dge_graph* g, const double* out_degree, int32_t n) {
+    if (!g || !out_degree || n < 0) DGE_FAIL(DGE_ERR_ARG, "dge_graph_set_out_degree: bad argument");
+    int rc = dge_graph_ensure_csr(g);
+    if (rc) return rc;
+    if (n != g->V) DGE_FAIL(DGE_ERR_ARG, "dge_graph_set_out_degree: %d values for %d vertices", n, g->V);
+    if (n) DGE_HIP(hipMemcpyAsync(g->d_outdeg, out_degree, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    g->alias_built = false;
+    if (g->S > 0) {              // source weights are outDegree values: refresh them (and their sum, unless the host fixed it)
+        dge_tmp<double> d_sum;
+        if ((rc = d_sum.alloc(1))) return rc;
+        double sum = 0.0;
+        hipLaunchKernelGGL(k_sources, dim3(1), dim3(64), 0, g->stream, g->d_srcv, g->S, g->d_outdeg, g->d_src_w, g->src_stream_sum, d_sum.p);
+        DGE_HIP(hipMemcpyAsync(&sum, d_sum.p, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+        DGE_HIP(hipStreamSynchronize(g->stream));
+        if (!g->src_sum_fixed) g->src_weight_sum = sum;
+    }
+    DGE_HIP(hipStreamSynchronize(g->stream));
+    return DGE_OK;
+}
+
+// LayeredGraph.sourceWeightSum is a protected field that subclasses assign (J/SpatialGraph.java:57,83)
+extern "C" int dge_graph_set_source_weight_sum(dge_graph* g, double sum) {
+    if (!g) DGE_FAIL(DGE_ERR_ARG, "dge_graph_set_source_weight_sum: null graph");
+    g->src_weight_sum = sum; g->src_sum_fixed = true; g->alias_built = false;
+    return DGE_OK;
+}
+
+extern "C" int dge_graph_get_csr(const dge_graph* gc, int64_t* row_ptr, int32_t* nbr, double* weight, double* prob, int32_t* alias,
+                                 double* out_degree, int32_t cap_vertices, int64_t cap_edges) {
+    dge_graph* g = const_cast<dge_graph*>(gc);
+    if (!g) DGE_FAIL(DGE_ERR_ARG, "dge_graph_get_csr: null graph");
+    int rc = dge_graph_ensure_csr(g);
+    if (rc) return rc;
+    if ((row_ptr || out_degree) && cap_vertices < g->V) DGE_FAIL(DGE_ERR_CAP, "dge_graph_get_csr: %d vertices exceed cap %d", g->V, cap_vertices);
+    if ((nbr || weight || prob || alias) && cap_edges < g->E) DGE_FAIL(DGE_ERR_CAP, "dge_graph_get_csr: %lld edges exceed cap %lld", (long long)g->E, (long long)cap_edges);
+    if ((prob || alias) && !g->alias_built) DGE_FAIL(DGE_ERR_STATE, "dge_graph_get_csr: alias tables not built");
+    DGE_HIP(hipSetDevice(g->device));
+    DGE_HIP(hipStreamSynchronize(g->stream));
+    if (row_ptr) DGE_HIP(hipMemcpy(row_ptr, g->d_row_ptr, ((size_t)g->V + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (out_degree && g->V) DGE_HIP(hipMemcpy(out_degree, g->d_outdeg, (size_t)g->V * sizeof(double), hipMemcpyDeviceToHost));
+    if (g->E) {
+        if (nbr) DGE_HIP(hipMemcpy(nbr, g->d_nbr, (size_t)g->E * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (weight) DGE_HIP(hipMemcpy(weight, g->d_w, (size_t)g->E * sizeof(double), hipMemcpyDeviceToHost));
+        if (prob) DGE_HIP(hipMemcpy(prob, g->d_prob, (size_t)g->E * sizeof(double), hipMemcpyDeviceToHost));
+        if (alias) DGE_HIP(hipMemcpy(alias, g->d_alias, (size_t)g->E * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     return DGE_OK;
 }
 
@@ -511,6 +574,7 @@ extern "C" int dge_graph_keep_top_k(dge_graph* g, int32_t k) {
         hipLaunchKernelGGL(k_sources, dim3(1), dim3(64), 0, g->stream, g->d_srcv, g->S, g->d_outdeg, g->d_src_w, 1, d_sum.p);
         DGE_HIP(hipMemcpyAsync(&g->src_weight_sum, d_sum.p, sizeof(double), hipMemcpyDeviceToHost, g->stream));
         DGE_HIP(hipStreamSynchronize(g->stream));
+        g->src_stream_sum = 1; g->src_sum_fixed = false;
     }
     return DGE_OK;
 }

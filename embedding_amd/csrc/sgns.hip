@@ -24,19 +24,8 @@
 
 #include "dge_algos.h"
 #include "dge_internal.h"
+#include "sgns_kernels.h"
 
-#define EXP_TABLE_SIZE 1000
-#define MAX_EXP 6
-#define NEG_BATCH 5
-#ifndef DGE_LOCKED_WAVES
-#define DGE_LOCKED_WAVES 3
-#endif
-#ifndef DGE_HOTMIX_WAVES
-#define DGE_HOTMIX_WAVES 3
-#endif
-#ifndef DGE_HS_WAVES
-#define DGE_HS_WAVES 4
-#endif
 
 struct EventPair { hipEvent_t a, b; int kind; };
 
@@ -156,1009 +145,6 @@ __global__ void k_remap_compact(const int32_t* __restrict__ walks, int64_t n_row
     }
     for (int j = len; j < L; j++) out[j] = -1;
     len_out[r] = len;
-}
-
-// ------------------------------------------------------------------------------------------ trainer
-struct TrainParams {
-    const int32_t* sen; const int64_t* len; const int64_t* wb;
-    float* syn0; float* syn1neg; const int32_t* table; const float* exp_table;
-    int64_t n_rows; int32_t L, W, K, stride;
-    int64_t V, T;
-    uint64_t seed;
-    int64_t gidx_base;        // (epoch*total_walks + walk_index_base): RNG stream key of row 0
-    int64_t words_done_base;  // epoch*total_words + words_before
-    int64_t all_words;        // epochs*total_words
-    double words_scale;
-    float alpha0, min_alpha;
-    int64_t n_workers;
-    unsigned long long* counters;
-    int* locks;               // one commit-lock word per syn1neg row (all zero between launches)
-    float* syn1;              // hierarchical softmax: inner-node rows, Huffman paths (null when off)
-    const int64_t* hs_off; const int32_t* hs_points; const uint64_t* hs_codes;
-    int32_t hs_hot0, hs_n_hot; // inner nodes [hs_hot0, hs_hot0 + hs_n_hot) — the ones nearest the root — combine in LDS
-    int32_t hs_drain;         // an LDS accumulator is drained to memory every hs_drain additions
-    int32_t hot_rows;         // policy 7: vocabulary rows [0, hot_rows) — the most frequent — are never locked, they take atomics
-    // multi-GPU block schedule (dge_model_set_partition): only pairs whose context row is in partition part_ctx and whose
-    // centre row is in partition part_tgt (row % part_n) are trained; negatives are moved into partition part_tgt
-    int32_t part_n, part_ctx, part_tgt;
-    int32_t filler_row;       // a row index whose offset is outside every table descriptor (see row_load): loads of it cost no traffic
-    int32_t big_seg_shift;    // BIG: 0, or (tests) a smaller segment size than the 4 GiB window allows
-    int32_t syn0_free;        // HOTMIX kernels: the pair's syn0 row is never locked either (read agent-scope, updated with atomics)
-};
-
-// PART: which of a walk's (<= 64, register-resident) tokens lie in partition `part`: bit j of the result = token j.
-// Lane j of the group holds tokens j, j+16, j+32, j+48; a ballot collects 16 of them at a time.
-__device__ __forceinline__ uint64_t part_token_mask(int32_t tk0, int32_t tk1, int32_t tk2, int32_t tk3, int32_t n, int32_t part) {
-    const int sh = threadIdx.x & 48;
-    uint64_t m = (uint64_t)((__ballot(tk0 >= 0 && tk0 % n == part) >> sh) & 0xFFFFull);
-    m |= (uint64_t)((__ballot(tk1 >= 0 && tk1 % n == part) >> sh) & 0xFFFFull) << 16;
-    m |= (uint64_t)((__ballot(tk2 >= 0 && tk2 % n == part) >> sh) & 0xFFFFull) << 32;
-    m |= (uint64_t)((__ballot(tk3 >= 0 && tk3 % n == part) >> sh) & 0xFFFFull) << 48;
-    return m;
-}
-// PART: a block visits every walk of the batch for a few of its pairs (at 8 ranks: 6 of 383), so the next walk's length,
-// word offset and tokens are fetched while the current walk is trained
-__device__ __forceinline__ void walk_fetch(const TrainParams& p, int64_t w, int L, int lane, int& len, int64_t& wb,
-                                           int32_t& t0, int32_t& t1, int32_t& t2, int32_t& t3) {
-    len = 0; wb = 0; t0 = t1 = t2 = t3 = -1;
-    if (w < p.n_rows) {
-        len = (int)p.len[w]; wb = p.wb[w];
-        const int32_t* sen = p.sen + w * L;
-        if (lane < L) t0 = sen[lane];
-        if (lane + 16 < L) t1 = sen[lane + 16];
-        if (lane + 32 < L) t2 = sen[lane + 32];
-        if (lane + 48 < L) t3 = sen[lane + 48];
-    }
-}
-__device__ __forceinline__ int first_bit_from(uint64_t m, int from, int none) {       // lowest set bit >= from, else `none`
-    const uint64_t r = from < 64 ? (m >> from) : 0ull;
-    return r ? from + (int)__builtin_ctzll(r) : none;
-}
-
-// a negative drawn from the whole table, moved to the row of partition `part` nearest below it: rows are ordered by
-// count, so the row keeps (almost exactly) the frequency rank it was drawn with
-__device__ __forceinline__ int32_t part_row(int32_t t, int32_t n, int32_t part, int64_t V) {
-    int32_t r = (t / n) * n + part;
-    if (r >= V) r -= n;
-    return r;
-}
-
-template <int DCH> struct Row { float4 v[DCH]; };
-typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// Cache policy of the table traffic.  The eight XCDs have private L2s that are not coherent with each other, and a
-// plain store parks its line dirty in the writer's L2: with plain loads/stores every XCD would train its own stale
-// copy of a row and the last write-back would win (measured: >90 % of the updates lost on a 10 MB table).  So the
-// Hogwild schedules move rows with agent-scope (sc1) loads and either write-through (sc1) stores or memory-side
-// float atomics; the in-order schedule (one worker, one CU) keeps plain accesses.
-//   POL 0  plain loads / plain stores            (workers == 1: bit-exact with the oracle)
-//   POL 1  sc1 loads / sc1 write-through stores  (Hogwild, row granularity: last writer of a row wins)
-//   POL 2  sc1 loads / float atomic adds         (Hogwild, element granularity: no update is lost)
-//   (policy 5, every row update under a per-row commit lock, has its own kernel: k_sgns_train_locked)
-template <int POL> struct Policy {
-    static constexpr int LOAD_AUX = POL == 0 ? 0 : 16;    // aux bit 4 = sc1 on gfx950
-    static constexpr int STORE_AUX = POL == 0 ? 0 : 16;
-    static constexpr bool ATOMIC = POL == 2;              // updates are float atomics
-};
-
-// try-lock of one row: true when this lane took it.  The caller makes the row's load address depend on the result,
-// so the load cannot be issued before the exchange has returned.
-__device__ __forceinline__ bool row_trylock(int* locks, int32_t row) { return atomicExch(&locks[row], 1) == 0; }
-// the row's write-through stores are drained (vmcnt(0), which the workgroup-scope release fence emits) before the
-// lock word is cleared with an agent-scope store
-// Before a lock word is cleared, the row's stores must be visible to every XCD.  Draining the wave's stores
-// (s_waitcnt vmcnt(0)) is NOT enough even for sc1 "write-through" stores: measured with dge_selftest_locked_rows,
-// 256..1024 hot rows lose up to ~40 of 10^4 increments per row that way.  None are lost with an agent-scope release
-// (buffer_wbl2 sc1 + vmcnt(0)) — but that fence costs the trainer a factor 19 — and none with the per-line commit
-// probes below, with or without an acquire on the reading side (the sc1 loads are enough there).
-// consume the probes' return values: forces the s_waitcnt on them (and, being a workgroup-scope release, on the stores)
-__device__ __forceinline__ void row_commit_wait(float probes) {
-    asm volatile("" ::"v"(probes));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-}
-// STRICT commit: the row is known to be in memory (probes), the lock word is cleared by a memory-side atomic and so
-// changes promptly where the try-lock exchanges execute.  Relaxed commit: the lock word follows the row's write-through
-// stores as one more write-through store — the same path, which is what keeps the overtaking of data by a re-lock rare
-// (measured: an atomic unlock there loses 9 % of a 1024-row hot set's updates instead of 1.5 %).
-template <bool STRICT>
-__device__ __forceinline__ void row_unlock(int* locks, int32_t row) {
-    if (STRICT) (void)__hip_atomic_exchange(&locks[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else __hip_atomic_store(&locks[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ float group16_sum(float p) {
-    p += __shfl_xor(p, 1);
-    p += __shfl_xor(p, 2);
-    p += __shfl_xor(p, 4);
-    p += __shfl_xor(p, 8);
-    return p;
-}
-
-// one table seen through a buffer descriptor: byte offset of (row, lane) = row*stride*4 + lane*16 (< 4 GiB)
-// Tables of 4 GiB and more (cfg5: 10 M rows x 256 floats = 10 GB) do not fit one descriptor's 32-bit window: their
-// accesses build the descriptor of the row's SEGMENT (a power-of-two number of rows that fits a 4 GiB window).  That
-// descriptor can differ between the four groups of a wave, so the compiler serialises the instruction per distinct
-// segment (a "waterfall"); the common case keeps the single table-wide descriptor (template parameter BIG of the kernels).
-struct TableView {
-    __amdgpu_buffer_rsrc_t rsrc;
-    float* base;
-    uint32_t row_bytes;
-    uint32_t seg_shift;       // BIG: rows per segment = 1 << seg_shift (the largest power of two whose rows fit a 4 GiB window)
-    bool big;
-};
-__device__ __forceinline__ TableView make_view(float* base, int64_t rows, int stride, int seg_shift_override = 0) {
-    TableView t;
-    t.base = base;
-    t.row_bytes = (uint32_t)stride * 4u;
-    t.big = (uint64_t)rows * (uint64_t)stride * 4ull >= 0xFFFFFFFFull;
-    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, t.big ? 0 : (int)(uint32_t)(rows * stride * 4), 0x00020000);   // unused when BIG
-    t.seg_shift = 31u - (uint32_t)__builtin_clz(0xFFFFFFFFu / t.row_bytes);
-    if (seg_shift_override > 0 && (uint32_t)seg_shift_override < t.seg_shift) t.seg_shift = (uint32_t)seg_shift_override;   // tests: tiny segments
-    return t;
-}
-// BIG: the descriptor of the 4 GiB-window segment that holds `row`, and the row's byte offset inside it.  The four groups
-// of a wave mostly land in the same segment (a 10 GB table has three), so the per-descriptor serialisation the compiler
-// emits ("waterfall") runs once or twice instead of once per distinct row.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_view(const TableView& t, int32_t row, uint32_t& row_off) {
-    const uint32_t seg = (uint32_t)row >> t.seg_shift;
-    row_off = ((uint32_t)row & ((1u << t.seg_shift) - 1u)) * t.row_bytes;
-    return __builtin_amdgcn_make_buffer_rsrc(t.base + ((size_t)seg << t.seg_shift) * (t.row_bytes / 4), 0, (int)(uint32_t)(t.row_bytes << t.seg_shift), 0x00020000);
-}
-
-// Lane j of a 16-lane group owns elements {64c + 16m + j : m = 0..3} of chunk c (kept as v[c].{x,y,z,w}): every
-// memory instruction of a group then touches 64 CONTIGUOUS bytes of the row, which is the shape the memory-side
-// float atomics want (one 64-B request per group instead of four) and costs the loads nothing (HBM-bound).
-template <int DCH, int AUX, bool BIG>
-__device__ __forceinline__ void row_load(Row<DCH>& r, const TableView& t, int32_t row, int lane) {
-    if (BIG) {
-        uint32_t ro;
-        const __amdgpu_buffer_rsrc_t rs = row_view(t, row, ro);
-        const uint32_t o = ro + (uint32_t)lane * 4u;
-#pragma unroll
-        for (int c = 0; c < DCH; c++) {
-            r.v[c].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + c * 256u), 0, AUX));
-            r.v[c].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + c * 256u + 64u), 0, AUX));
-            r.v[c].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + c * 256u + 128u), 0, AUX));
-            r.v[c].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + c * 256u + 192u), 0, AUX));
-        }
-        return;
-    }
-    const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 4u;
-#pragma unroll
-    for (int c = 0; c < DCH; c++) {
-        r.v[c].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, (int)(off + c * 256u), 0, AUX));
-        r.v[c].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, (int)(off + c * 256u + 64u), 0, AUX));
-        r.v[c].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, (int)(off + c * 256u + 128u), 0, AUX));
-        r.v[c].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, (int)(off + c * 256u + 192u), 0, AUX));
-    }
-}
-// A batch slot without a row (a filler of a partial batch, a row whose lock was not won) loads the row `filler_row`: an index
-// whose byte offset lies beyond the table descriptor's range, which the hardware answers with zeros WITHOUT touching memory
-// (loading the centre's row instead cost cfg5 4 % and K = 20 at D = 256 12 %).  It is a ROW index, chosen once per launch, so the
-// loads keep the plain address arithmetic of a real row: selecting an out-of-range OFFSET per load instruction, or branching
-// between the two forms, made the common full batch 8-50 % slower.  Tables of 4 GiB and more (segment descriptors) keep the
-// centre's row as filler.
-template <int DCH, int AUX, bool BIG>
-__device__ __forceinline__ void row_store(const Row<DCH>& r, const TableView& t, int32_t row, int lane) {
-    if (BIG) {
-        uint32_t ro;
-        const __amdgpu_buffer_rsrc_t rs = row_view(t, row, ro);
-        const uint32_t o = ro + (uint32_t)lane * 4u;
-#pragma unroll
-        for (int c = 0; c < DCH; c++) {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].x), rs, (int)(o + c * 256u), 0, AUX);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].y), rs, (int)(o + c * 256u + 64u), 0, AUX);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].z), rs, (int)(o + c * 256u + 128u), 0, AUX);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].w), rs, (int)(o + c * 256u + 192u), 0, AUX);
-        }
-        return;
-    }
-    const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 4u;
-#pragma unroll
-    for (int c = 0; c < DCH; c++) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].x), t.rsrc, (int)(off + c * 256u), 0, AUX);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].y), t.rsrc, (int)(off + c * 256u + 64u), 0, AUX);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].z), t.rsrc, (int)(off + c * 256u + 128u), 0, AUX);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.v[c].w), t.rsrc, (int)(off + c * 256u + 192u), 0, AUX);
-    }
-}
-// row += g * x, element-wise float atomics at the memory side (64 contiguous bytes per group and instruction)
-template <int DCH>
-__device__ __forceinline__ void row_atomic_axpy(const TableView& t, int32_t row, int lane, float g, const Row<DCH>& x) {
-    float* p = t.base + (size_t)row * (t.row_bytes / 4) + lane;
-#pragma unroll
-    for (int c = 0; c < DCH; c++) {
-        atomicAdd(p + c * 64 + 0, g * x.v[c].x);
-        atomicAdd(p + c * 64 + 16, g * x.v[c].y);
-        atomicAdd(p + c * 64 + 32, g * x.v[c].z);
-        atomicAdd(p + c * 64 + 48, g * x.v[c].w);
-    }
-}
-template <int DCH>
-__device__ __forceinline__ float row_dot(const Row<DCH>& a, const Row<DCH>& b) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int c = 0; c < DCH; c++) {
-        acc = fmaf(a.v[c].x, b.v[c].x, acc);
-        acc = fmaf(a.v[c].y, b.v[c].y, acc);
-        acc = fmaf(a.v[c].z, b.v[c].z, acc);
-        acc = fmaf(a.v[c].w, b.v[c].w, acc);
-    }
-    return group16_sum(acc);
-}
-// y += g * x
-template <int DCH>
-__device__ __forceinline__ void row_axpy(Row<DCH>& y, float g, const Row<DCH>& x) {
-#pragma unroll
-    for (int c = 0; c < DCH; c++) {
-        y.v[c].x = fmaf(g, x.v[c].x, y.v[c].x);
-        y.v[c].y = fmaf(g, x.v[c].y, y.v[c].y);
-        y.v[c].z = fmaf(g, x.v[c].z, y.v[c].z);
-        y.v[c].w = fmaf(g, x.v[c].w, y.v[c].w);
-    }
-}
-template <int DCH>
-__device__ __forceinline__ void row_zero(Row<DCH>& y) {
-#pragma unroll
-    for (int c = 0; c < DCH; c++) y.v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-__device__ __forceinline__ float sgns_g(float f, float label, float alpha, const float* s_exp) {
-    if (f > (float)MAX_EXP) return (label - 1.0f) * alpha;
-    if (f < -(float)MAX_EXP) return (label - 0.0f) * alpha;
-    int idx = (int)((f + (float)MAX_EXP) * (float)(EXP_TABLE_SIZE / MAX_EXP / 2));
-    idx = min(max(idx, 0), EXP_TABLE_SIZE - 1);
-    return (label - s_exp[idx]) * alpha;
-}
-
-__device__ __forceinline__ uint64_t shfl16_u64(uint64_t v, int src) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = (uint32_t)__shfl((int)lo, src, 16);
-    hi = (uint32_t)__shfl((int)hi, src, 16);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// one (target row, label 0) update against l1; sequential form used when a pair drew the same row twice
-template <int DCH, int POL, bool BIG>
-__device__ __forceinline__ void neg_update_serial(const Row<DCH>& l1, Row<DCH>& neu, const TableView& syn1neg, int32_t tg,
-                                                  int lane, float alpha, const float* s_exp) {
-    Row<DCH> r;
-    row_load<DCH, Policy<POL>::LOAD_AUX, BIG>(r, syn1neg, tg, lane);
-    float f = row_dot(l1, r);
-    float g = sgns_g(f, 0.0f, alpha, s_exp);
-    row_axpy(neu, g, r);
-    row_axpy(r, g, l1);
-    row_store<DCH, Policy<POL>::STORE_AUX, BIG>(r, syn1neg, tg, lane);
-}
-
-// Hierarchical softmax, Hogwild: every pair walks its centre's Huffman path from the root, so an inner node of subtree
-// weight w takes a fraction w/total of ALL pairs' updates — the root all of them.  As memory-side atomics those
-// serialise on a handful of rows (measured on cfg3: 12 ns per 64-B request, 38 s per step).  The hs_n_hot nodes
-// nearest the root (the highest rows: weights ascend with the row index) therefore collect their updates in per-block
-// LDS accumulators; the worker that makes an accumulator's hs_drain-th addition takes its content out (an exchange
-// per element, so concurrent additions are never lost) and adds it to the row in memory.  Rows are still READ from
-// memory: a block sees its own parked updates at most hs_drain additions late.
-extern __shared__ float s_dyn[];
-template <int DCH>
-__device__ __forceinline__ void hot_add(float* s_hot, int* s_cnt, int slot, int drain, const TableView& t, int32_t row, int lane,
-                                        float g, const Row<DCH>& x) {
-    float* a = s_hot + slot * (DCH * 64) + lane;
-#pragma unroll
-    for (int c = 0; c < DCH; c++) {
-        atomicAdd(a + c * 64 + 0, g * x.v[c].x);
-        atomicAdd(a + c * 64 + 16, g * x.v[c].y);
-        atomicAdd(a + c * 64 + 32, g * x.v[c].z);
-        atomicAdd(a + c * 64 + 48, g * x.v[c].w);
-    }
-    int n = 0;
-    if (lane == 0) n = atomicAdd(&s_cnt[slot], 1) + 1;
-    n = __shfl(n, 0, 16);
-    if (n % drain == 0) {
-        float* gp = t.base + (size_t)row * (t.row_bytes / 4) + lane;
-#pragma unroll
-        for (int c = 0; c < DCH; c++)
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const float v = atomicExch(a + c * 64 + m * 16, 0.f);
-                if (v != 0.f) atomicAdd(gp + c * 64 + m * 16, v);
-            }
-    }
-}
-
-// end of the kernel, every thread of the block: what is still parked in LDS goes to memory (rows are contiguous)
-__device__ __forceinline__ void hot_drain_block(const float* s_hot, int n_floats, float* first_row) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_floats; i += blockDim.x) {
-        const float v = s_hot[i];
-        if (v != 0.f) atomicAdd(first_row + i, v);
-    }
-}
-
-__device__ __forceinline__ int32_t walk_tok(bool in_regs, const int32_t* sen, int idx, int32_t tk0, int32_t tk1, int32_t tk2, int32_t tk3) {
-    if (!in_regs) return sen[idx];
-    const int r = idx >> 4;
-    const int32_t v = r == 0 ? tk0 : (r == 1 ? tk1 : (r == 2 ? tk2 : tk3));
-    return __shfl(v, idx & 15, 16);
-}
-
-template <int DCH, int POL, bool BIG, bool HS, bool PART>
-__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HS ? DGE_HS_WAVES : 4) : 1)
-k_sgns_train(TrainParams p) {
-    using P = Policy<POL>;
-    __shared__ float s_exp[EXP_TABLE_SIZE];
-    for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
-    __syncthreads();
-
-    const int lane = threadIdx.x & 15;
-    const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    constexpr bool HOT = HS && P::ATOMIC;         // inner nodes near the root combine their updates in LDS (hot_add)
-    float* s_hot = HOT ? s_dyn : nullptr;
-    int* s_hot_cnt = HOT ? (int*)(s_dyn + (size_t)p.hs_n_hot * DCH * 64) : nullptr;
-    if (HOT) {
-        for (int i = threadIdx.x; i < p.hs_n_hot * (DCH * 64 + 1); i += blockDim.x) s_dyn[i] = 0.f;   // +0.0f == int 0
-        __syncthreads();
-    }
-    if (!HOT && worker >= p.n_workers) return;    // (the HOT kernel keeps every thread for its final block-wide drain)
-
-    const TableView syn0 = make_view(p.syn0, p.V, p.stride, p.big_seg_shift);
-    const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride, p.big_seg_shift);
-    const TableView syn1 = make_view(HS ? p.syn1 : p.syn1neg, p.V, p.stride, p.big_seg_shift);
-    int64_t hs_o = 0; int hs_n = 0; uint64_t hs_bits = 0;   // Huffman path of the open centre
-
-    // lane j turns the pair's LCG state s into the state after j+1 draws: s*mA + cA
-    uint64_t mA = 1, cA = 0;
-    for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
-
-    const int L = p.L, W = p.W, K = p.K;
-    const bool toks_in_regs = L <= 64;
-    unsigned long long my_pairs = 0, my_words = 0;
-    // PART (block schedule): only centres in partition part_tgt and contexts in partition part_ctx are visited — found
-    // through two bit masks over the walk's tokens, so a block costs what its own pairs cost.  Every pair draws from
-    // its own stream (seeded from the centre's stream and the context position): the draws of a pair do not depend on
-    // which other pairs of the centre this block trains.
-    uint64_t ctx_mask = 0, tgt_mask = 0, pair_mask = 0, s_centre = 0;
-    int nx_len = 0; int64_t nx_wb = 0; int32_t nx0 = -1, nx1 = -1, nx2 = -1, nx3 = -1;
-
-    // ---- per-worker state: walk w, centre i, next context c (contexts are c..c_hi without i)
-    int64_t w = (HOT && worker >= p.n_workers) ? p.n_rows - p.n_workers : worker - p.n_workers;   // surplus workers find no walk
-    if (PART) walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
-    int len = 0, i = 0, c = 1, c_hi = 0;
-    int32_t tk0 = -1, tk1 = -1, tk2 = -1, tk3 = -1;       // the walk's tokens: lane j holds tokens j, j+16, j+32, j+48
-    const int32_t* sen = p.sen;
-    int32_t word = 0;
-    float alpha = 0.f;
-    uint64_t s = 0;
-    int64_t gbase = 0;
-    Row<DCH> h, dh;                                       // syn1neg[word] and (ATOMIC) its accumulated update
-    bool h_dirty = false;
-
-#define DGE_TOK(idx) walk_tok(toks_in_regs, sen, (idx), tk0, tk1, tk2, tk3)
-    // close the open centre: publish what it accumulated on syn1neg[word]
-#define DGE_CLOSE_CENTRE()                                                                                         \
-    do {                                                                                                           \
-        if (h_dirty) {                                                                                             \
-            h_dirty = false;                                                                                       \
-            if (P::ATOMIC) row_atomic_axpy(syn1neg, word, lane, 1.0f, dh);                                         \
-            else row_store<DCH, P::STORE_AUX, BIG>(h, syn1neg, word, lane);                                           \
-        }                                                                                                          \
-    } while (0)
-
-    for (;;) {
-        // ------------------------------------------------------------------ advance to the next (centre, context) pair
-        bool new_centre = false, alive = true;
-        while (c > c_hi) {
-            DGE_CLOSE_CENTRE();
-            if (PART) i = first_bit_from(tgt_mask, i + 1, len); else i++;
-            while (i >= len) {                             // next walk of this worker (empty walks are skipped)
-                w += p.n_workers;
-                if (w >= p.n_rows) { alive = false; break; }
-                int64_t wb_next = 0;
-                if (PART) {                                // prefetched while the previous walk was trained
-                    len = nx_len; wb_next = nx_wb; tk0 = nx0; tk1 = nx1; tk2 = nx2; tk3 = nx3;
-                    walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
-                } else len = (int)p.len[w];
-                i = 0;
-                if (len > 0) {
-                    if (!PART || p.part_ctx == p.part_tgt) my_words += (unsigned long long)len;      // (block schedule: once per batch, in episode 0)
-                    sen = p.sen + w * L;
-                    if (!PART && toks_in_regs) {
-                        tk0 = lane < L ? sen[lane] : -1;
-                        tk1 = lane + 16 < L ? sen[lane + 16] : -1;
-                        tk2 = lane + 32 < L ? sen[lane + 32] : -1;
-                        tk3 = lane + 48 < L ? sen[lane + 48] : -1;
-                    }
-                    if (PART) {
-                        ctx_mask = part_token_mask(tk0, tk1, tk2, tk3, p.part_n, p.part_ctx);
-                        tgt_mask = part_token_mask(tk0, tk1, tk2, tk3, p.part_n, p.part_tgt);
-                        i = first_bit_from(tgt_mask, 0, len);
-                    }
-                    // learning rate from the exact number of in-vocabulary tokens that precede this walk
-                    const int64_t wbw = PART ? wb_next : p.wb[w];
-                    const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
-                    alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
-                    if (alpha < p.min_alpha) alpha = p.min_alpha;
-                    gbase = (p.gidx_base + w) * (int64_t)L;
-                }
-            }
-            if (!alive) break;
-            // open centre i: DL4J's window draw, radius W - b
-            word = DGE_TOK(i);
-            s = dge_mix64(p.seed + (uint64_t)(gbase + i));
-            s = s * DGE_W2V_MULT + 11;
-            const int radius = W - (int)(s % (uint64_t)W);
-            c = max(0, i - radius);
-            c_hi = min(len - 1, i + radius);
-            if (c_hi == i) c_hi--;
-            if (c == i) c++;
-            new_centre = true;
-            if (PART) {
-                s_centre = s;
-                pair_mask = ctx_mask & ~(1ull << i) & (c < 64 ? (~0ull << c) : 0ull);
-                if (c_hi < 63) pair_mask &= (1ull << (c_hi + 1)) - 1ull;
-                c = first_bit_from(pair_mask, 0, c_hi + 1);
-            }
-            if (HS) { hs_o = p.hs_off[word]; hs_n = (int)(p.hs_off[word + 1] - hs_o); hs_bits = p.hs_codes[word]; }
-        }
-        if (!alive) break;
-        const int32_t last = DGE_TOK(c);
-        if (PART) s = dge_mix64(s_centre + (uint64_t)c);
-
-        // ------------------------------------------------------------------ one pair: l1 = syn0[last], target rows in syn1neg
-        Row<DCH> l1, neu;
-        row_load<DCH, P::LOAD_AUX, BIG>(l1, syn0, last, lane);
-        if (new_centre) {
-            row_load<DCH, P::LOAD_AUX, BIG>(h, syn1neg, word, lane);
-            if (P::ATOMIC) row_zero(dh);
-        }
-        row_zero(neu);
-        if (HS) {
-            // word2vec.c "HIERARCHICAL SOFTMAX", ahead of the negatives: the inner nodes on the centre's Huffman path,
-            // label 1 - code.  Outside (-6, 6) the step is skipped (not saturated, unlike the negative-sampling branch).
-            // The rows of one path are distinct and l1 does not change within the pair, so a batch in flight is the
-            // sequential result.
-            for (int kd = 0; kd < hs_n; kd += 16) {
-                const int kc = min(16, hs_n - kd);
-                const int32_t t = lane < kc ? p.hs_points[hs_o + kd + lane] : -1;
-                for (int base = 0; base < kc; base += NEG_BATCH) {
-                    int32_t tg[NEG_BATCH];
-                    Row<DCH> rr[NEG_BATCH];
-#pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) {
-                        int32_t v = __shfl(t, (base + q) & 15, 16);
-                        tg[q] = (base + q < kc) ? v : -1;
-                    }
-#pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX, BIG>(rr[q], syn1, tg[q] >= 0 ? tg[q] : (BIG ? 0 : p.filler_row), lane);
-#pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++)
-                        if (tg[q] >= 0) {
-                            const float f = row_dot(l1, rr[q]);
-                            if (f > -(float)MAX_EXP && f < (float)MAX_EXP) {
-                                const int idx = (int)((f + (float)MAX_EXP) * (float)(EXP_TABLE_SIZE / MAX_EXP / 2));
-                                const float code = (float)((hs_bits >> (kd + base + q)) & 1ULL);
-                                const float g = (1.0f - code - s_exp[idx]) * alpha;
-                                row_axpy(neu, g, rr[q]);
-                                if (P::ATOMIC) {
-                                    if (tg[q] >= p.hs_hot0) hot_add<DCH>(s_hot, s_hot_cnt, tg[q] - p.hs_hot0, p.hs_drain, syn1, tg[q], lane, g, l1);
-                                    else row_atomic_axpy(syn1, tg[q], lane, g, l1);
-                                } else {
-                                    row_axpy(rr[q], g, l1);
-                                    row_store<DCH, P::STORE_AUX, BIG>(rr[q], syn1, tg[q], lane);
-                                }
-                            }
-                        }
-                }
-            }
-        }
-        {   // d == 0: target = word, label 1 (word2vec order: positive first)
-            float f = row_dot(l1, h);
-            float g = sgns_g(f, 1.0f, alpha, s_exp);
-            row_axpy(neu, g, h);
-            row_axpy(h, g, l1);
-            if (P::ATOMIC) row_axpy(dh, g, l1);
-            h_dirty = true;
-        }
-        for (int kd = 0; kd < K; kd += 16) {
-            const int kc = min(16, K - kd);
-            // lane j draws negative kd+j
-            const uint64_t sl = s * mA + cA;
-            int32_t t = -1;
-            if (lane < kc) {
-                t = p.table[(sl >> 16) % (uint64_t)p.T];
-                if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
-                if (PART) t = part_row(t, p.part_n, p.part_tgt, p.V);
-                if (t == word) t = -1;
-            }
-            s = shfl16_u64(sl, kc - 1);
-            for (int base = 0; base < kc; base += NEG_BATCH) {
-                int32_t tg[NEG_BATCH];
-#pragma unroll
-                for (int q = 0; q < NEG_BATCH; q++) {
-                    int32_t v = __shfl(t, (base + q) & 15, 16);
-                    tg[q] = (base + q < kc) ? v : -1;
-                }
-                bool dup = false;
-                if (!P::ATOMIC) {
-#pragma unroll
-                    for (int q = 1; q < NEG_BATCH; q++)
-#pragma unroll
-                        for (int r = 0; r < q; r++) dup |= (tg[q] >= 0 && tg[q] == tg[r]);
-                }
-                if (!dup) {
-                    // all rows of the batch in flight together: loads are unconditional (a skipped slot reads the
-                    // centre's own row, always valid), only the arithmetic and the store are guarded
-                    Row<DCH> rr[NEG_BATCH];
-#pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX, BIG>(rr[q], syn1neg, tg[q] >= 0 ? tg[q] : (BIG ? word : p.filler_row), lane);
-#pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++)
-                        if (tg[q] >= 0) {
-                            float f = row_dot(l1, rr[q]);
-                            float g = sgns_g(f, 0.0f, alpha, s_exp);
-                            row_axpy(neu, g, rr[q]);
-                            if (P::ATOMIC) {
-                                row_atomic_axpy(syn1neg, tg[q], lane, g, l1);
-                            } else {
-                                row_axpy(rr[q], g, l1);
-                                row_store<DCH, P::STORE_AUX, BIG>(rr[q], syn1neg, tg[q], lane);
-                            }
-                        }
-                } else {
-#pragma unroll 1
-                    for (int q = 0; q < NEG_BATCH; q++)
-                        if (tg[q] >= 0) neg_update_serial<DCH, POL, BIG>(l1, neu, syn1neg, tg[q], lane, alpha, s_exp);
-                }
-            }
-        }
-        if (P::ATOMIC) {
-            row_atomic_axpy(syn0, last, lane, 1.0f, neu);
-        } else {
-#pragma unroll
-            for (int q = 0; q < DCH; q++) {
-                l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
-            }
-            row_store<DCH, P::STORE_AUX, BIG>(l1, syn0, last, lane);
-        }
-        my_pairs++;
-        if (PART) {
-            pair_mask &= pair_mask - 1ull;
-            c = first_bit_from(pair_mask, 0, c_hi + 1);
-        } else {
-            c++;
-            if (c == i) c++;
-        }
-    }
-    DGE_CLOSE_CENTRE();
-#undef DGE_TOK
-#undef DGE_CLOSE_CENTRE
-    if (lane == 0) {
-        if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
-        if (my_words) atomicAdd(&p.counters[1], my_words);
-    }
-    if (HOT) hot_drain_block(s_hot, p.hs_n_hot * DCH * 64, p.syn1 + (size_t)p.hs_hot0 * (DCH * 64));
-}
-
-// ------------------------------------------------------------------------------------------ all-locked Hogwild trainer
-// Policies 5/6: every row update of BOTH tables is a read-modify-write under that row's commit lock, rows move as 16 bytes
-// per lane (lane j owns elements 64c+4j..64c+4j+3: one dwordx4 per chunk, a whole 256-B chunk per group and
-// instruction).  Measured on cfg3 (ablations in DESIGN.md §5.1): the write-through stores of the 4-byte-per-lane layout
-// that the float atomics need cost more than everything else in the pair; with 16-byte stores and 2 small atomic
-// requests per row (take / drop the lock) the pair is bounded by its HBM traffic again.
-// Lock order: the pair's syn0 row first (together with the first chunk of syn1neg try-locks; if it is not won,
-// everything won in that round is dropped again and the round is repeated), then syn1neg rows in try-lock rounds that
-// never wait while holding a syn1neg lock: no hold-and-wait cycle exists.
-// STRICT (policy 6): a row is committed with one returning atomic per 128-B line before its lock drops — no update is ever
-// lost (dge_selftest_locked_rows).  Relaxed (policy 5): the wave only drains its own stores (vmcnt) before dropping the
-// lock; a re-lock from another XCD can overtake the write-through, which loses a row update with measured probability
-// <= 4e-7 at >= 65k rows (0 of 2.4e6 at 1M rows) and up to 1.5 % of the worst row's updates on a 1024-row hot set
-// hammered by 12k workers — Hogwild noise, below what unsynchronised float read-modify-writes lose (policy 1).
-// Commit of a row before its lock drops: after the row's write-through stores, ONE returning float atomic (+0.0f) per
-// 128-B line of the row.  A line's store and the atomic that follows it travel the same channel in order and the atomic
-// is performed at the memory side, so its return implies the line's data is there; the wave then waits for the returns
-// (row_commit_wait) and only then clears the lock word.  Lane l probes line l of the row.
-__device__ __forceinline__ float row_probe_lines(const TableView& t, int32_t row, int lane, int n_lines) {
-    float old = 0.f;
-    if (lane < n_lines) old = __hip_atomic_fetch_add(t.base + (size_t)row * (t.row_bytes / 4) + lane * 32, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return old;
-}
-template <int DCH, int AUX, bool BIG>
-__device__ __forceinline__ void rowA_load(Row<DCH>& r, const TableView& t, int32_t row, int lane) {
-    if (BIG) {
-        uint32_t ro;
-        const __amdgpu_buffer_rsrc_t rs = row_view(t, row, ro);
-#pragma unroll
-        for (int c = 0; c < DCH; c++) {
-            const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + (uint32_t)lane * 16u + c * 256u), 0, AUX));
-            r.v[c] = make_float4(f.x, f.y, f.z, f.w);
-        }
-        return;
-    }
-    const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 16u;
-#pragma unroll
-    for (int c = 0; c < DCH; c++) {
-        // NOTE (hipcc 7.2): bit-casting the ELEMENTS of the loaded <4 x i32> lets the optimiser narrow the load to one
-        // dword (wrong data in y/z/w); casting the whole vector keeps the dwordx4.
-        const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(t.rsrc, (int)(off + c * 256u), 0, AUX));
-        r.v[c] = make_float4(f.x, f.y, f.z, f.w);
-    }
-}
-template <int DCH, int AUX, bool BIG>
-__device__ __forceinline__ void rowA_store(const Row<DCH>& r, const TableView& t, int32_t row, int lane) {
-    if (BIG) {
-        uint32_t ro;
-        const __amdgpu_buffer_rsrc_t rs = row_view(t, row, ro);
-#pragma unroll
-        for (int c = 0; c < DCH; c++) {
-            v4f f;
-            f.x = r.v[c].x; f.y = r.v[c].y; f.z = r.v[c].z; f.w = r.v[c].w;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), rs, (int)(ro + (uint32_t)lane * 16u + c * 256u), 0, AUX);
-        }
-        return;
-    }
-    const uint32_t off = (uint32_t)row * t.row_bytes + (uint32_t)lane * 16u;
-#pragma unroll
-    for (int c = 0; c < DCH; c++) {
-        v4f f;
-        f.x = r.v[c].x; f.y = r.v[c].y; f.z = r.v[c].z; f.w = r.v[c].w;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), t.rsrc, (int)(off + c * 256u), 0, AUX);
-    }
-}
-
-// Policy 7 (HOTMIX): rows the vocabulary's head are wanted by many workers at once — under row locks they make the
-// kernel spin (cfg5: 5e5 edges/s).  Those rows are never locked: they are read with agent-scope loads and updated with
-// memory-side float atomics, like policy 2; all other rows keep the lock protocol.  A row is always updated one way or
-// the other, never both, so neither side can overwrite the other's update.
-// The atomics want 64 contiguous bytes per group instruction (lane j' -> element 64c + 16m + j'), the registers hold the
-// 16-byte layout (lane j -> elements 64c + 4j .. 4j+3): element 16m + j' sits in lane 4m + j'/4, component j' % 4.
-template <int DCH>
-__device__ __forceinline__ void rowA_atomic_axpy(const TableView& t, int32_t row, int lane, float g, const Row<DCH>& x) {
-    float* p = t.base + (size_t)row * (t.row_bytes / 4) + lane;
-    const int hi = lane >> 2, comp = lane & 3;
-#pragma unroll
-    for (int c = 0; c < DCH; c++)
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int src = 4 * m + hi;
-            const float x0 = __shfl(x.v[c].x, src, 16), x1 = __shfl(x.v[c].y, src, 16), x2 = __shfl(x.v[c].z, src, 16), x3 = __shfl(x.v[c].w, src, 16);
-            const float v = comp == 0 ? x0 : (comp == 1 ? x1 : (comp == 2 ? x2 : x3));
-            atomicAdd(p + c * 64 + 16 * m, g * v);
-        }
-}
-// the centre's delta parked in LDS (index 64q + 16*component + lane holds element 64q + 4*lane + component)
-template <int DCH>
-__device__ __forceinline__ void ldsA_atomic_add(const TableView& t, int32_t row, int lane, const float* d_base) {
-    float* p = t.base + (size_t)row * (t.row_bytes / 4) + lane;
-    const int hi = lane >> 2, comp = lane & 3;
-#pragma unroll
-    for (int c = 0; c < DCH; c++)
-#pragma unroll
-        for (int m = 0; m < 4; m++) atomicAdd(p + c * 64 + 16 * m, d_base[c * 64 + comp * 16 + 4 * m + hi]);
-}
-
-template <int DCH, bool STRICT, bool BIG, bool HOTMIX = false>
-__device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* locks, int32_t row, const float* d, int lane, int32_t hot_rows = 0) {
-    if (HOTMIX && row < hot_rows) { ldsA_atomic_add<DCH>(syn1neg, row, lane, d - lane); return; }
-    for (;;) {
-        const bool won = lane == 0 ? row_trylock(locks, row) : false;
-        const bool got = __shfl((int)won, 0, 16) != 0;
-        if (got) {
-            Row<DCH> cur;
-            rowA_load<DCH, 16, BIG>(cur, syn1neg, got ? row : 0, lane);
-#pragma unroll
-            for (int q = 0; q < DCH; q++) {
-                cur.v[q].x += d[q * 64]; cur.v[q].y += d[q * 64 + 16]; cur.v[q].z += d[q * 64 + 32]; cur.v[q].w += d[q * 64 + 48];
-            }
-            rowA_store<DCH, 16, BIG>(cur, syn1neg, row, lane);
-            row_commit_wait(STRICT ? row_probe_lines(syn1neg, row, lane, DCH * 2) : 0.f);
-            if (won) row_unlock<STRICT>(locks, row);
-            return;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
-#define LK_NEG_LANES 13      /* lanes 0..12 draw negatives, lane 13 = pending centre flush, lane 14 = the pair's syn0 row */
-#ifndef LK_CHUNK
-#define LK_CHUNK 10          /* negatives per lock round: a multiple of NEG_BATCH, so no batch of a full chunk loads filler rows */
-#endif
-// 3 waves per SIMD is the measured optimum for D <= 128: 4 (128 VGPRs) spills 88 B per lane and runs 20 % slower, 2 runs 12 % slower
-template <int DCH, bool STRICT, bool BIG, bool HOTMIX, bool PART>
-__global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HOTMIX ? (PART ? 2 : DGE_HOTMIX_WAVES) : (DCH == 1 ? 4 : DGE_LOCKED_WAVES)) : ((HOTMIX && DCH <= 4) ? 2 : 1))
-k_sgns_train_locked(TrainParams p) {
-    __shared__ float s_exp[EXP_TABLE_SIZE];
-    __shared__ float s_dh[16 * 2 * DCH * 64];
-    for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
-    __syncthreads();
-
-    const int lane = threadIdx.x & 15;
-    const int wk = threadIdx.x >> 4;
-    const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    if (worker >= p.n_workers) return;
-
-    const TableView syn0 = make_view(p.syn0, p.V, p.stride, p.big_seg_shift);
-    const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride, p.big_seg_shift);
-    int* const locks1 = p.locks;
-    int* const locks0 = p.locks + p.V + 1;
-    const int32_t hot_rows = HOTMIX ? p.hot_rows : 0;
-
-    uint64_t mA = 1, cA = 0;
-    for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
-
-    const int L = p.L, W = p.W, K = p.K;
-    const bool toks_in_regs = L <= 64;
-    unsigned long long my_pairs = 0, my_words = 0;
-
-    int64_t w = worker - p.n_workers;
-    int len = 0, i = 0, c = 1, c_hi = 0;
-    int32_t tk0 = -1, tk1 = -1, tk2 = -1, tk3 = -1;
-    const int32_t* sen = p.sen;
-    int32_t word = 0;
-    float alpha = 0.f;
-    uint64_t s = 0;
-    int64_t gbase = 0;
-    Row<DCH> h;
-    bool h_dirty = false;
-    int32_t pend_row = -1;
-    int cur_buf = 0;
-    float* const my_dh = s_dh + (size_t)wk * 2 * DCH * 64;
-    bool retry_pair = false;      // the pair's syn0 row was busy: same pair again on the next trip through the loop
-    int32_t t_first = -1;         // this lane's slot of the pair's first chunk (kept across a retry: the draw is not repeated)
-    int32_t last = 0;
-    uint64_t ctx_mask = 0, tgt_mask = 0, pair_mask = 0, s_centre = 0;     // PART: see k_sgns_train
-    int nx_len = 0; int64_t nx_wb = 0; int32_t nx0 = -1, nx1 = -1, nx2 = -1, nx3 = -1;
-    if (PART) walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
-
-#define LK_TOK(idx) walk_tok(toks_in_regs, sen, (idx), tk0, tk1, tk2, tk3)
-    // positive target (label 1): the centre's row lives in registers for all its contexts, its accumulated delta in LDS
-#define LK_POSITIVE()                                                                                                  \
-    do {                                                                                                               \
-        const float f_ = row_dot(l1, h);                                                                               \
-        const float g_ = sgns_g(f_, 1.0f, alpha, s_exp);                                                               \
-        row_axpy(neu, g_, h);                                                                                          \
-        row_axpy(h, g_, l1);                                                                                           \
-        float* d_ = my_dh + cur_buf * DCH * 64 + lane;                                                                 \
-        _Pragma("unroll") for (int q_ = 0; q_ < DCH; q_++) {                                                           \
-            d_[q_ * 64] = fmaf(g_, l1.v[q_].x, d_[q_ * 64]); d_[q_ * 64 + 16] = fmaf(g_, l1.v[q_].y, d_[q_ * 64 + 16]); \
-            d_[q_ * 64 + 32] = fmaf(g_, l1.v[q_].z, d_[q_ * 64 + 32]); d_[q_ * 64 + 48] = fmaf(g_, l1.v[q_].w, d_[q_ * 64 + 48]); \
-        }                                                                                                              \
-        h_dirty = true;                                                                                                \
-    } while (0)
-#define LK_CLOSE_CENTRE()                                                                                              \
-    do {                                                                                                               \
-        if (h_dirty) {                                                                                                 \
-            h_dirty = false;                                                                                           \
-            if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows); \
-            pend_row = word;                                                                                           \
-            cur_buf ^= 1;                                                                                              \
-        }                                                                                                              \
-    } while (0)
-
-    for (;;) {
-        bool new_centre = false, alive = true;
-        while (!retry_pair && c > c_hi) {
-            LK_CLOSE_CENTRE();
-            if (PART) i = first_bit_from(tgt_mask, i + 1, len); else i++;
-            while (i >= len) {
-                w += p.n_workers;
-                if (w >= p.n_rows) { alive = false; break; }
-                int64_t wb_next = 0;
-                if (PART) {                                // prefetched while the previous walk was trained
-                    len = nx_len; wb_next = nx_wb; tk0 = nx0; tk1 = nx1; tk2 = nx2; tk3 = nx3;
-                    walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
-                } else len = (int)p.len[w];
-                i = 0;
-                if (len > 0) {
-                    if (!PART || p.part_ctx == p.part_tgt) my_words += (unsigned long long)len;      // (block schedule: once per batch, in episode 0)
-                    sen = p.sen + w * L;
-                    if (!PART && toks_in_regs) {
-                        tk0 = lane < L ? sen[lane] : -1;
-                        tk1 = lane + 16 < L ? sen[lane + 16] : -1;
-                        tk2 = lane + 32 < L ? sen[lane + 32] : -1;
-                        tk3 = lane + 48 < L ? sen[lane + 48] : -1;
-                    }
-                    if (PART) {
-                        ctx_mask = part_token_mask(tk0, tk1, tk2, tk3, p.part_n, p.part_ctx);
-                        tgt_mask = part_token_mask(tk0, tk1, tk2, tk3, p.part_n, p.part_tgt);
-                        i = first_bit_from(tgt_mask, 0, len);
-                    }
-                    const int64_t wbw = PART ? wb_next : p.wb[w];
-                    const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
-                    alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
-                    if (alpha < p.min_alpha) alpha = p.min_alpha;
-                    gbase = (p.gidx_base + w) * (int64_t)L;
-                }
-            }
-            if (!alive) break;
-            word = LK_TOK(i);
-            s = dge_mix64(p.seed + (uint64_t)(gbase + i));
-            s = s * DGE_W2V_MULT + 11;
-            const int radius = W - (int)(s % (uint64_t)W);
-            c = max(0, i - radius);
-            c_hi = min(len - 1, i + radius);
-            if (c_hi == i) c_hi--;
-            if (c == i) c++;
-            new_centre = true;
-            if (PART) {
-                s_centre = s;
-                pair_mask = ctx_mask & ~(1ull << i) & (c < 64 ? (~0ull << c) : 0ull);
-                if (c_hi < 63) pair_mask &= (1ull << (c_hi + 1)) - 1ull;
-                c = first_bit_from(pair_mask, 0, c_hi + 1);
-            }
-        }
-        if (!alive) break;
-        if (!retry_pair) {
-            last = LK_TOK(c);
-            if (PART) s = dge_mix64(s_centre + (uint64_t)c);
-        }
-
-        Row<DCH> l1, neu;
-        if (new_centre) {
-            // the previous centre's delta is still parked in LDS; when it belongs to THIS row (the same token twice in a walk)
-            // it goes out first, so that one worker alone reads exactly what the sequential loop would
-            if (pend_row == word) {
-                flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows);
-                pend_row = -1;
-            }
-            rowA_load<DCH, 16, BIG>(h, syn1neg, word, lane);       // unlocked read: stale by at most the OTHER workers' updates in flight
-            float* d = my_dh + cur_buf * DCH * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < DCH; q++) { d[q * 64] = 0.f; d[q * 64 + 16] = 0.f; d[q * 64 + 32] = 0.f; d[q * 64 + 48] = 0.f; }
-        }
-        row_zero(neu);
-        bool have_l1 = false, abort_pair = false;
-        const bool l1_only = retry_pair;
-        int kd = 0;
-        do {    // chunks of up to 13 negatives (at least one pass so that the syn0 row is locked and loaded even when K == 0)
-            const int kc = min(LK_CHUNK, K - kd);
-            int32_t t = -1;
-            if (retry_pair && kd == 0) {
-                t = t_first;
-            } else {
-                const uint64_t sl = s * mA + cA;
-                if (lane < kc) {
-                    t = p.table[(sl >> 16) % (uint64_t)p.T];
-                    if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
-                    if (PART) t = part_row(t, p.part_n, p.part_tgt, p.V);
-                    if (t == word) t = -1;
-                }
-                if (kc > 0) s = shfl16_u64(sl, kc - 1);
-                if (kd == 0) t_first = t;
-            }
-            if (lane == 13) t = pend_row;
-            if (lane == 14) t = last;
-            // One lock round per CHUNK: every still-untrained row of the chunk (and the pending centre flush, and the pair's
-            // syn0 row) is asked for at once; the rows that were won are then trained NEG_BATCH at a time — loads of a batch
-            // in flight together, no wait between batches — and one commit wait ends the round before the locks drop.  With
-            // K <= NEG_BATCH this is one batch per round; with K = 20 it is two lock/commit round trips per pair instead of five.
-            unsigned pend13 = (unsigned)(__ballot(lane < kc && t >= 0) >> (threadIdx.x & 48)) & 0x1FFFu;
-            bool flush_pending = pend_row >= 0;
-            while (pend13 || !have_l1) {
-                // a pair that already lost the race for its syn0 row once asks for that row ALONE until it has it:
-                // otherwise the many waiting workers of a hot row keep grabbing (and dropping) the syn1neg rows the
-                // row's current holder needs, and the holder starves (seen as a hang on a 3-row vocabulary)
-                const bool others_ok = have_l1 || !l1_only;
-                // (a negative that drew the row whose flush is still pending lets the flush go first: word2vec order)
-                const bool want = (others_ok && lane < kc && ((pend13 >> lane) & 1u) && !(flush_pending && t == pend_row)) ||
-                                  (others_ok && lane == 13 && flush_pending) || (lane == 14 && !have_l1);
-                const bool lockfree = HOTMIX && want && (t < hot_rows || (lane == 14 && p.syn0_free));     // a head row: no lock, atomics
-                const bool won = (want && !lockfree) ? row_trylock(lane == 14 ? locks0 : locks1, t) : false;
-                const unsigned long long bal = __ballot(won || lockfree);
-                const unsigned gotl = (unsigned)(bal >> (threadIdx.x & 48)) & 0xFFFFu;
-                if (!have_l1 && !((gotl >> 14) & 1u)) {
-                    // the pair's syn0 row is busy (possibly held by another group of THIS wave, which can only drop it
-                    // once this group stops looping): drop whatever this round won and leave the pair for the next
-                    // trip through the outer loop — no waiting while holding, no spinning under divergence
-                    if (won) row_unlock<STRICT>(lane == 14 ? locks0 : locks1, t);
-                    abort_pair = true;
-                    break;
-                }
-                const bool got_l1 = !have_l1;
-                const unsigned got13 = gotl & 0x1FFFu & pend13;
-                const bool gotf = flush_pending && ((gotl >> 13) & 1u);
-                Row<DCH> fr;
-                float my_hot_g = 0.f;                      // HOTMIX: lane j keeps the step of the chunk's j-th row when that is a head row
-                if (got_l1) rowA_load<DCH, 16, BIG>(l1, syn0, (gotl >> 14) & 1u ? last : 0, lane);
-                if (flush_pending) rowA_load<DCH, 16, BIG>(fr, syn1neg, gotf ? pend_row : (BIG ? word : p.filler_row), lane);
-                have_l1 = true;
-                bool do_pos = got_l1;                      // the positive target comes first (word2vec order), once l1 is here
-                float acc = 0.f;                           // STRICT: the commit probes' returns
-                for (int base = 0; base < kc; base += NEG_BATCH) {
-                    const unsigned got = (got13 >> base) & ((1u << NEG_BATCH) - 1u);
-                    if (!got) continue;
-                    int32_t tg[NEG_BATCH];
-                    Row<DCH> rr[NEG_BATCH];
-#pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) tg[q] = __shfl(t, (base + q) & 15, 16);
-#pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16, BIG>(rr[q], syn1neg, ((got >> q) & 1u) ? tg[q] : (BIG ? word : p.filler_row), lane);
-                    if (do_pos) { do_pos = false; LK_POSITIVE(); }     // behind the batch's loads: they are in flight meanwhile
-#pragma unroll
-                    for (int q = 0; q < NEG_BATCH; q++)
-                        if ((got >> q) & 1u) {
-                            float f = row_dot(l1, rr[q]);
-                            float g = sgns_g(f, 0.0f, alpha, s_exp);
-                            row_axpy(neu, g, rr[q]);
-                            if (HOTMIX && tg[q] < hot_rows) {
-                                if (lane == base + q) my_hot_g = g;   // the atomics go out after this round's locks have dropped (below)
-                            } else {
-                                row_axpy(rr[q], g, l1);
-                                rowA_store<DCH, 16, BIG>(rr[q], syn1neg, tg[q], lane);
-                            }
-                        }
-                    if (STRICT) {   // every stored row is committed line by line (lane = 4*slot + line for DCH 2) before the locks drop
-                        const int n_lines = DCH * 2;
-#pragma unroll
-                        for (int rep = 0; rep < (NEG_BATCH * DCH * 2 + 15) / 16; rep++) {
-                            const int idx = lane + rep * 16, q = idx / n_lines, ln = idx - q * n_lines;
-                            int32_t row = -1;
-#pragma unroll
-                            for (int qq = 0; qq < NEG_BATCH; qq++) if (qq == q && ((got >> qq) & 1u)) row = tg[qq];
-                            if (row >= 0) acc += __hip_atomic_fetch_add(syn1neg.base + (size_t)row * (syn1neg.row_bytes / 4) + ln * 32, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                }
-                if (do_pos) LK_POSITIVE();                 // (no row of the chunk was won in this round, or K == 0)
-                const bool hot_flush = HOTMIX && gotf && pend_row < hot_rows;
-                if (gotf && !hot_flush) {
-                    const float* d = my_dh + (cur_buf ^ 1) * DCH * 64 + lane;
-#pragma unroll
-                    for (int q = 0; q < DCH; q++) {
-                        fr.v[q].x += d[q * 64]; fr.v[q].y += d[q * 64 + 16]; fr.v[q].z += d[q * 64 + 32]; fr.v[q].w += d[q * 64 + 48];
-                    }
-                    rowA_store<DCH, 16, BIG>(fr, syn1neg, pend_row, lane);
-                    if (STRICT) acc += row_probe_lines(syn1neg, pend_row, lane, DCH * 2);
-                }
-                row_commit_wait(acc);
-                if (won && lane != 14) row_unlock<STRICT>(locks1, t);
-                if (HOTMIX) {
-                    // head rows: memory-side atomics, issued behind the commit so that the wait above (which drains every
-                    // outstanding memory operation of the wave) never sits on them while row locks are held
-                    for (int j = 0; j < kc; j++) {
-                        const int32_t tj = __shfl(t, j, 16);
-                        const float gj = __shfl(my_hot_g, j, 16);
-                        if (((got13 >> j) & 1u) && tj < hot_rows) rowA_atomic_axpy<DCH>(syn1neg, tj, lane, gj, l1);
-                    }
-                    if (hot_flush) ldsA_atomic_add<DCH>(syn1neg, pend_row, lane, my_dh + (cur_buf ^ 1) * DCH * 64);
-                }
-                pend13 &= ~got13;
-                if (gotf) { flush_pending = false; pend_row = -1; if (lane == 13) t = -1; }
-                if (pend13) __builtin_amdgcn_s_sleep(2);
-            }
-            kd += LK_CHUNK;
-        } while (kd < K && !abort_pair);
-        if (abort_pair) { retry_pair = true; __builtin_amdgcn_s_sleep(8); continue; }
-        retry_pair = false;
-
-#pragma unroll
-        for (int q = 0; q < DCH; q++) {
-            l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
-        }
-        if (HOTMIX && (last < hot_rows || p.syn0_free)) {
-            rowA_atomic_axpy<DCH>(syn0, last, lane, 1.0f, neu);
-        } else {
-            rowA_store<DCH, 16, BIG>(l1, syn0, last, lane);
-            row_commit_wait(STRICT ? row_probe_lines(syn0, last, lane, DCH * 2) : 0.f);
-            if (lane == 14) row_unlock<STRICT>(locks0, last);
-        }
-        my_pairs++;
-        if (PART) {
-            pair_mask &= pair_mask - 1ull;
-            c = first_bit_from(pair_mask, 0, c_hi + 1);
-        } else {
-            c++;
-            if (c == i) c++;
-        }
-    }
-    LK_CLOSE_CENTRE();
-    if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows);
-#undef LK_TOK
-#undef LK_POSITIVE
-#undef LK_CLOSE_CENTRE
-    if (lane == 0) {
-        if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
-        if (my_words) atomicAdd(&p.counters[1], my_words);
-    }
 }
 
 // ------------------------------------------------------------------------------------------ lock protocol self-test
@@ -1528,29 +514,13 @@ static int ensure_work(dge_model* m, int64_t n_rows, int32_t L) {
     return DGE_OK;
 }
 
-template <int DCH, bool BIG>
-static void launch_train_b(const TrainParams& p, int pol, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st) {
-    switch (pol) {
-        case 0: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 10: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;    // + hierarchical softmax
-        case 12: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, true, false>), dim3(blocks), dim3(threads), shmem, st, p); break;
-        case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 7: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-        // block schedule of the multi-GPU path (dge_model_set_partition): in-order, atomics, commit locks
-        case 20: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 22: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 25: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 27: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true, true>), dim3(blocks), dim3(threads), 0, st, p); break;
-        default: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-    }
-}
-template <int DCH>
-static void launch_train(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st) {
-    if (big) launch_train_b<DCH, true>(p, pol, blocks, threads, shmem, st);
-    else launch_train_b<DCH, false>(p, pol, blocks, threads, shmem, st);
-}
+// the trainer kernels are compiled per row width in sgns_train_dch.hip (one object per DCH)
+void dge_launch_train_dch1(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st);
+void dge_launch_train_dch2(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st);
+void dge_launch_train_dch3(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st);
+void dge_launch_train_dch4(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st);
+void dge_launch_train_dch6(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st);
+void dge_launch_train_dch8(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st);
 
 static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32_t L, int64_t walk_index_base, int32_t epoch,
                       int64_t words_before, double words_scale, int64_t total_walks) {
@@ -1665,12 +635,12 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     DGE_HIP(hipEventCreate(&ev.a)); DGE_HIP(hipEventCreate(&ev.b));
     DGE_HIP(hipEventRecord(ev.a, st));
     switch (m->stride / 64) {
-        case 1: launch_train<1>(p, pol, big, blocks, threads, shmem, st); break;
-        case 2: launch_train<2>(p, pol, big, blocks, threads, shmem, st); break;
-        case 3: launch_train<3>(p, pol, big, blocks, threads, shmem, st); break;
-        case 4: launch_train<4>(p, pol, big, blocks, threads, shmem, st); break;
-        case 6: launch_train<6>(p, pol, big, blocks, threads, shmem, st); break;
-        default: launch_train<8>(p, pol, big, blocks, threads, shmem, st); break;
+        case 1: dge_launch_train_dch1(p, pol, big, blocks, threads, shmem, st); break;
+        case 2: dge_launch_train_dch2(p, pol, big, blocks, threads, shmem, st); break;
+        case 3: dge_launch_train_dch3(p, pol, big, blocks, threads, shmem, st); break;
+        case 4: dge_launch_train_dch4(p, pol, big, blocks, threads, shmem, st); break;
+        case 6: dge_launch_train_dch6(p, pol, big, blocks, threads, shmem, st); break;
+        default: dge_launch_train_dch8(p, pol, big, blocks, threads, shmem, st); break;
     }
     DGE_HIP(hipEventRecord(ev.b, st));
     m->pending.push_back(ev);

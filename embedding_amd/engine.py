@@ -54,6 +54,30 @@ class DeviceGraph:
         v = np.ascontiguousarray(v, np.int32)
         check(lib.dge_graph_set_sources(self._h, _ptr(v), len(v), int(bool(stream_sum))))
 
+    def reserve_vertices(self, n):
+        check(lib.dge_graph_reserve_vertices(self._h, int(n)))
+
+    def set_out_degree(self, out_degree):
+        """Vertex.outDegree values as the host holds them (a public field of the reference), one per vertex."""
+        od = np.ascontiguousarray(out_degree, np.float64)
+        check(lib.dge_graph_set_out_degree(self._h, _ptr(od), len(od)))
+
+    def set_source_weight_sum(self, s):
+        check(lib.dge_graph_set_source_weight_sum(self._h, float(s)))
+
+    def get_csr(self, tables=True):
+        """The whole store in CSR order: row_ptr, nbr, weight, out_degree (+ prob, alias when the tables are built)."""
+        V, E = self.num_vertices, self.num_edges
+        row_ptr = np.zeros(V + 1, np.int64); nbr = np.zeros(max(E, 1), np.int32); wt = np.zeros(max(E, 1), np.float64)
+        od = np.zeros(max(V, 1), np.float64)
+        prob = np.zeros(max(E, 1), np.float64) if tables else None; alias = np.zeros(max(E, 1), np.int32) if tables else None
+        check(lib.dge_graph_get_csr(self._h, _ptr(row_ptr), _ptr(nbr), _ptr(wt), _ptr(prob), _ptr(alias), _ptr(od), V, max(E, 1)))
+        E = int(row_ptr[V])
+        out = dict(row_ptr=row_ptr, nbr=nbr[:E], weight=wt[:E], out_degree=od[:V])
+        if tables:
+            out.update(prob=prob[:E], alias=alias[:E])
+        return out
+
     def keep_top_k(self, k):
         check(lib.dge_graph_keep_top_k(self._h, int(k)))
 
@@ -156,8 +180,17 @@ class WalkCorpus:
 
 def make_config(dim, window, n_vertices, negative=5, min_count=2, epochs=1, workers=0, alpha=0.025, min_alpha=1e-4,
                 seed=1, table_size=100_000_000, update_policy=0, use_hs=False):
+    """struct dge_train_config, field by field (a ctypes view, not a mirror of DeepWalk: use_hs defaults to the plain
+    negative-sampling path that BASELINE.json's metric and bench.py are about).  `deepwalk_config` is the reference's setting."""
     return TrainConfig(int(dim), int(window), int(negative), int(min_count), int(epochs), int(workers), float(alpha),
                        float(min_alpha), int(seed), int(table_size), int(n_vertices), int(update_policy), int(bool(use_hs)), 0)
+
+
+def deepwalk_config(region_level, num_layer, n_vertices, use_hs=True, **kw):
+    """What J/DeepWalk.java:62-76 builds: layerSize 20 ("tract") or 2 ("CA"), windowSize = LayeredGraph.numLayer, 5 negatives,
+    minWordFrequency 2, one iteration, DL4J's learning rates — and the hierarchical-softmax term ON, because the builder never
+    calls useHierarchicSoftmax(false) (java/embedding/DeepWalk.java and the C++ mirror default to the same)."""
+    return make_config(2 if region_level == "CA" else 20, num_layer, n_vertices, negative=5, min_count=2, epochs=1, use_hs=use_hs, **kw)
 
 
 class SgnsModel:

@@ -54,7 +54,10 @@ def read_vec(path, header=False):
 
 def read_od_slices(paths):
     """Per-slice OD files -> layered cross-time edge list (J/CrossTimeGraph.java:36-47): vertex id = h*R + index of the
-    region id in ascending order; edge (h, src) -> ((h+1) % T, dst) for every positive flow; sources = layer 0."""
+    region id in ascending order; edge (h, src) -> ((h+1) % T, dst) for every positive flow.  Sources, as the reference
+    picks them (:43-47): EVERY layer-0 vertex that exists in the store — one that only occurs as a destination of slice
+    T-1 and has no out-edge included (it enters the source alias table with weight 0) — in ascending region order (the
+    reference: its region map's order; embedding_host.hpp:constructGraphFromOD does the same)."""
     T = len(paths)
     flows = []
     for h, p in enumerate(paths):
@@ -66,6 +69,6 @@ def read_od_slices(paths):
     src = np.concatenate([h * R + np.searchsorted(regions, a[:, 0].astype(np.int64)) for h, a in enumerate(flows)])
     dst = np.concatenate([((h + 1) % T) * R + np.searchsorted(regions, a[:, 1].astype(np.int64)) for h, a in enumerate(flows)])
     w = np.concatenate([a[:, 2] for a in flows])
-    present0 = np.unique(src[src < R])
+    present0 = np.unique(np.concatenate([src[src < R], dst[dst < R]]))
     return dict(src=src.astype(np.int32), dst=dst.astype(np.int32), w=w, sources=present0.astype(np.int32), regions=regions,
                 R=R, T=T, names=["%d-%d" % (h, r) for h in range(T) for r in regions])

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DGE_VERSION 101
+#define DGE_VERSION 102
 
 enum {
     DGE_OK = 0,
@@ -66,6 +66,16 @@ int  dge_graph_add_edges_device(dge_graph* g, const int32_t* d_src, const int32_
 /* bulk addSourceVertex(vn)  J/LayeredGraph.java:180-189 (after all edges).  stream_sum = 0: sourceWeightSum
  * is the running += of addSourceVertex; 1: DoubleStream.sum() as in J/SpatialGraph.java:56-57,82-83. */
 int  dge_graph_set_sources(dge_graph* g, const int32_t* v, int64_t n, int stream_sum);
+/* Vertex ids [0, n) exist even when no edge names them (isolated vertices; the unregistered source vertices that
+ * addSourceVertex creates for unknown names, J/LayeredGraph.java:182-183).  Before set_sources / build_alias. */
+int  dge_graph_reserve_vertices(dge_graph* g, int32_t n);
+/* Vertex.outDegree is a PUBLIC FIELD of the reference (J/LayeredGraph.java:35; assigned by J/SpatialGraph.java:33): a host that
+ * keeps that field hands over its values (host double[n], n = vertex count) instead of the recomputed running sums.
+ * After all edges; adding edges afterwards recomputes the sums. */
+int  dge_graph_set_out_degree(dge_graph* g, const double* out_degree, int32_t n);
+/* LayeredGraph.sourceWeightSum is a protected field that subclasses assign (J/SpatialGraph.java:57,83): fix it to the
+ * host's value.  After dge_graph_set_sources (which recomputes it). */
+int  dge_graph_set_source_weight_sum(dge_graph* g, double sum);
 /* SpatialGraph.keepNearestKVertices(k)  J/SpatialGraph.java:29-35: stable sort by weight descending,
  * keep the first k, outDegree recomputed.  DGE_ERR_TOPK if some vertex has fewer than k edges. */
 int  dge_graph_keep_top_k(dge_graph* g, int32_t k);
@@ -79,6 +89,11 @@ int  dge_graph_num_edges(const dge_graph* g, int64_t* n);
  * any output pointer may be null.  *k receives the degree even when cap is too small (DGE_ERR_CAP). */
 int  dge_graph_get_alias(const dge_graph* g, int32_t v, double* prob, int32_t* alias, int32_t* nbr,
                          double* weight, int32_t cap, int32_t* k, double* out_degree);
+/* the same for ALL vertices at once, in CSR order (edges of vertex v at [row_ptr[v], row_ptr[v+1]), insertion order kept):
+ * what a host needs to fill every Vertex's probTable/aliasTable after initiateAliasTables(), or to rebuild edgesOut /
+ * outDegree after keepNearestKVertices.  Host buffers; any output may be null; row_ptr has cap_vertices + 1 entries. */
+int  dge_graph_get_csr(const dge_graph* g, int64_t* row_ptr, int32_t* nbr, double* weight, double* prob, int32_t* alias,
+                       double* out_degree, int32_t cap_vertices, int64_t cap_edges);
 /* LayeredGraph.{probTable,aliasTable,sourceVertices,sourceWeightSum}  J/LayeredGraph.java:145-148 */
 int  dge_graph_get_source_alias(const dge_graph* g, double* prob, int32_t* alias, int32_t* src,
                                 int32_t cap, int32_t* k, double* weight_sum);

@@ -4,6 +4,8 @@
 //       -L../../embedding_amd -l:libdge.so -o libdge_jni.so
 #include <jni.h>
 
+#include <algorithm>
+#include <cstdint>
 #include <vector>
 
 #include "dge.h"
@@ -29,6 +31,13 @@ JNIEXPORT void JNICALL J(graphSetSources)(JNIEnv* e, jclass, jlong g, jintArray 
     int rc = dge_graph_set_sources((dge_graph*)g, (const int32_t*)p, n, ss ? 1 : 0);
     e->ReleaseIntArrayElements(v, p, JNI_ABORT); fail(e, rc);
 }
+JNIEXPORT void JNICALL J(graphReserveVertices)(JNIEnv* e, jclass, jlong g, jint n) { fail(e, dge_graph_reserve_vertices((dge_graph*)g, n)); }
+JNIEXPORT void JNICALL J(graphSetOutDegree)(JNIEnv* e, jclass, jlong g, jdoubleArray od, jint n) {
+    jdouble* p = e->GetDoubleArrayElements(od, nullptr);
+    int rc = dge_graph_set_out_degree((dge_graph*)g, p, n);
+    e->ReleaseDoubleArrayElements(od, p, JNI_ABORT); fail(e, rc);
+}
+JNIEXPORT void JNICALL J(graphSetSourceWeightSum)(JNIEnv* e, jclass, jlong g, jdouble s) { fail(e, dge_graph_set_source_weight_sum((dge_graph*)g, s)); }
 JNIEXPORT void JNICALL J(graphKeepTopK)(JNIEnv* e, jclass, jlong g, jint k) { fail(e, dge_graph_keep_top_k((dge_graph*)g, k)); }
 JNIEXPORT void JNICALL J(graphBuildAlias)(JNIEnv* e, jclass, jlong g, jboolean exact) { fail(e, dge_graph_build_alias((dge_graph*)g, exact ? 1 : 0)); }
 JNIEXPORT jdoubleArray JNICALL J(graphGetAlias)(JNIEnv* e, jclass, jlong g, jint v, jdoubleArray prob, jintArray alias, jintArray nbr) {
@@ -38,6 +47,39 @@ JNIEXPORT jdoubleArray JNICALL J(graphGetAlias)(JNIEnv* e, jclass, jlong g, jint
     e->ReleaseDoubleArrayElements(prob, pp, 0); e->ReleaseIntArrayElements(alias, pa, 0); e->ReleaseIntArrayElements(nbr, pn, 0);
     if (fail(e, rc)) return nullptr;
     jdouble r[2] = {(jdouble)k, od}; jdoubleArray out = e->NewDoubleArray(2); e->SetDoubleArrayRegion(out, 0, 2, r); return out;
+}
+// any array may be null; lengths are taken from the arrays themselves
+JNIEXPORT void JNICALL J(graphGetCsr)(JNIEnv* e, jclass, jlong g, jlongArray rowPtr, jintArray nbr, jdoubleArray w, jdoubleArray prob, jintArray alias,
+                                      jdoubleArray outDegree) {
+    jlong* prp = rowPtr ? e->GetLongArrayElements(rowPtr, nullptr) : nullptr;
+    jint* pn = nbr ? e->GetIntArrayElements(nbr, nullptr) : nullptr;
+    jdouble* pw = w ? e->GetDoubleArrayElements(w, nullptr) : nullptr;
+    jdouble* pp = prob ? e->GetDoubleArrayElements(prob, nullptr) : nullptr;
+    jint* pa = alias ? e->GetIntArrayElements(alias, nullptr) : nullptr;
+    jdouble* po = outDegree ? e->GetDoubleArrayElements(outDegree, nullptr) : nullptr;
+    jsize capV = 0x7fffffff; int64_t capE = INT64_MAX;
+    if (rowPtr) capV = e->GetArrayLength(rowPtr) - 1;
+    if (outDegree) capV = std::min<jsize>(capV, e->GetArrayLength(outDegree));
+    if (nbr) capE = std::min<int64_t>(capE, e->GetArrayLength(nbr));
+    if (w) capE = std::min<int64_t>(capE, e->GetArrayLength(w));
+    if (prob) capE = std::min<int64_t>(capE, e->GetArrayLength(prob));
+    if (alias) capE = std::min<int64_t>(capE, e->GetArrayLength(alias));
+    static_assert(sizeof(jlong) == sizeof(int64_t), "jlong is 64 bits");
+    int rc = dge_graph_get_csr((const dge_graph*)g, (int64_t*)prp, (int32_t*)pn, pw, pp, (int32_t*)pa, po, capV, capE);
+    if (rowPtr) e->ReleaseLongArrayElements(rowPtr, prp, 0);
+    if (nbr) e->ReleaseIntArrayElements(nbr, pn, 0);
+    if (w) e->ReleaseDoubleArrayElements(w, pw, 0);
+    if (prob) e->ReleaseDoubleArrayElements(prob, pp, 0);
+    if (alias) e->ReleaseIntArrayElements(alias, pa, 0);
+    if (outDegree) e->ReleaseDoubleArrayElements(outDegree, po, 0);
+    fail(e, rc);
+}
+JNIEXPORT void JNICALL J(graphGetSourceAlias)(JNIEnv* e, jclass, jlong g, jdoubleArray prob, jintArray alias) {
+    jint cap = e->GetArrayLength(prob); int32_t k = 0;
+    jdouble* pp = e->GetDoubleArrayElements(prob, nullptr); jint* pa = e->GetIntArrayElements(alias, nullptr);
+    int rc = dge_graph_get_source_alias((const dge_graph*)g, pp, (int32_t*)pa, nullptr, cap, &k, nullptr);
+    e->ReleaseDoubleArrayElements(prob, pp, 0); e->ReleaseIntArrayElements(alias, pa, 0);
+    fail(e, rc);
 }
 JNIEXPORT jint JNICALL J(graphSampleNext)(JNIEnv* e, jclass, jlong g, jint v, jdouble x) { int32_t n = -1; fail(e, dge_graph_sample_next((dge_graph*)g, v, x, &n)); return n; }
 JNIEXPORT jlong JNICALL J(sampleWalks)(JNIEnv* e, jclass, jlong g, jlong n, jint L, jlong seed, jint mode, jlong first, jintArray out) {

@@ -69,6 +69,7 @@ struct orc_graph {
     double* prob; int32_t* alias;  /* per-vertex alias tables, concatenated by row_ptr */
     /* sources (:145-148) */
     int64_t n_src; int32_t* srcv; double src_weight_sum; double* src_prob; int32_t* src_alias;
+    int src_stream_sum, src_sum_fixed;
     int alias_built;
 };
 
@@ -159,7 +160,50 @@ int orc_graph_set_sources(orc_graph* g, const int32_t* v, int64_t n, int stream_
     }
     if (stream_sum) g->src_weight_sum = java8_stream_sum(od, n);
     free(od);
+    g->src_stream_sum = stream_sum ? 1 : 0; g->src_sum_fixed = 0;
     g->alias_built = 0;
+    return 0;
+}
+
+int orc_graph_reserve_vertices(orc_graph* g, int32_t n) {
+    if (!g || n < 0) return 1;
+    if (n > g->n_vertices) { g->n_vertices = n; g->built = 0; g->alias_built = 0; }
+    return 0;
+}
+/* Vertex.outDegree (J/LayeredGraph.java:35) is a public field: prob = k*w/outDegree (:62) and the source weights (:208)
+ * read whatever it holds */
+int orc_graph_set_out_degree(orc_graph* g, const double* od, int32_t n) {
+    if (!g || !od) return 1;
+    build_csr(g);
+    if (n != g->n_vertices) return 1;
+    for (int32_t v = 0; v < n; v++) g->out_degree[v] = od[v];
+    g->alias_built = 0;
+    if (g->n_src > 0 && !g->src_sum_fixed) {        /* the sum of the source weights follows, in the form set_sources used */
+        double* sw = (double*)malloc((size_t)g->n_src * sizeof(double));
+        double s = 0.0;
+        for (int64_t i = 0; i < g->n_src; i++) { sw[i] = g->out_degree[g->srcv[i]]; s += sw[i]; }
+        g->src_weight_sum = g->src_stream_sum ? java8_stream_sum(sw, g->n_src) : s;
+        free(sw);
+    }
+    return 0;
+}
+int orc_graph_set_source_weight_sum(orc_graph* g, double s) {
+    if (!g) return 1;
+    g->src_weight_sum = s; g->src_sum_fixed = 1; g->alias_built = 0;
+    return 0;
+}
+int orc_graph_get_csr(const orc_graph* gc, int64_t* row_ptr, int32_t* nbr, double* weight, double* prob, int32_t* alias, double* out_degree) {
+    orc_graph* g = (orc_graph*)gc;
+    if (!g) return 1;
+    build_csr(g);
+    int32_t V = g->n_vertices; int64_t E = g->row_ptr[V];
+    if ((prob || alias) && !g->alias_built) return 5;
+    if (row_ptr) memcpy(row_ptr, g->row_ptr, ((size_t)V + 1) * sizeof(int64_t));
+    if (out_degree) memcpy(out_degree, g->out_degree, (size_t)V * sizeof(double));
+    if (nbr) memcpy(nbr, g->nbr, (size_t)E * sizeof(int32_t));
+    if (weight) memcpy(weight, g->wt, (size_t)E * sizeof(double));
+    if (prob) memcpy(prob, g->prob, (size_t)E * sizeof(double));
+    if (alias) memcpy(alias, g->alias, (size_t)E * sizeof(int32_t));
     return 0;
 }
 

@@ -40,6 +40,12 @@ void  orc_graph_free(orc_graph* g);
 int   orc_graph_add_edges(orc_graph* g, const int32_t* src, const int32_t* dst, const double* w, int64_t n);
 int   orc_graph_set_sources(orc_graph* g, const int32_t* v, int64_t n, int stream_sum);
 int   orc_graph_keep_top_k(orc_graph* g, int32_t k);
+/* hosts that keep the reference's public fields hand them over: vertex count incl. isolated vertices
+ * (J/LayeredGraph.java:182-183), Vertex.outDegree (:35), sourceWeightSum (:146; J/SpatialGraph.java:57,83) */
+int   orc_graph_reserve_vertices(orc_graph* g, int32_t n);
+int   orc_graph_set_out_degree(orc_graph* g, const double* od, int32_t n);
+int   orc_graph_set_source_weight_sum(orc_graph* g, double s);
+int   orc_graph_get_csr(const orc_graph* g, int64_t* row_ptr, int32_t* nbr, double* weight, double* prob, int32_t* alias, double* out_degree);
 int   orc_graph_build_alias(orc_graph* g, int exact_reference_order);
 int32_t orc_graph_num_vertices(const orc_graph* g);
 int64_t orc_graph_num_edges(const orc_graph* g);

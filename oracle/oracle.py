@@ -52,6 +52,10 @@ def lib():
     L.orc_graph_add_edges.argtypes = [vp, vp, vp, vp, i64]
     L.orc_graph_set_sources.argtypes = [vp, vp, i64, C.c_int]
     L.orc_graph_keep_top_k.argtypes = [vp, i32]
+    L.orc_graph_reserve_vertices.argtypes = [vp, i32]
+    L.orc_graph_set_out_degree.argtypes = [vp, vp, i32]
+    L.orc_graph_set_source_weight_sum.argtypes = [vp, dbl]
+    L.orc_graph_get_csr.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.orc_graph_build_alias.argtypes = [vp, C.c_int]
     L.orc_graph_num_vertices.argtypes = [vp]; L.orc_graph_num_vertices.restype = i32
     L.orc_graph_num_edges.argtypes = [vp]; L.orc_graph_num_edges.restype = i64
@@ -121,6 +125,30 @@ class Graph:
     def set_sources(self, v, stream_sum=False):
         v = np.ascontiguousarray(v, np.int32)
         self._chk(lib().orc_graph_set_sources(self._h, _ptr(v), len(v), int(stream_sum)), "set_sources")
+
+    def reserve_vertices(self, n):
+        self._chk(lib().orc_graph_reserve_vertices(self._h, int(n)), "reserve_vertices")
+
+    def set_out_degree(self, od):
+        od = np.ascontiguousarray(od, np.float64)
+        self._chk(lib().orc_graph_set_out_degree(self._h, _ptr(od), len(od)), "set_out_degree")
+
+    def set_source_weight_sum(self, s):
+        self._chk(lib().orc_graph_set_source_weight_sum(self._h, float(s)), "set_source_weight_sum")
+
+    def get_csr(self, tables=True):
+        V = self.num_vertices
+        row_ptr = np.zeros(V + 1, np.int64)
+        self._chk(lib().orc_graph_get_csr(self._h, _ptr(row_ptr), None, None, None, None, None), "get_csr")
+        E = int(row_ptr[V]); n = max(E, 1)
+        nbr = np.zeros(n, np.int32); wt = np.zeros(n, np.float64); od = np.zeros(max(V, 1), np.float64)
+        prob = np.zeros(n, np.float64) if tables else None; alias = np.zeros(n, np.int32) if tables else None
+        self._chk(lib().orc_graph_get_csr(self._h, _ptr(row_ptr), _ptr(nbr), _ptr(wt), _ptr(prob) if tables else None,
+                                          _ptr(alias) if tables else None, _ptr(od)), "get_csr")
+        out = dict(row_ptr=row_ptr, nbr=nbr[:E], weight=wt[:E], out_degree=od[:V])
+        if tables:
+            out.update(prob=prob[:E], alias=alias[:E])
+        return out
 
     def keep_top_k(self, k):
         self._chk(lib().orc_graph_keep_top_k(self._h, int(k)), "keep_top_k")

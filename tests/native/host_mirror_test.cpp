@@ -1,4 +1,4 @@
-// Port of T/LayeredGraphTest.java:12-44 to the C++ host mirror (embedding_amd/host/embedding_host.hpp), plus the
+// Port of T/LayeredGraphTest.java:12-44 (in its original standalone-Vertex form) to the C++ host mirror (embedding_amd/host/embedding_host.hpp), plus the
 // writer-loop / DeepWalk plumbing (.seq -> .vec).  Needs a GPU: built and run by tests/test_gpu_host_mirror.py.
 #include <cassert>
 #include <cmath>
@@ -14,20 +14,48 @@ using namespace embedding;
 
 int main(int argc, char** argv) {
     std::string tmp = argc > 1 ? argv[1] : "/tmp";
-    {   // testAliasTable
+    {   // T/LayeredGraphTest.java:12-44 as written: standalone Vertex / Edge objects, no graph
+        LayeredGraph::Vertex org("start", 0), d1("d1", 1), d2("d2", 2), d3("d3", 3);
+        LayeredGraph::Edge e1(&org, &d1, 2), e2(&org, &d2, 10), e3(&org, &d3, 8);
+        org.addOutEdge(e1); org.addOutEdge(e2); org.addOutEdge(e3);
+        org.initiateAliasTable();
+        CHECK(org.aliasTable[0] == 1); CHECK(org.aliasTable[1] == 2); CHECK(org.aliasTable[2] == -1);
+        CHECK(org.probTable[0] == 0.3); CHECK(org.probTable[1] == 0.8); CHECK(org.probTable[2] == 1.0);
+        CHECK(org.outDegree == 20.0);
+        CHECK(org.sampleNextVertex(0.05)->id == 1); CHECK(org.sampleNextVertex(0.3)->id == 2); CHECK(org.sampleNextVertex(0.4)->id == 2);
+        CHECK(org.sampleNextVertex(0.65)->id == 3); CHECK(org.sampleNextVertex(0.9)->id == 3);
+        CHECK(d1.sampleNextVertex() == nullptr);                      // dead end: null, and no draw taken (:106-107)
+        LayeredGraph::rnd = Random(42);
+        LayeredGraph::Vertex* nx = org.sampleNextVertex();            // x = 0.7275636800328681 -> slot 2, y = 0.18 < 1 -> d3
+        CHECK(nx == &d3 && LayeredGraph::rnd.draws() == 1);
+    }
+    {   // the same through a graph: tables land in the Vertex fields, ids are insertion ordinals, public state is honoured
         LayeredGraph g;
         g.addEdge("start", "d1", 2);
         g.addEdge("start", "d2", 10);
         g.addEdge("start", "d3", 8);
         g.addSourceVertex("start");
+        CHECK(g.allEdges.size() == 3 && g.allEdges[1].to->name == "d2" && g.sourceWeightSum == 20.0);
         g.initiateAliasTables();
-        LayeredGraph::Vertex org = g.vertex("start");
-        CHECK(org.aliasTable[0] == 1); CHECK(org.aliasTable[1] == 2); CHECK(org.aliasTable[2] == -1);
-        CHECK(org.probTable[0] == 0.3); CHECK(org.probTable[1] == 0.8); CHECK(org.probTable[2] == 1.0);
-        CHECK(org.outDegree == 20.0);
-        CHECK(org.sampleNextVertex(0.05) == 1); CHECK(org.sampleNextVertex(0.3) == 2); CHECK(org.sampleNextVertex(0.4) == 2);
-        CHECK(org.sampleNextVertex(0.65) == 3); CHECK(org.sampleNextVertex(0.9) == 3);
-        CHECK(g.vertex("d1").id == 1 && g.vertex("d3").id == 3);      // ids are insertion ordinals
+        LayeredGraph::Vertex& org = *g.allVertices.at("start");
+        CHECK(org.aliasTable[0] == 1 && org.aliasTable[1] == 2 && org.aliasTable[2] == -1);
+        CHECK(org.probTable[0] == 0.3 && org.probTable[1] == 0.8 && org.probTable[2] == 1.0 && org.outDegree == 20.0);
+        CHECK(org.sampleNextVertex(0.05)->id == 1 && org.sampleNextVertex(0.65)->id == 3);
+        CHECK(g.allVertices.at("d1")->id == 1 && g.allVertices.at("d3")->id == 3);
+        CHECK(g.probTable.size() == 1 && g.probTable[0] == 1.0 && g.aliasTable[0] == -1);
+        // a caller edits the public fields (as J/SpatialGraph.java:31-33 does): the next initiateAliasTables() uses them as they stand
+        org.edgesOut.pop_back(); org.outDegree = 12.0;
+        g.initiateAliasTables();
+        CHECK(org.probTable.size() == 2 && org.probTable[0] == 2 * 2.0 / 12.0 && org.aliasTable[0] == 1);
+        // an unknown source name: unregistered vertex (J/LayeredGraph.java:182-183); a walk from it is the single token
+        LayeredGraph g2;
+        g2.addEdge("a", "b", 1);
+        g2.addSourceVertex("ghost");
+        CHECK(g2.allVertices.count("ghost") == 0 && g2.sourceVertices.size() == 1 && g2.sourceVertices[0]->id == 2);
+        g2.initiateAliasTables();
+        LayeredGraph::numLayer = 3;
+        std::vector<std::string> w = g2.sampleVertexSequence();
+        CHECK(w.size() == 1 && w[0] == "ghost");
     }
     {   // java.util.Random mirror: seed 42 -> 0.7275636800328681 ; seed 0 -> 0.730967787376657
         Random r(42); CHECK(r.nextDouble() == 0.7275636800328681);
@@ -88,14 +116,23 @@ int main(int argc, char** argv) {
         for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) wt.push_back(std::exp(-100.0 * std::fabs(i - j) * 0.004));
         SpatialGraph g;
         SpatialGraph::constructGraph(g, names, wt);
-        CHECK(g.vertex("105").edgesOutTo.size() == 10);
+        CHECK(g.allVertices.at("105")->edgesOut.size() == 10);
+        {   // the pruned store is visible in the public fields: nearest first (self loop, w = 1), outDegree = DoubleStream.sum()
+            const LayeredGraph::Vertex& v = *g.allVertices.at("105");
+            CHECK(v.edgesOut[0].to == &v && v.edgesOut[0].weight == 1.0);
+            std::vector<double> ws; for (const auto& e : v.edgesOut) ws.push_back(e.weight);
+            CHECK(v.outDegree == SpatialGraph::java8StreamSum(ws));
+            for (size_t i = 1; i < v.edgesOut.size(); i++) CHECK(v.edgesOut[i - 1].weight >= v.edgesOut[i].weight);
+        }
         LayeredGraph::rnd = Random(7);
         SpatialGraph::outputSampleSequence(g, tmp + "/taxi-spatial.seq");
         std::ifstream in(tmp + "/taxi-spatial.seq"); std::string line; std::getline(in, line);
         CHECK(line.substr(0, 2) == "0-" && line.find(" 1-") != std::string::npos && line.find(" 2-") != std::string::npos);
     }
-    {   // DeepWalk.learnEmbedding on both corpora (the "usespatial" directory case, J/DeepWalk.java:47-50)
+    {   // DeepWalk.learnEmbedding on both corpora (the "usespatial" directory case, J/DeepWalk.java:47-50), negative sampling alone
         LayeredGraph::numLayer = 3;
+        CHECK(DeepWalk::useHierarchicSoftmax);                        // the default is what DL4J's builder leaves on
+        DeepWalk::useHierarchicSoftmax = false;
         dge_train_stats st = DeepWalk::learnEmbedding({seq, tmp + "/taxi-spatial.seq"}, vec, 20);
         CHECK(st.pairs > 0);
         std::ifstream in(vec); std::string line; int lines = 0;
@@ -111,7 +148,6 @@ int main(int argc, char** argv) {
         DeepWalk::useHierarchicSoftmax = true;
         const std::string vec_hs = tmp + "/taxi-deepwalk-hs.vec";
         dge_train_stats st = DeepWalk::learnEmbedding({seq, tmp + "/taxi-spatial.seq"}, vec_hs, 20, 0, 1);
-        DeepWalk::useHierarchicSoftmax = false;
         CHECK(st.pairs > 0);
         std::ifstream a(vec), b(vec_hs); std::string la, lb; int lines = 0, differ = 0;
         while (std::getline(a, la) && std::getline(b, lb)) { lines++; if (la != lb) differ++; }

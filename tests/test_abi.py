@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(dge):
 
 def test_struct_layouts(dge):
     assert C.sizeof(dge.TrainConfig) == 64 and C.sizeof(dge.TrainStats) == 40
-    assert dge.lib.dge_version() == 101
+    assert dge.lib.dge_version() == 102
 
 
 def test_no_device_means_loud_failure(dge):
@@ -79,3 +79,74 @@ def test_bench_workloads_and_traffic_table():
     assert bench.measured_traffic("cfg3", "policy99", 1.0) is None
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert "edges" in base["metric"].lower() or "edges" in json.dumps(base).lower()
+
+
+# ---------------------------------------------------------------------------------------------- the Java / JNI form (source only: no JDK here)
+JAVA = os.path.join(ROOT, "java", "embedding")
+
+
+def _java(name):
+    txt = open(os.path.join(JAVA, name)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return re.sub(r"//[^\n]*", "", txt)
+
+
+def test_jni_shim_matches_native_engine_and_the_header():
+    """java/jni/dge_jni.cpp: one JNI function per `static native` of NativeEngine.java, every C entry point it calls is declared in
+    include/dge.h, and its C++ passes g++ -fsyntax-only against a declaration-only stand-in for jni.h (tests/native/jni_stub — not
+    the JDK's header; a real build needs $JAVA_HOME)."""
+    import subprocess
+    natives = set(re.findall(r"static native [\w\[\]]+ (\w+)\(", _java("NativeEngine.java")))
+    shim = open(os.path.join(ROOT, "java", "jni", "dge_jni.cpp")).read()
+    assert natives == set(re.findall(r"\bJ\((\w+)\)\(", shim)) and len(natives) >= 18
+    called = set(re.findall(r"\b(dge_[a-z0-9_]+)\s*\(", re.sub(r"//[^\n]*", "", shim)))
+    assert called <= set(_declared()), called - set(_declared())
+    used = set()
+    for f in os.listdir(JAVA):
+        used |= set(re.findall(r"NativeEngine\.(\w+)\(", _java(f)))
+    assert used <= natives, used - natives                          # every native the Java classes call exists
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(ROOT, "tests", "native", "jni_stub"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "java", "jni", "dge_jni.cpp")])
+
+
+def test_java_surface_lists_every_member_of_the_scope_table():
+    """the public Java member set a drop-in must keep (signatures from J/LayeredGraph.java, J/CrossTimeGraph.java,
+    J/SpatialGraph.java, J/DeepWalk.java).  Text check only — javac is not in this image."""
+    lg = _java("LayeredGraph.java")
+    for decl in ("public static Random rnd", "public static int numLayer", "static public class Edge", "public Vertex from", "public Vertex to",
+                 "public double weight", "public Edge(Vertex f, Vertex t, double w)", "static public class Vertex", "public String name",
+                 "public int id", "public List<Edge> edgesOut", "public double outDegree", "int[] aliasTable", "double[] probTable",
+                 "public Vertex(String n, int i)", "public void addOutEdge(Edge e)", "public void initiateAliasTable()",
+                 "public Vertex sampleNextVertex()", "public Vertex sampleNextVertex(double x)", "public List<Edge> allEdges",
+                 "public Map<String, Vertex> allVertices", "public List<Vertex> sourceVertices", "protected double sourceWeightSum",
+                 "protected double[] probTable", "protected int[] aliasTable", "public LayeredGraph()",
+                 "public void addEdge(String fn, String tn, double weight)", "public void addSourceVertex(String vn)",
+                 "public void initiateAliasTables()", "public List<String> sampleVertexSequence()"):
+        assert decl in lg, decl
+    ct = _java("CrossTimeGraph.java")
+    for decl in ("public class CrossTimeGraph extends LayeredGraph", "public static int numSamples", "public static int numLayer",
+                 "public static CrossTimeGraph constructGraph_tract()", "public static CrossTimeGraph constructGraph_CA()",
+                 "public static CrossTimeGraph constructGraph_CA(int[] timeIntervals)",
+                 "public static void outputSampleSequence(String regionLevel, int[] timeIntervals)",
+                 "public static void outputSampleSequence(String regionLevel)",
+                 "public static void sampleSequenceHelper(CrossTimeGraph g, String regionLevel)", "public static void main(String[] argv)"):
+        assert decl in ct, decl
+    sg = _java("SpatialGraph.java")
+    for decl in ("public class SpatialGraph extends LayeredGraph", "public static int numSamples", "public static int numLayer",
+                 "public void keepNearestKVertices(int k)", "public static SpatialGraph constructGraph_tract()",
+                 "public static SpatialGraph constructGraph_CA()", "public static void outputSampleSequence(String regionLevel)",
+                 "public static void main(String[] argv)", "NativeEngine.graphKeepTopK"):
+        assert decl in sg, decl
+    dw = _java("DeepWalk.java")
+    for decl in ("public static int Year", "public static void learnEmbedding() throws Exception",
+                 "public static void learnEmbedding(String regionLevel, String spatialGF) throws Exception",
+                 "public static void checkInputFile(String regionLevel, String spatialGF)", "public static void main(String[] argv)"):
+        assert decl in dw, decl
+    # the reference's own test (T/LayeredGraphTest.java:13-43) uses exactly these expressions on the class above
+    for use in ("new LayeredGraph.Vertex(", "new LayeredGraph.Edge(", ".addOutEdge(", ".initiateAliasTable()", ".aliasTable[", ".probTable[",
+                ".outDegree", ".sampleNextVertex("):
+        assert use.strip(".(").split(".")[-1].split("(")[0].split("[")[0] in lg
+    for f in os.listdir(JAVA):                                      # balanced braces / parentheses: the cheapest syntax check there is
+        t = _java(f)
+        t = re.sub(r'"(\\.|[^"\\])*"', '""', t); t = re.sub(r"'(\\.|[^'\\])'", "' '", t)
+        assert t.count("{") == t.count("}") and t.count("(") == t.count(")") and t.count("[") == t.count("]"), f

@@ -199,3 +199,48 @@ def test_full_size_walk_properties(dge):
     # source choice follows out-degree (J/LayeredGraph.java:199-204)
     sa = g.get_source_alias()
     assert abs(sa["prob"].mean() - 1.0) < 0.5 and sa["weight_sum"] > 0
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_host_held_public_fields_are_honoured(dge, oracle, exact):
+    """The reference's Vertex.outDegree and LayeredGraph.sourceWeightSum are fields that callers assign (J/LayeredGraph.java:35,146;
+    J/SpatialGraph.java:33,57), and addSourceVertex may create vertices no edge names (:182-183).  A host that keeps those fields
+    hands them over (dge_graph_reserve_vertices / set_out_degree / set_source_weight_sum) and reads every table back in one piece
+    (dge_graph_get_csr): bit-exact against the oracle fed the same values, walks included."""
+    src, dst, w, sources = layered_graph(R=50, T=4, deg=7, seed=11)
+    rng = np.random.default_rng(3)
+    V = int(max(src.max(), dst.max())) + 1
+    og, dg = oracle.Graph(), dge.DeviceGraph(0)
+    for g in (og, dg):
+        g.add_edges(src, dst, w)
+        g.reserve_vertices(V + 3)                                    # three isolated vertices (unregistered sources)
+    od = og.get_csr(tables=False)["out_degree"].copy()
+    assert len(od) == V + 3 and np.array_equal(bits(od), bits(dg.get_csr(tables=False)["out_degree"]))
+    od[:V] *= rng.choice([1.0, 1.0, 1.0 + 2.0 ** -40, 0.5, 3.0], V)  # fields as a caller left them, not the running sums
+    srcs = np.concatenate([sources, [V + 1, V]]).astype(np.int32)
+    for g in (og, dg):
+        g.set_out_degree(od)
+        g.set_sources(srcs)
+        g.set_source_weight_sum(float(od[srcs].sum()) * 1.25)
+        g.build_alias(exact)
+    a, b = og.get_csr(), dg.get_csr()
+    assert np.array_equal(a["row_ptr"], b["row_ptr"]) and np.array_equal(a["nbr"], b["nbr"]) and np.array_equal(a["alias"], b["alias"])
+    for k in ("weight", "prob", "out_degree"):
+        assert np.array_equal(bits(a[k]), bits(b[k])), k
+    assert np.array_equal(bits(b["out_degree"]), bits(od))
+    for v in (0, 7, V - 1, V + 2):                                    # the per-vertex view agrees with the bulk one
+        x = dg.get_alias(v); lo, hi = b["row_ptr"][v], b["row_ptr"][v + 1]
+        assert np.array_equal(bits(x["prob"]), bits(b["prob"][lo:hi])) and np.array_equal(x["alias"], b["alias"][lo:hi])
+    sa, sb = og.get_source_alias(), dg.get_source_alias()
+    assert sa["weight_sum"] == sb["weight_sum"] == float(od[srcs].sum()) * 1.25
+    assert np.array_equal(sa["alias"], sb["alias"]) and np.array_equal(bits(sa["prob"]), bits(sb["prob"]))
+    for mode in (0, 1):
+        assert np.array_equal(og.sample_walks(3000, 4, seed=9, rng_mode=mode), dg.sample_walks(3000, 4, seed=9, rng_mode=mode))
+    # refreshed source weights when the fields change after set_sources; a later set_sources drops the fixed sum
+    od2 = od * 2.0
+    for g in (og, dg):
+        g.set_sources(srcs); g.set_out_degree(od2); g.build_alias(exact)
+    sa, sb = og.get_source_alias(), dg.get_source_alias()
+    assert sa["weight_sum"] == sb["weight_sum"] and np.array_equal(bits(sa["prob"]), bits(sb["prob"]))
+    with pytest.raises(dge.DgeError):
+        dg.set_out_degree(od[:-1])                                    # one value per vertex

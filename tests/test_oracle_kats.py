@@ -275,6 +275,29 @@ def test_file_formats_roundtrip(tmp_path, oracle):
     assert n == ["1", "2", "3"] and v.shape == (3, 8)
 
 
+def test_od_sources_include_a_destination_only_layer0_vertex(tmp_path, oracle):
+    """J/CrossTimeGraph.java:43-47 adds EVERY "0-<id>" that exists in allVertices as a source — also a region that slice 0 never
+    leaves but slice T-1 arrives at (outDegree 0: it sits in the source alias table with weight 0 and is never drawn).  The source
+    table's length k enters every draw (i = (int)(x*k)), so leaving such a vertex out would change all seeded walks."""
+    from embedding_amd import io
+    rows = {0: [(10, 11, 3), (11, 10, 2)], 1: [(10, 11, 1), (11, 12, 4)]}      # region 12: only a destination of the LAST slice
+    paths = []
+    for h in (0, 1):
+        p = tmp_path / ("taxi-h%d.od" % h)
+        with open(p, "w") as f:
+            for a, b, w in rows[h]:
+                f.write("%d %d %d\n" % (a, b, w))
+        paths.append(str(p))
+    G = io.read_od_slices(paths)
+    assert G["regions"].tolist() == [10, 11, 12] and G["names"][2] == "0-12"
+    assert G["sources"].tolist() == [0, 1, 2]                         # "0-12" is a source although nothing leaves it
+    g = oracle.Graph(); g.add_edges(G["src"], G["dst"], G["w"]); g.set_sources(G["sources"]); g.build_alias(True)
+    sa = g.get_source_alias()
+    assert len(sa["prob"]) == 3 and sa["prob"][2] == 0.0 and sa["weight_sum"] == 5.0
+    walks = g.sample_walks(500, 2, seed=3, rng_mode=0)
+    assert (walks[:, 0] != 2).all() and set(walks[:, 0].tolist()) == {0, 1}
+
+
 def test_quality_metric_restatement(oracle):
     """embedding_amd/evaluate.py (P/embeddingEvaluation_tract.py:169-196,249-260): KNN by cosine distance + nDCG@k."""
     from embedding_amd import evaluate as ev
