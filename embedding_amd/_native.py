@@ -92,6 +92,7 @@ SIGNATURES = {
     "dge_comm_free": (None, [_vp]),
     "dge_model_allreduce_deltas": (_int, [_vp, _vp]),
     "dge_model_exchange_partitions": (_int, [_vp, _vp, _int, _i32]),
+    "dge_set_tuning": (_int, [_i32, _i64]),
     "dge_knn_cosine": (_int, [_int, _vp, _i32, _i32, _i32, _vp, _vp, _P(_dbl)]),
     "dge_selftest_locked_rows": (_int, [_int, _i32, _i64, _i32, C.c_uint64, _i32, _P(_i64), _P(_dbl)]),
     "dge_selftest_hot_add": (_int, [_int, _i32, _i64, _i32, _i32, C.c_uint64, _P(_i64), _P(_dbl)]),

@@ -309,7 +309,7 @@ extern "C" int dge_graph_create(dge_graph** out, int device) {
     if (rc) return rc;
     dge_graph* g = new dge_graph();
     g->device = device;
-    DGE_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { delete g; DGE_FAIL(DGE_ERR_DEVICE, "dge_graph_create: hipStreamCreate failed"); }
     g->own_stream = true;
     *out = g;
     return DGE_OK;
@@ -811,7 +811,10 @@ extern "C" int dge_walks_from_host(int device, const int32_t* walks, int64_t n_w
     w->device = device; w->n = n_walks; w->L = max_len;
     rc = dge_dev_alloc(&w->d, (size_t)(n_walks * max_len));
     if (rc) { delete w; return rc; }
-    if (n_walks) DGE_HIP(hipMemcpy(w->d, walks, (size_t)(n_walks * max_len) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (n_walks && hipMemcpy(w->d, walks, (size_t)(n_walks * max_len) * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        dge_walks_free(w);
+        DGE_FAIL(DGE_ERR_DEVICE, "dge_walks_from_host: copy to the device failed");
+    }
     *out = w;
     return DGE_OK;
 }

@@ -29,6 +29,14 @@
 
 struct EventPair { hipEvent_t a, b; int kind; };
 
+// ablation / test knobs (dge_set_tuning): -1 = the library's own rule
+static int64_t g_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1};
+extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
+    if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
+    g_tuning[knob] = value < 0 ? -1 : value;
+    return DGE_OK;
+}
+
 struct dge_model {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -522,6 +530,37 @@ void dge_launch_train_dch4(const TrainParams& p, int pol, bool big, unsigned blo
 void dge_launch_train_dch6(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st);
 void dge_launch_train_dch8(const TrainParams& p, int pol, bool big, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st);
 
+// Launch timing: a pair of events per kernel launch, read by dge_model_stats.  A host that trains in a long loop without asking for
+// stats must not pile up event handles: launches of one model complete in stream order, so once 64 pairs are pending the finished
+// ones at the front are folded into the totals and destroyed.
+static void reap_finished_events(dge_model* m) {
+    size_t n = 0;
+    while (n < m->pending.size() && hipEventQuery(m->pending[n].b) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->pending[n].a, m->pending[n].b) == hipSuccess) { if (m->pending[n].kind == 0) m->kernel_ms += ms; else m->walk_ms += ms; }
+        (void)hipEventDestroy(m->pending[n].a); (void)hipEventDestroy(m->pending[n].b);
+        n++;
+    }
+    m->pending.erase(m->pending.begin(), m->pending.begin() + (ptrdiff_t)n);
+}
+static int timing_begin(dge_model* m, EventPair& ev, int kind) {
+    if (m->pending.size() >= 64) reap_finished_events(m);
+    ev.kind = kind; ev.a = nullptr; ev.b = nullptr;
+    DGE_HIP(hipEventCreate(&ev.a));
+    if (hipEventCreate(&ev.b) != hipSuccess) { (void)hipEventDestroy(ev.a); DGE_FAIL(DGE_ERR_DEVICE, "hipEventCreate failed"); }
+    if (hipEventRecord(ev.a, m->stream) != hipSuccess) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); DGE_FAIL(DGE_ERR_DEVICE, "hipEventRecord failed"); }
+    return DGE_OK;
+}
+static int timing_end(dge_model* m, EventPair& ev, int rc_so_far) {
+    if (rc_so_far != DGE_OK || hipEventRecord(ev.b, m->stream) != hipSuccess) {
+        (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
+        if (rc_so_far != DGE_OK) return rc_so_far;
+        DGE_FAIL(DGE_ERR_DEVICE, "hipEventRecord failed");
+    }
+    m->pending.push_back(ev);
+    return DGE_OK;
+}
+
 static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32_t L, int64_t walk_index_base, int32_t epoch,
                       int64_t words_before, double words_scale, int64_t total_walks) {
     if (n_rows == 0 || m->V == 0) return DGE_OK;
@@ -549,7 +588,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt; p.syn0_free = 0;
     p.big_seg_shift = 0;
     p.filler_row = (int32_t)(0xFFFFFFF0u / ((uint32_t)m->stride * 4u)) - 1;      // offset + the largest in-row displacement stays below 2^32
-    if (const char* e = getenv("DGE_BIG_SEG_SHIFT")) p.big_seg_shift = atoi(e);          // tests: several segments on a small table
+    if (g_tuning[DGE_TUNE_SEGMENT_SHIFT] >= 0) p.big_seg_shift = (int32_t)g_tuning[DGE_TUNE_SEGMENT_SHIFT];   // tests: several segments on a small table
     const bool part = m->part_n > 1;
     const bool hs = m->cfg.use_hs != 0;
     if (part && hs) DGE_FAIL(DGE_ERR_STATE, "the block schedule (dge_model_set_partition) cannot carry the hierarchical-softmax term: a Huffman path crosses every partition");
@@ -584,7 +623,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         const double fail_all = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
         // a flat vocabulary with a few busy rows: only those; a skewed one: the whole head
         p.hot_rows = (int32_t)std::min<int64_t>((m->cfg.update_policy == 0 && fail_all < 0.25) ? m->hot_rows_serial : std::max(m->hot_rows_auto, m->hot_rows_serial), m->V);
-        if (const char* e = getenv("DGE_HOT_ROWS")) { long long v = atoll(e); if (v >= 0) p.hot_rows = (int32_t)std::min<int64_t>(v, m->V); }     // tuning/ablation knob
+        if (g_tuning[DGE_TUNE_HOT_ROWS] >= 0) p.hot_rows = (int32_t)std::min<int64_t>(g_tuning[DGE_TUNE_HOT_ROWS], m->V);     // ablation knob
     }
     if (pol == 100 || (workers == 1 && pol != 5 && pol != 6 && pol != 7 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
     if (pol == 3) pol = 0;
@@ -621,19 +660,18 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
             p.hs_n_hot = (int32_t)std::min<int64_t>(std::max<int64_t>(m->V - 1, 0), 30720 / row_b);
             p.hs_hot0 = (int32_t)(std::max<int64_t>(m->V - 1, 0) - p.hs_n_hot);
             p.hs_drain = 64;
-            if (const char* e = getenv("DGE_HS_DRAIN")) { int v = atoi(e); if (v >= 1) p.hs_drain = v; }      // tuning/ablation knob
+            if (g_tuning[DGE_TUNE_HS_DRAIN] >= 1) p.hs_drain = (int32_t)g_tuning[DGE_TUNE_HS_DRAIN];      // ablation knob
             shmem = (size_t)p.hs_n_hot * (size_t)row_b;
         }
     }
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
 
-    // per-segment descriptors (TableView) for tables of 4 GiB and more; DGE_FORCE_BIG=1 selects that code path on small
+    // per-segment descriptors (TableView) for tables of 4 GiB and more; DGE_TUNE_FORCE_SEGMENTS selects that code path on small
     // tables too so that the parity tests can cover it
-    const bool big = (uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull || getenv("DGE_FORCE_BIG") != nullptr;
-    EventPair ev; ev.kind = 0;
-    DGE_HIP(hipEventCreate(&ev.a)); DGE_HIP(hipEventCreate(&ev.b));
-    DGE_HIP(hipEventRecord(ev.a, st));
+    const bool big = (uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull || g_tuning[DGE_TUNE_FORCE_SEGMENTS] > 0;
+    EventPair ev;
+    if ((rc = timing_begin(m, ev, 0))) return rc;
     switch (m->stride / 64) {
         case 1: dge_launch_train_dch1(p, pol, big, blocks, threads, shmem, st); break;
         case 2: dge_launch_train_dch2(p, pol, big, blocks, threads, shmem, st); break;
@@ -642,8 +680,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         case 6: dge_launch_train_dch6(p, pol, big, blocks, threads, shmem, st); break;
         default: dge_launch_train_dch8(p, pol, big, blocks, threads, shmem, st); break;
     }
-    DGE_HIP(hipEventRecord(ev.b, st));
-    m->pending.push_back(ev);
+    if ((rc = timing_end(m, ev, DGE_OK))) return rc;
     m->launches++;
     m->last_policy = pol >= 20 ? pol - 20 : (pol >= 10 ? pol - 10 : pol); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
     DGE_HIP(hipGetLastError());
@@ -666,13 +703,11 @@ extern "C" int dge_model_walk_and_train(dge_model* m, const dge_graph* g, dge_wa
     if (!g->alias_built) DGE_FAIL(DGE_ERR_STATE, "dge_model_walk_and_train: alias tables not built");
     if (w->device != m->device || g->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_walk_and_train: handles live on different devices");
     DGE_HIP(hipSetDevice(m->device));
-    EventPair ev; ev.kind = 1;
-    DGE_HIP(hipEventCreate(&ev.a)); DGE_HIP(hipEventCreate(&ev.b));
-    DGE_HIP(hipEventRecord(ev.a, m->stream));
-    int rc = dge_launch_walks_strided(g, m->stream, w->d + row0 * w->L, n_rows, w->L, walk_seed, walk_index_base, nullptr);
+    EventPair ev;
+    int rc = timing_begin(m, ev, 1);
     if (rc) return rc;
-    DGE_HIP(hipEventRecord(ev.b, m->stream));
-    m->pending.push_back(ev);
+    rc = timing_end(m, ev, dge_launch_walks_strided(g, m->stream, w->d + row0 * w->L, n_rows, w->L, walk_seed, walk_index_base, nullptr));
+    if (rc) return rc;
     if (total_walks <= 0) total_walks = w->n;
     return train_rows(m, w->d + row0 * w->L, n_rows, w->L, walk_index_base, epoch, words_before, words_scale, total_walks);
 }
@@ -779,8 +814,7 @@ static int drain_events(dge_model* m) {
     DGE_HIP(hipStreamSynchronize(m->stream));
     for (auto& e : m->pending) {
         float ms = 0.f;
-        DGE_HIP(hipEventElapsedTime(&ms, e.a, e.b));
-        if (e.kind == 0) m->kernel_ms += ms; else m->walk_ms += ms;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { if (e.kind == 0) m->kernel_ms += ms; else m->walk_ms += ms; }
         (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
     }
     m->pending.clear();

@@ -342,3 +342,24 @@ class SgnsModel:
 
     def import_delta(self, d_buf, scale):
         check(lib.dge_model_import_delta(self._h, _dev_ptr(d_buf), float(scale)))
+
+
+TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3}      # include/dge.h: DGE_TUNE_*
+
+
+class tuning:
+    """Context manager around dge_set_tuning (ablation / test knobs of the trainer; process-wide):
+    `with tuning(hot_rows=100): model.train(...)`.  Leaving the block puts the knobs back to the library's own rules."""
+
+    def __init__(self, **knobs):
+        self.knobs = {TUNING_KNOBS[k]: int(v) for k, v in knobs.items()}
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            check(lib.dge_set_tuning(k, v))
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.knobs:
+            check(lib.dge_set_tuning(k, -1))
+        return False

@@ -274,6 +274,19 @@ int  dge_knn_cosine(int device, const float* features, int32_t n, int32_t dim, i
                     double* ms_kernel);
 
 /* ------------------------------------------------------------------------------------------------
+ * Ablation / test knobs of the trainer (process-wide, not thread-safe; nothing in a normal run sets them).  value < 0 puts
+ * a knob back to the library's own rule.
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+    DGE_TUNE_HOT_ROWS = 0,        /* update_policy 7: head rows [0, value) stay out of the lock protocol instead of the count-derived head */
+    DGE_TUNE_HS_DRAIN = 1,        /* hierarchical softmax: additions between drains of an LDS accumulator (default 64) */
+    DGE_TUNE_FORCE_SEGMENTS = 2,  /* > 0: address the tables through per-segment descriptors as tables of >= 4 GiB are (parity tests) */
+    DGE_TUNE_SEGMENT_SHIFT = 3,   /* rows per descriptor segment = 2^value (with FORCE_SEGMENTS: many segments on a small table) */
+    DGE_TUNE_COUNT = 4
+};
+int  dge_set_tuning(int32_t knob, int64_t value);
+
+/* ------------------------------------------------------------------------------------------------
  * Device self-test of the commit-lock protocol of update_policy 5 (new; no reference counterpart): n_workers groups
  * each do `iters` rounds of "lock 5 pseudo-random rows of an n_rows x 128 table, add 1.0 to every element, unlock".
  * Returns the number of row increments performed and the largest |element - increments of its row| (0 when no

@@ -1,5 +1,5 @@
 """Hierarchical softmax: quality of the device-filling schedule vs the sequential oracle (run on the GPU box).
-Usage: python scripts/quality_hs.py [R]   (env DGE_HS_DRAIN is read by the library per launch)"""
+Usage: python scripts/quality_hs.py [R]   (the drain period is set through dge_set_tuning)"""
 import os, sys, time, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import embedding_amd as E
@@ -44,7 +44,7 @@ print("oracle HS 8thr:", metrics(o8.syn0, o8.syn1neg, o8.vocab_ids), "median cos
 ons = O.train_sgns(walks, NV, D, L, negative=K, threads=8, table_size=10_000_000, arith=0)
 print("oracle NS-only 8thr:", metrics(ons.syn0, ons.syn1neg, ons.vocab_ids), flush=True)
 for workers, load in ((0, "1"), (0, "16"), (0, "64"), (0, "256"), (0, "1024"), (1024, "64"), (64, "64")):
-    os.environ["DGE_HS_DRAIN"] = load
+    E.lib.dge_set_tuning(1, int(load))            # DGE_TUNE_HS_DRAIN
     cfg = E.make_config(D, L, NV, negative=K, workers=workers, table_size=10_000_000, use_hs=True)
     dm = E.SgnsModel.fit(walks, cfg, 0); syn0, vid = dm.vectors(); st = dm.stats()
     print("gpu HS workers", workers, "drain", load, "pairs", st["pairs"], "kernel_ms %.1f" % st["kernel_ms"], metrics(syn0, dm.syn1neg(), vid),

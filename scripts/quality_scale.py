@@ -83,10 +83,10 @@ for pol in ((2, 7, 0) if ZIPF else (0, 2, 5, 6, 1, 3)):
           "| AUC %.4f pos %.3f neg %.3f" % auc(m), "| ran as", m.schedule(), flush=True)
     m.close()
 
-if ZIPF and len(sys.argv) > 2 and sys.argv[2] == "sweep":       # head size of the mixed policy (DGE_HOT_ROWS overrides the rule)
+if ZIPF and len(sys.argv) > 2 and sys.argv[2] == "sweep":       # head size of the mixed policy (dge_set_tuning overrides the rule)
     import os
     for hot in (1000, 3000, 7000, 30000, 100000):
-        os.environ["DGE_HOT_ROWS"] = str(hot)
+        E.lib.dge_set_tuning(0, hot)                 # DGE_TUNE_HOT_ROWS
         m = E.SgnsModel.create(E.make_config(D, L, NV, negative=K, workers=0, update_policy=7), counts, 0)
         m.train(corpus); st = m.stats()
         print("policy 7 head", hot, "-> %.3e edges/s" % (st["pairs"] / (st["kernel_ms"] / 1e3)), "| AUC %.4f" % auc(m)[0], flush=True)

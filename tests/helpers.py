@@ -78,3 +78,18 @@ def simulate_gather_syn0(models):
         for r in range(N):
             if r != g:
                 m.import_partition(0, N, r, bufs[r])
+
+
+def link_auc(syn0, syn1neg, vocab_ids, test_walks, R, seed=3):
+    """Link prediction on held-out walk steps: AUC of syn0[next] . syn1neg[current] for true next vertices against a random region of
+    the same slice (the statistical parity measure of scripts/quality_scale.py, on the host)."""
+    rng = np.random.default_rng(seed)
+    NV = int(max(int(vocab_ids.max()), int(test_walks.max())) + 1)
+    remap = -np.ones(NV + R, np.int64); remap[vocab_ids.astype(np.int64)] = np.arange(len(vocab_ids))
+    a = test_walks[:, :-1].reshape(-1).astype(np.int64); b = test_walks[:, 1:].reshape(-1).astype(np.int64)
+    ok = (a >= 0) & (b >= 0); a, b = a[ok], b[ok]
+    rnd = (b // R) * R + rng.integers(0, R, len(b))
+    ra, rb, rr = remap[a], remap[b], remap[np.minimum(rnd, NV - 1)]
+    ok = (ra >= 0) & (rb >= 0) & (rr >= 0); ra, rb, rr = ra[ok], rb[ok], rr[ok]
+    pos = (syn0[rb].astype(np.float64) * syn1neg[ra]).sum(1); neg = (syn0[rr].astype(np.float64) * syn1neg[ra]).sum(1)
+    return float((pos > neg).mean() + 0.5 * (pos == neg).mean())

@@ -1,0 +1,137 @@
+"""GPU parity on the SHAPES of BASELINE.json's configurations that the other suites do not reach:
+  configs[0]  the reference's own operating point — tract level, 801 regions x 8 slices, dim 20, window = walk length 8, 5 negatives,
+              minWordFrequency 2 (J/DeepWalk.java:62-76, 89-104) — at the CI size of SURVEY.md §8(d): 156 k walks;
+  configs[4]  the power-law dynamic graph, dim 256, 20 negatives, scaled down (synth.powerlaw_flow_graph_torch).
+The walk half is checked bit for bit against the oracle; the SGNS half against the oracle's restatement (parity unpinned)."""
+import numpy as np
+import pytest
+
+from helpers import bits, cosine_rows, link_auc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg1(dge, oracle):
+    from embedding_amd import synth
+    G = synth.flow_graph_numpy(801, 8, 200, seed=synth.SEED)
+    og = oracle.Graph(); dg = dge.DeviceGraph(0)
+    for g in (og, dg):
+        g.add_edges(G["src"], G["dst"], G["w"]); g.set_sources(G["sources"]); g.build_alias(True)     # the reference's pairing order
+    return G, og, dg
+
+
+def test_cfg1_reference_sized_graph_tables_and_walks_bit_exact(cfg1):
+    """801 x 8 layered graph, ~1.3 M edges, mean out-degree 200 (up to 801): every alias table in the reference's pairing order, the
+    source table over 801 sources, and all 156 k walks of the java-sequential stream (what J/CrossTimeGraph.java:134-140 writes after
+    `LayeredGraph.rnd = new Random(seed)`) and of the strided layout."""
+    G, og, dg = cfg1
+    a, b = og.get_csr(), dg.get_csr()
+    assert a["row_ptr"][-1] == len(G["src"]) > 1_000_000 and int(np.diff(a["row_ptr"]).max()) == 801
+    assert np.array_equal(a["row_ptr"], b["row_ptr"]) and np.array_equal(a["nbr"], b["nbr"]) and np.array_equal(a["alias"], b["alias"])
+    assert np.array_equal(bits(a["prob"]), bits(b["prob"])) and np.array_equal(bits(a["out_degree"]), bits(b["out_degree"]))
+    sa, sb = og.get_source_alias(), dg.get_source_alias()
+    assert len(sa["prob"]) == 801 and np.array_equal(sa["alias"], sb["alias"]) and np.array_equal(bits(sa["prob"]), bits(sb["prob"]))
+    for mode in (0, 1):
+        wo, do = og.sample_walks(156_000, 8, seed=2013, rng_mode=mode, return_draws=True)
+        wd, dd = dg.sample_walks(156_000, 8, seed=2013, rng_mode=mode, return_draws=True)
+        assert np.array_equal(wo, wd) and do == dd == 156_000 * 8            # every slice-h vertex has out-edges: 8 draws per walk
+        assert (wd // 801 == np.arange(8)[None, :]).all()                    # token j of a walk lies in slice j (J/CrossTimeGraph.java:36-39)
+
+
+def test_cfg1_full_replay_one_worker_bit_exact_and_hogwild(cfg1, dge, oracle):
+    """w2v.fit() with the reference's builder values (J/DeepWalk.java:73-76: layerSize 20, windowSize 8, negativeSample 5,
+    minWordFrequency 2, one iteration) on all 156 k walks: one in-order worker reproduces the oracle's tables bit for bit; the
+    device-filling Hogwild run trains the same pairs and stays at least as close to the sequential result as the oracle's own
+    8-thread Hogwild (.workers(8), :75) does."""
+    G, og, dg = cfg1
+    walks = dg.sample_walks(156_000, 8, seed=2013, rng_mode=0)
+    NV = 801 * 8
+    kw = dict(negative=5, min_count=2, epochs=1, seed=7, table_size=1_000_003)
+    o1 = oracle.train_sgns(walks, NV, 20, 8, threads=1, arith=1, **kw)
+    d1 = dge.SgnsModel.fit(walks, dge.make_config(20, 8, NV, workers=1, **kw), 0)
+    s0, vid = d1.vectors()
+    assert o1.V == NV and np.array_equal(vid, o1.vocab_ids) and d1.stats()["pairs"] == o1.pairs and 6.0e6 < o1.pairs < 7.2e6
+    assert np.array_equal(bits(s0), bits(o1.syn0)) and np.array_equal(bits(d1.syn1neg()), bits(o1.syn1neg))
+    # Hogwild: the device (auto schedule on a 6 408-row vocabulary) against the oracle's 8 threads
+    dh = dge.SgnsModel.fit(walks, dge.make_config(20, 8, NV, workers=0, **kw), 0)
+    o8 = oracle.train_sgns(walks, NV, 20, 8, threads=8, arith=0, **kw)
+    o0 = oracle.train_sgns(walks, NV, 20, 8, threads=1, arith=0, **kw)
+    assert dh.stats()["pairs"] == o1.pairs == o8.pairs
+    hs0 = dh.vectors()[0]
+    assert np.isfinite(hs0).all() and np.isfinite(dh.syn1neg()).all()
+    c_dev = np.median(cosine_rows(hs0, o0.syn0)); c_cpu = np.median(cosine_rows(o8.syn0, o0.syn0))
+    assert c_dev > c_cpu - 0.02, ("median cosine to the sequential result: device Hogwild %.4f, CPU 8 threads %.4f" % (c_dev, c_cpu), dh.schedule())
+    test = dg.sample_walks(20_000, 8, seed=99, rng_mode=1)
+    a_dev = link_auc(hs0, dh.syn1neg(), vid, test, 801); a_seq = link_auc(o0.syn0, o0.syn1neg, vid, test, 801)
+    a_cpu = link_auc(o8.syn0, o8.syn1neg, vid, test, 801)
+    assert a_dev > min(a_seq, a_cpu) - 0.01, (a_dev, a_seq, a_cpu)
+
+
+@pytest.fixture(scope="module")
+def cfg5_small(dge):
+    """configs[4] at 1/100: 4 166 regions x 24 slices, 10 M edges, power-law out-degree and Zipf-popular destinations"""
+    import torch
+    from embedding_amd import synth
+    G = synth.powerlaw_flow_graph_torch(4166, 24, 10_000_000, "cuda:0")
+    dg = dge.DeviceGraph(0); dg.add_edges_device(G["src"], G["dst"], G["w"]); dg.set_sources(G["sources"]); dg.build_alias(False)
+    host = dict(src=G["src"].cpu().numpy(), dst=G["dst"].cpu().numpy(), w=G["w"].cpu().numpy(), sources=G["sources"])
+    del G; torch.cuda.empty_cache()
+    return host, dg
+
+
+def test_cfg5_shaped_graph_and_one_worker_mixed_policy(cfg5_small, dge, oracle):
+    """Power-law graph (hubs of thousands of out-edges): Vose tables and walks bit-exact; then D = 256, K = 20 under the mixed policy 7
+    with the head the library derives from the counts itself (no DGE_HOT_ROWS): one worker agrees with the sequential oracle to 1e-4
+    cosine on every row."""
+    H, dg = cfg5_small
+    og = oracle.Graph(); og.add_edges(H["src"], H["dst"], H["w"]); og.set_sources(H["sources"]); og.build_alias(False)
+    deg = np.bincount(H["src"])
+    assert deg.max() >= 4000                                            # hubs
+    for v in (int(deg.argmax()), 0, 4165, 50_000):
+        a, b = og.get_alias(v), dg.get_alias(v)
+        assert np.array_equal(a["alias"], b["alias"]) and np.array_equal(bits(a["prob"]), bits(b["prob"])), v
+    assert np.array_equal(og.sample_walks(20_000, 24, seed=5, rng_mode=1), dg.sample_walks(20_000, 24, seed=5, rng_mode=1))
+    walks = dg.sample_walks(2500, 24, seed=5, rng_mode=1)
+    NV = 4166 * 24
+    kw = dict(negative=20, min_count=2, epochs=1, seed=3, table_size=1_000_003)
+    om = oracle.train_sgns(walks, NV, 256, 24, threads=1, arith=0, **kw)
+    dm = dge.SgnsModel.fit(walks, dge.make_config(256, 24, NV, workers=1, update_policy=7, **kw), 0)
+    s0, vid = dm.vectors()
+    sch = dm.schedule()
+    assert sch["update_policy"] == 7 and 0 < sch["hot_rows"] <= om.V, sch                # a real, count-derived head
+    assert np.array_equal(vid, om.vocab_ids) and dm.stats()["pairs"] == om.pairs
+    c0 = cosine_rows(s0, om.syn0).min(); c1 = cosine_rows(dm.syn1neg() + 1e-30, om.syn1neg + 1e-30).min()
+    assert c0 > 1 - 1e-4 and c1 > 1 - 1e-4, (1 - c0, 1 - c1, sch)
+
+
+def test_cfg5_shaped_auto_schedule_resolves_to_the_mixed_policy(dge):
+    """configs[4] at 1/10 (1 M vertices, 100 M edges, 1 M walks, D = 256, K = 20): `update_policy = 0` must pick the mixed policy 7
+    THROUGH THE AUTO RULE (skewed vocabulary of >= 262 144 rows, head derived from the counts), train exactly the pairs that the
+    lossless atomics schedule (policy 2) trains, stay finite, and predict held-out walk steps as well as policy 2 does."""
+    import torch
+    from embedding_amd import synth
+    R, T, L, D, K = 41666, 24, 24, 256, 20
+    NV = R * T
+    G = synth.powerlaw_flow_graph_torch(R, T, 100_000_000, "cuda:0")
+    g = dge.DeviceGraph(0); g.add_edges_device(G["src"], G["dst"], G["w"]); g.set_sources(G["sources"]); del G
+    torch.cuda.empty_cache()
+    g.build_alias(False)
+    corpus = g.sample_walks_device(1_000_000, L, seed=5)
+    counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0"); corpus.count_tokens(NV, counts)
+    test = g.sample_walks(50_000, L, seed=99, rng_mode=1)
+    res = {}
+    for pol in (0, 2):
+        m = dge.SgnsModel.create(dge.make_config(D, L, NV, negative=K, workers=0, update_policy=pol, epochs=1, seed=1), counts, 0)
+        m.train(corpus)
+        st, sch = m.stats(), m.schedule()
+        s0, vid = m.vectors(); s1 = m.syn1neg()
+        assert np.isfinite(s0).all() and np.isfinite(s1).all()
+        res[pol] = dict(pairs=st["pairs"], sch=sch, auc=link_auc(s0, s1, vid, test, R), rate=st["pairs"] / (st["kernel_ms"] * 1e-3), V=len(vid))
+        m.close()
+    assert res[0]["V"] >= 262144, res[0]["V"]
+    assert res[0]["sch"]["update_policy"] == 7 and 0 < res[0]["sch"]["hot_rows"] < res[0]["V"] // 8, res[0]["sch"]
+    assert res[2]["sch"]["update_policy"] == 2
+    assert res[0]["pairs"] == res[2]["pairs"] > 3.0e8
+    assert res[0]["auc"] > res[2]["auc"] - 0.01 and res[2]["auc"] > 0.6, res
+    assert res[0]["rate"] > res[2]["rate"], res                         # and the auto choice is the faster one

@@ -29,11 +29,11 @@ def _case(seed):
 
 
 @pytest.mark.parametrize("seed", list(range(40)) + [-s for s in range(1, 17)])
-def test_random_configuration_bit_exact(dge, oracle, seed, monkeypatch):
+def test_random_configuration_bit_exact(dge, oracle, seed, request):
     import torch
-    if seed < 0:                      # the same cases again through the per-row-descriptor addressing of >= 4 GiB tables
-        monkeypatch.setenv("DGE_FORCE_BIG", "1")
-        monkeypatch.setenv("DGE_BIG_SEG_SHIFT", "3")     # 8 rows per descriptor segment: rows of one pair spread over many segments
+    if seed < 0:                      # the same cases again through the per-segment-descriptor addressing of >= 4 GiB tables
+        knobs = dge.tuning(force_segments=1, segment_shift=3)     # 8 rows per descriptor segment: rows of one pair spread over many segments
+        knobs.__enter__(); request.addfinalizer(lambda: knobs.__exit__(None, None, None))
         seed = -seed
     ids, NV, cfg, mode = _case(seed)
     if mode == "hs" and cfg["negative"] == 0 and cfg["dim"] > 256:
@@ -125,7 +125,7 @@ def test_random_graph_alias_and_walks_bit_exact(dge, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", list(range(100, 124)))
-def test_random_configuration_lock_kernels_one_worker(dge, oracle, seed, monkeypatch):
+def test_random_configuration_lock_kernels_one_worker(dge, oracle, seed):
     """The same random configurations through the commit-lock kernel (policy 5), its strict form (6) and the mixed policy (7, with a
     random head size), ONE worker each: with nobody else on the tables the lock kernels run the sequential word2vec schedule — positive
     target first, a parked centre delta flushed before its row is read again — so they agree with the oracle to rounding (not bit for bit:
@@ -136,11 +136,10 @@ def test_random_configuration_lock_kernels_one_worker(dge, oracle, seed, monkeyp
                            seed=cfg["seed"], table_size=cfg["table_size"], arith=0)
     rng = np.random.default_rng(seed)
     for pol in (5, 6, 7):
-        if pol == 7:
-            monkeypatch.setenv("DGE_HOT_ROWS", str(int(rng.integers(0, max(om.V, 1) + 1))))
         c = dge.make_config(cfg["dim"], cfg["window"], NV, negative=cfg["negative"], min_count=cfg["min_count"], epochs=cfg["epochs"],
                             workers=1, seed=cfg["seed"], table_size=cfg["table_size"], update_policy=pol)
-        dm = dge.SgnsModel.fit(ids, c, 0)
+        with dge.tuning(**({"hot_rows": int(rng.integers(0, max(om.V, 1) + 1))} if pol == 7 else {})):
+            dm = dge.SgnsModel.fit(ids, c, 0)
         syn0, vid = dm.vectors()
         assert np.array_equal(vid, om.vocab_ids) and dm.stats()["pairs"] == om.pairs, (seed, pol, cfg)
         if om.V:

@@ -230,20 +230,20 @@ def test_mixed_policy_head_rows_by_atomics(dge, oracle, monkeypatch):
     for dim in (64, 128, 20, 256):
         om = oracle.train_sgns(walks, NV, dim, 6, table_size=20011, arith=0)
         for hot in (0, 7, om.V // 2, om.V):
-            monkeypatch.setenv("DGE_HOT_ROWS", str(hot))
             for workers, tol in ((1, 1 - 1e-4), (16, 0.99)):
                 c = dge.make_config(dim, 6, NV, workers=workers, table_size=20011, update_policy=7)
-                dm = dge.SgnsModel.fit(walks, c, 0)
+                with dge.tuning(hot_rows=hot):
+                    dm = dge.SgnsModel.fit(walks, c, 0)
+                assert dm.schedule()["hot_rows"] == hot
                 syn0, vid = dm.vectors()
                 assert dm.stats()["pairs"] == om.pairs and np.array_equal(vid, om.vocab_ids)
                 assert cosine_rows(syn0, om.syn0).min() > tol, (dim, hot, workers)
                 assert cosine_rows(dm.syn1neg(), om.syn1neg).min() > tol, (dim, hot, workers)
-    monkeypatch.delenv("DGE_HOT_ROWS")
     # a 3-row vocabulary where every row is "hot" or none is: terminates either way
     tiny = np.array([[0, 1, 2, 1, 0]] * 64, np.int32)
-    for hot in ("0", "3"):
-        monkeypatch.setenv("DGE_HOT_ROWS", hot)
-        dm = dge.SgnsModel.fit(tiny, dge.make_config(8, 5, 3, min_count=1, workers=16, table_size=101, update_policy=7), 0)
+    for hot in (0, 3):
+        with dge.tuning(hot_rows=hot):
+            dm = dge.SgnsModel.fit(tiny, dge.make_config(8, 5, 3, min_count=1, workers=16, table_size=101, update_policy=7), 0)
         assert np.isfinite(dm.vectors()[0]).all() and dm.stats()["pairs"] > 0
     with pytest.raises(dge.DgeError):
         dge.SgnsModel.fit(tiny, dge.make_config(8, 5, 3, update_policy=4), 0)
@@ -268,16 +268,14 @@ def test_tables_beyond_4_gib(dge, oracle, monkeypatch):
     stays bit-exact in order and within rounding under the locked policy; (b) a real 4.3 GB table: rows at the far end
     of the table are the ones that move, everything else keeps its initial value."""
     walks, NV = _walks(oracle, dge, n=300)
-    monkeypatch.setenv("DGE_FORCE_BIG", "1")
-    monkeypatch.setenv("DGE_BIG_SEG_SHIFT", "4")         # 16 rows per descriptor segment instead of 4 GiB worth
-    for dim in (64, 128):
-        om, dm = _fit_both(oracle, dge, walks, NV, arith=1, dim=dim)
-        assert np.array_equal(bits(dm.vectors()[0]), bits(om.syn0)) and np.array_equal(bits(dm.syn1neg()), bits(om.syn1neg))
-        o0 = oracle.train_sgns(walks, NV, dim, 6, table_size=20011, arith=0)
-        for pol in (5, 6, 2):
-            c = dge.make_config(dim, 6, NV, workers=1, table_size=20011, update_policy=pol)
-            assert cosine_rows(dge.SgnsModel.fit(walks, c, 0).vectors()[0], o0.syn0).min() > 1 - 1e-4
-    monkeypatch.delenv("DGE_FORCE_BIG")
+    with dge.tuning(force_segments=1, segment_shift=4):       # 16 rows per descriptor segment instead of 4 GiB worth
+        for dim in (64, 128):
+            om, dm = _fit_both(oracle, dge, walks, NV, arith=1, dim=dim)
+            assert np.array_equal(bits(dm.vectors()[0]), bits(om.syn0)) and np.array_equal(bits(dm.syn1neg()), bits(om.syn1neg))
+            o0 = oracle.train_sgns(walks, NV, dim, 6, table_size=20011, arith=0)
+            for pol in (5, 6, 2):
+                c = dge.make_config(dim, 6, NV, workers=1, table_size=20011, update_policy=pol)
+                assert cosine_rows(dge.SgnsModel.fit(walks, c, 0).vectors()[0], o0.syn0).min() > 1 - 1e-4
     import torch
     V, D = 2_200_000, 512                                  # 2.2 M rows x 2 KB = 4.5 GB per table
     counts = torch.zeros(V, dtype=torch.int64, device="cuda:0")
@@ -530,10 +528,10 @@ def test_hierarchical_softmax_lds_combining_conserves_updates(dge, oracle, monke
     walks, NV = _walks(oracle, dge, R=400, T=6, n=30000)
     kw = dict(dim=32, window=6, negative=2, min_count=2, epochs=1, threads=1, alpha=1e-6, min_alpha=1e-6, seed=1, table_size=20011)
     om = oracle.train_sgns(walks, NV, arith=1, use_hs=True, **kw)
-    for drain, tol in (("1", 0.02), ("64", 0.02), ("1000000000", 0.10)):
-        monkeypatch.setenv("DGE_HS_DRAIN", drain)
+    for drain, tol in ((1, 0.02), (64, 0.02), (1000000000, 0.10)):
         c = dge.make_config(32, 6, NV, negative=2, alpha=1e-6, min_alpha=1e-6, table_size=20011, use_hs=True)
-        dm = dge.SgnsModel.fit(walks, c, 0)
+        with dge.tuning(hs_drain=drain):
+            dm = dge.SgnsModel.fit(walks, c, 0)
         assert dm.stats()["pairs"] == om.pairs
         a, b = dm.syn1().astype(np.float64), om.syn1.astype(np.float64)
         na, nb = np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1)
