@@ -4,8 +4,9 @@
 One process per GPU.  A "step" is one pass of the hot path over one batch of walks: the walk kernel re-samples the
 batch from the alias tables in HBM, the batch is remapped to vocabulary rows, and the SGNS kernel trains every
 (centre, context) pair of it with 1 positive + K negative updates.  Everything the step reads is resident in HBM
-before the timed region starts.  With N > 1 ranks every rank trains its own walk shard (no data-path collective)
-and the embedding deltas are all-reduced over RCCL after each step.
+before the timed region starts.  With N > 1 ranks the block schedule of embedding_amd/distributed.py runs: rows split by
+row % N, N episodes per global batch of N x the single-GPU batch, the syn1neg partitions passed round a ring of point-to-point RCCL
+transfers (`--multi-gpu allreduce` = the walk-shard + delta-averaging scheme, kept for comparison).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -20,13 +21,17 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # BASELINE.json configs[2]/[3]: R*T = 1 000 008 layered vertices, ~100 M edges, 24 hourly slices, D=128, K=5
-    "cfg3": dict(R=41667, T=24, mean_degree=100, dim=128, negative=5, L=24, walks_per_vertex=10,
+    "cfg3": dict(R=41667, T=24, mean_degree=100, dim=128, negative=5, L=24, walks_per_vertex=10, expect_policy=5,
                  name="synthetic 1M-node / 100M-edge flow graph, 24 timeslices, dim=128, K=5, L=W=24"),
+    # the same shape with Zipf-popular destination regions (real trip data is skewed; the headline stays cfg3 as specified): the
+    # vocabulary gets a head, auto moves it out of the lock protocol (policy 7) — printed next to cfg3 in profiles/ and README.md
+    "cfg3_zipf": dict(R=41667, T=24, mean_degree=100, dim=128, negative=5, L=24, walks_per_vertex=10, dst="zipf", expect_policy=7,
+                      name="synthetic 1M-node / 100M-edge flow graph with Zipf-popular destinations, 24 timeslices, dim=128, K=5, L=W=24"),
     # BASELINE.json configs[1]: 100k-node / 5M-edge static graph, D=64, K=5
-    "cfg2": dict(R=100000, T=1, mean_degree=50, dim=64, negative=5, L=8, walks_per_vertex=10,
+    "cfg2": dict(R=100000, T=1, mean_degree=50, dim=64, negative=5, L=8, walks_per_vertex=10, expect_policy=2,
                  name="synthetic 100k-node / 5M-edge static flow graph, dim=64, K=5, L=W=8"),
     # BASELINE.json configs[4]: power-law 10M-node / 1B-edge dynamic graph, D=256, K=20 (8 GPUs in the config; runs on 1)
-    "cfg5": dict(R=416667, T=24, n_edges=1_000_000_000, dim=256, negative=20, L=24, walks_per_vertex=1, powerlaw=True,
+    "cfg5": dict(R=416667, T=24, n_edges=1_000_000_000, dim=256, negative=20, L=24, walks_per_vertex=1, powerlaw=True, expect_policy=7,
                  name="power-law 10M-node / 1B-edge dynamic graph, 24 timeslices, dim=256, K=20, L=W=24"),
     # BASELINE.json configs[0] at the reference's own size: tract level, 801 regions x 8 slices, D=20, 15.6 M walks
     # (J/DeepWalk.java:62-66,89-104); the flow graph is synthetic (the taxi data is not shipped)
@@ -49,6 +54,8 @@ def main():
     ap.add_argument("--multi-gpu", choices=["blocks", "allreduce"], default="blocks",
                     help="N>1: 'blocks' = row-partitioned block schedule, exact (default); 'allreduce' = the earlier walk-shard + delta "
                          "averaging scheme, kept for comparison (it under-trains by the factor N: DESIGN.md §7)")
+    ap.add_argument("--ring-transport", choices=["auto", "p2p", "allgather"], default="auto",
+                    help="N>1, block schedule: how a trained syn1neg partition reaches the next rank (auto: point to point, all-gather if refused)")
     ap.add_argument("--sim-ranks", type=int, default=0,
                     help="single process: run rank 0's share of an N-rank block-schedule step (its N episodes over the N-fold batch, "
                          "partition pack/unpack included, no network) to estimate per-rank throughput at N ranks")
@@ -123,7 +130,7 @@ def main():
     if wl.get("powerlaw"):
         G = synth.powerlaw_flow_graph_torch(R, T, wl["n_edges"], dev)
     else:
-        G = synth.flow_graph_torch(R, T, wl["mean_degree"], dev)
+        G = synth.flow_graph_torch(R, T, wl["mean_degree"], dev, dst=wl.get("dst", "uniform"))
     stage("edge list generated: %d edges" % G["n_edges"])
     g = E.DeviceGraph(local_rank)
     g.add_edges_device(G["src"], G["dst"], G["w"])
@@ -165,7 +172,7 @@ def main():
         corpus = g.sample_walks_device(BG, L, seed=WALK_SEED, rng_mode=1, first_index=0)
         pf = model.partition_floats(NB)
         part_buf = torch.empty(pf, dtype=torch.float32, device=dev)
-        gather_buf = torch.empty(pf * (NB if N > 1 else 1), dtype=torch.float32, device=dev)
+        recv_buf = torch.empty(pf, dtype=torch.float32, device=dev)
         stage("block schedule: %d ranks, global batch %d walks, partition buffers %.0f MB" % (NB, BG, pf * 4 / 1e6))
     exchange = (N > 1 and not blocks) or args.force_exchange
     if exchange and not dist.is_initialized():
@@ -174,6 +181,7 @@ def main():
     if exchange:
         delta = torch.empty(model.sync_size(), dtype=torch.float32, device=dev)
         model.snapshot()
+    copy_rate = box_copy_rate(dev) if rank == 0 else None
     setup_s = time.time() - t0
 
     def step_blocks(i):
@@ -189,7 +197,7 @@ def main():
                 model.train(corpus, 0, BG, walk_index_base=first, epoch=0, words_before=0, words_scale=1.0, total_walks=epoch_walks)
 
         if N > 1:
-            block_schedule_step(model, train_fn, N, rank, part_buf, gather_buf)
+            block_schedule_step(model, train_fn, N, rank, part_buf, recv_buf, transport=None if args.ring_transport == "auto" else args.ring_transport)
         else:                                                  # --sim-ranks: rank 0's episodes, exchange replaced by a local pack/unpack
             for e in range(NB):
                 model.set_partition(NB, 0, e % NB)
@@ -264,7 +272,7 @@ def main():
             "config": {"workload": wl["name"], "vertices": NV, "edges": int(n_edges), "timeslices": T, "dim": D,
                        "negatives": K, "walk_len": L, "window": L, "walks_per_step_per_gpu": B,
                        "pairs_per_step_per_gpu": st["pairs"] / args.steps, "vocabulary": int((counts >= 2).sum().item()),
-                       "sgns_workers": args.workers, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, all-gather of syn1neg partitions" % N if blocks and N > 1
+                       "sgns_workers": args.workers, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, syn1neg partitions passed round a ring" % N if blocks and N > 1
                                        else "SIMULATED rank 0 of a %d-rank block schedule on one GPU (value = this rank's share only)" % NB if blocks
                                        else "walk-shard x%d, RCCL all-reduce of deltas per step (comparison mode)" % N if N > 1 else "1 GPU"),
                        "setup_s": round(setup_s, 1)},
@@ -275,8 +283,10 @@ def main():
                          "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
                          "walk_kernel_ms_per_launch": st["walk_kernel_ms"] / launches,
                          "walk_steps_per_s": (B * L) / (st["walk_kernel_ms"] / launches * 1e-3) if st["walk_kernel_ms"] > 0 else None,
-                         "walk_bytes_per_step": 36},
+                         "walk_bytes_per_step": 36, "box_copy_GBps": copy_rate},
         }
+        if "expect_policy" in wl and not (args.policy or args.workers or args.hs or NB > 1) and sched["update_policy"] != wl["expect_policy"]:
+            print("warning: workload %s resolved to policy %d, the committed traffic profile is for policy %d" % (args.workload, sched["update_policy"], wl["expect_policy"]), file=sys.stderr)
         if N == 1 and not args.no_cpu_baseline:
             sample = g.sample_walks(min(shard, 400_000), L, seed=WALK_SEED, rng_mode=1, first_index=shard0)   # = first rows of the corpus
             out["cpu_baseline"] = cpu_baseline(sample, NV, D, L, K, args.cpu_seconds)
@@ -342,20 +352,46 @@ def measured_traffic(workload, policy, pairs_per_launch):       # policy: "polic
 
 def cpu_baseline(walks, NV, D, L, K, seconds):
     """The CPU restatement (oracle, 'port') timed with Hogwild threads on this box's host cores, on a bounded sample
-    of the same walks.  A reported baseline, not the target; not the Java reference (no JDK here)."""
+    of the same walks: once with the reference's own `.workers(8)` (J/DeepWalk.java:75) and once with every core of one GPU's
+    share of the host.  A reported baseline, not the target; not the Java reference (no JDK here)."""
     from oracle import oracle as O
     O.build()
     # the GPU box exposes every host core but one GPU's share is 16 of them (task notes); more threads than that only
     # time-slice against the cgroup quota (measured: 256 threads run 1.3e6 edges/s, slower than 16)
     cores = min(len(os.sched_getaffinity(0)), 16)
-    probe = walks[:20_000]
-    m = O.train_sgns(probe, NV, D, L, negative=K, threads=cores, table_size=10_000_000)
-    rate = m.pairs / max(m.seconds, 1e-9)
-    n = int(min(len(walks), max(20_000, 0.5 * seconds * rate / (m.pairs / len(probe)))))   # the probe over-estimates the rate ~2x
-    m = O.train_sgns(walks[:n], NV, D, L, negative=K, threads=cores, table_size=10_000_000)
-    return {"value": m.pairs / max(m.seconds, 1e-9), "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": "%d walks (%d pairs) of the same corpus, oracle/dge_oracle.c Hogwild with %d OpenMP threads, %.1f s"
-                      % (n, m.pairs, cores, m.seconds)}
+
+    def run(threads, secs):
+        probe = walks[:20_000]
+        m = O.train_sgns(probe, NV, D, L, negative=K, threads=threads, table_size=10_000_000)
+        rate = m.pairs / max(m.seconds, 1e-9)
+        n = int(min(len(walks), max(20_000, 0.5 * secs * rate / (m.pairs / len(probe)))))   # the probe over-estimates the rate ~2x
+        m = O.train_sgns(walks[:n], NV, D, L, negative=K, threads=threads, table_size=10_000_000)
+        return {"value": m.pairs / max(m.seconds, 1e-9), "unit": "edges/s", "cores": threads, "kind": "port",
+                "sample": "%d walks (%d pairs) of the same corpus, oracle/dge_oracle.c Hogwild with %d OpenMP threads, %.1f s"
+                          % (n, m.pairs, threads, m.seconds)}
+
+    out = run(cores, 0.6 * seconds)
+    if cores != 8:
+        w8 = run(min(8, cores), 0.4 * seconds)
+        out["reference_workers_8"] = {k: w8[k] for k in ("value", "cores", "sample")}     # .workers(8), J/DeepWalk.java:75
+    return out
+
+
+def box_copy_rate(dev):
+    """How fast THIS box moves bytes: a 1 GiB device-to-device copy, read + written bytes per second (GB/s).  Boxes of the pool differ
+    by +-7 %; the figure lets a reader tell a slow kernel from a slow box.  Outside the timed region."""
+    import torch
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev); b = torch.empty_like(a)
+    a.fill_(1.0); b.copy_(a); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 0.0
+    for _ in range(5):
+        e0.record(); b.copy_(a); e1.record(); torch.cuda.synchronize()
+        best = max(best, 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return best
 
 
 if __name__ == "__main__":

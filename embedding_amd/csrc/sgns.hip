@@ -989,6 +989,10 @@ struct RcclApi {
     int (*CommInitRank)(void**, int, dge_unique_id, int) = nullptr;     // ncclUniqueId is a 128-byte struct passed by value
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -1003,9 +1007,14 @@ int rccl_load() {
     g_rccl.CommInitRank = (int (*)(void**, int, dge_unique_id, int))dlsym(h, "ncclCommInitRank");
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
     g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
+    g_rccl.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
+    g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy) DGE_FAIL(DGE_ERR_DEVICE, "librccl lacks an expected symbol");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy || !g_rccl.Send || !g_rccl.Recv ||
+        !g_rccl.GroupStart || !g_rccl.GroupEnd) DGE_FAIL(DGE_ERR_DEVICE, "librccl lacks an expected symbol");
     g_rccl.lib = h;
     return DGE_OK;
 }
@@ -1060,24 +1069,54 @@ extern "C" int dge_model_allreduce_deltas(dge_model* m, dge_comm* c) {
     return dge_model_import_delta(m, c->d_buf, 1.0f / (float)c->nranks);
 }
 
-// block schedule, the exchange after episode `episode` (or, with table 0 and episode 0, the final gather of syn0): rank g
-// publishes partition (g + episode) % nranks of `table` and takes the partitions the other ranks publish
-extern "C" int dge_model_exchange_partitions(dge_model* m, dge_comm* c, int table, int32_t episode) {
-    if (!m || !c || (table != 0 && table != 1) || episode < 0) DGE_FAIL(DGE_ERR_ARG, "dge_model_exchange_partitions: bad argument");
-    if (c->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_exchange_partitions: communicator and model live on different devices");
+// block schedule with RCCL called from the library.  dge_model_ring_pass: after episode `episode` rank g hands the syn1neg partition
+// it just trained, (g + episode) % N, to rank g-1 and takes partition (g + 1 + episode) % N — the one it trains next — from rank
+// g+1 (ncclSend/ncclRecv in one group).  dge_model_gather_table: every rank publishes partition `rank` of `table` and takes the
+// others (all-gather): the end of training, or a checkpoint.
+static int comm_buffers(dge_model* m, dge_comm* c, int64_t need) {
+    if (c->buf_floats >= need) return DGE_OK;
+    dge_dev_free(c->d_buf); c->d_buf = nullptr; c->buf_floats = 0;
+    int rc = dge_dev_alloc(&c->d_buf, (size_t)need + 64);
+    if (rc) return rc;
+    c->buf_floats = need;
+    return DGE_OK;
+}
+
+extern "C" int dge_model_ring_pass(dge_model* m, dge_comm* c, int32_t episode) {
+    if (!m || !c || episode < 0) DGE_FAIL(DGE_ERR_ARG, "dge_model_ring_pass: bad argument");
+    if (c->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_ring_pass: communicator and model live on different devices");
+    if (c->nranks == 1) return DGE_OK;
     DGE_HIP(hipSetDevice(m->device));
     int64_t pf = 0;
     int rc = dge_model_partition_floats(m, c->nranks, &pf);
     if (rc) return rc;
-    const int64_t need = pf * ((int64_t)c->nranks + 1);
-    if (c->buf_floats < need) { dge_dev_free(c->d_buf); c->d_buf = nullptr; if ((rc = dge_dev_alloc(&c->d_buf, (size_t)need + 64))) return rc; c->buf_floats = need; }
+    if ((rc = comm_buffers(m, c, 2 * pf))) return rc;
+    float* mine = c->d_buf; float* next = c->d_buf + pf;
+    if ((rc = dge_model_export_partition(m, 1, c->nranks, (c->rank + episode) % c->nranks, mine))) return rc;
+    const int dst = (c->rank + c->nranks - 1) % c->nranks, src = (c->rank + 1) % c->nranks;
+    int n = g_rccl.GroupStart();
+    if (!n) n = g_rccl.Send(mine, (size_t)pf, /*ncclFloat32*/ 7, dst, c->nccl, m->stream);
+    if (!n) n = g_rccl.Recv(next, (size_t)pf, /*ncclFloat32*/ 7, src, c->nccl, m->stream);
+    const int n2 = g_rccl.GroupEnd();
+    if (n || n2) return rccl_fail(n ? n : n2, "ncclSend/ncclRecv");
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    return dge_model_import_partition(m, 1, c->nranks, (c->rank + 1 + episode) % c->nranks, next);
+}
+
+extern "C" int dge_model_gather_table(dge_model* m, dge_comm* c, int table) {
+    if (!m || !c || (table != 0 && table != 1)) DGE_FAIL(DGE_ERR_ARG, "dge_model_gather_table: bad argument");
+    if (c->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_gather_table: communicator and model live on different devices");
+    DGE_HIP(hipSetDevice(m->device));
+    int64_t pf = 0;
+    int rc = dge_model_partition_floats(m, c->nranks, &pf);
+    if (rc) return rc;
+    if ((rc = comm_buffers(m, c, pf * ((int64_t)c->nranks + 1)))) return rc;
     float* mine = c->d_buf; float* all = c->d_buf + pf;
-    if ((rc = dge_model_export_partition(m, table, c->nranks, (c->rank + episode) % c->nranks, mine))) return rc;
+    if ((rc = dge_model_export_partition(m, table, c->nranks, c->rank, mine))) return rc;
     int n = g_rccl.AllGather(mine, all, (size_t)pf, /*ncclFloat32*/ 7, c->nccl, m->stream);
     if (n) return rccl_fail(n, "ncclAllGather");
     DGE_HIP(hipStreamSynchronize(m->stream));
     for (int r = 0; r < c->nranks; r++)
-        if (r != c->rank && (rc = dge_model_import_partition(m, table, c->nranks, (r + episode) % c->nranks, all + (int64_t)r * pf))) return rc;
+        if (r != c->rank && (rc = dge_model_import_partition(m, table, c->nranks, r, all + (int64_t)r * pf))) return rc;
     return DGE_OK;
 }
-

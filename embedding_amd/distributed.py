@@ -8,8 +8,8 @@ TRAINING uses the block schedule (`block_schedule_step`): vocabulary rows are sp
 trains, over the SAME global batch of walks, the pairs whose context row is in partition g and whose centre row is in
 partition (g+e) % N, with negatives moved into that partition.  The N blocks of an episode are row-disjoint in both
 tables and after N episodes every pair was trained exactly once: the result is the single-GPU result with the pairs in
-another order — nothing is averaged.  Between episodes the ranks all-gather the syn1neg partitions they just trained
-(V/N rows each); syn0 partitions stay home until `gather_table`.
+another order — nothing is averaged.  Between episodes every rank passes the syn1neg partition it just trained (V/N rows) to
+rank-1, which trains it next (a ring of point-to-point transfers); syn0 partitions stay home until `gather_table`.
 
 The earlier scheme — every rank trains its own walk shard from a snapshot, deltas are all-reduced and applied with 1/N
 (`exchange_deltas`) — is kept for comparison only: measured (scripts/quality_exchange.py, profiles/r01_quality_exchange.txt)
@@ -58,49 +58,84 @@ def exchange_deltas(model, buf, world, dist_mod=None):
     model.import_delta(buf, 1.0 / world)
 
 
-def block_schedule_step(model, train_fn, world, rank, part_buf=None, gather_buf=None, dist_mod=None):
+_RING_TRANSPORT = {"mode": "p2p"}      # "p2p", or "allgather" once point-to-point transfers turned out to be unavailable
+
+
+def _ring_pass(send_buf, recv_buf, world, rank, d, transport=None):
+    """Every rank sends `send_buf` to rank - 1 and receives rank + 1's into `recv_buf` (one point-to-point transfer per rank: over
+    xGMI a partition of cfg3, 64 MB, is ~0.5 ms on one link).  Backends that cannot move device tensors point to point (gloo in the
+    CPU/one-GPU tests) are staged through host memory.  transport="allgather" (also chosen for the rest of the run when the
+    backend refuses point-to-point operations) moves the same bytes with an all-gather and keeps rank + 1's share."""
+    import torch
+    dst, src = (rank - 1) % world, (rank + 1) % world
+    mode = transport or _RING_TRANSPORT["mode"]
+    if mode == "p2p":
+        staged = getattr(send_buf, "is_cuda", False) and d.get_backend() != "nccl"
+        s, r = (send_buf.cpu(), torch.empty(recv_buf.shape, dtype=recv_buf.dtype)) if staged else (send_buf, recv_buf)
+        try:
+            for w in d.batch_isend_irecv([d.P2POp(d.isend, s, dst), d.P2POp(d.irecv, r, src)]):
+                w.wait()
+            if staged:
+                recv_buf.copy_(r)
+        except (RuntimeError, NotImplementedError) as e:
+            if transport is not None:
+                raise
+            import sys
+            print("[distributed] point-to-point transfer unavailable (%s): all-gather from here on" % (str(e).splitlines()[0],), file=sys.stderr, flush=True)
+            _RING_TRANSPORT["mode"] = mode = "allgather"
+    if mode == "allgather":
+        allb = torch.empty(send_buf.numel() * world, dtype=send_buf.dtype, device=send_buf.device)
+        d.all_gather_into_tensor(allb, send_buf)
+        recv_buf.copy_(allb[src * send_buf.numel():(src + 1) * send_buf.numel()])
+    _wait_device(recv_buf)             # the transfer runs on torch's streams; libdge reads recv_buf on its own stream
+
+
+def block_schedule_step(model, train_fn, world, rank, part_buf=None, recv_buf=None, dist_mod=None, transport=None):
     """One global batch under the block schedule.  `train_fn()` trains the batch on `model` (it is called once per
     episode, with the model's partition filter set); `model` needs set_partition / export_partition / import_partition /
-    partition_floats (embedding_amd.SgnsModel).  `part_buf` [partition_floats] and `gather_buf` [world * partition_floats]
-    are float32 tensors on the model's device (allocated here when not given).  Returns the buffers for reuse."""
+    partition_floats (embedding_amd.SgnsModel).  `part_buf` and `recv_buf` are float32 tensors of partition_floats elements on the
+    model's device (allocated here when not given).  Returns the buffers for reuse.
+
+    The syn1neg partitions travel a RING: partition p is trained by rank p in episode 0, by rank p-1 in episode 1, ... so after
+    every episode a rank hands the partition it just trained to rank-1 and takes the next one from rank+1 — one partition per
+    rank and episode, point to point, instead of an all-gather of all of them; a rank only ever reads the syn1neg partition it
+    is about to train and its own syn0 partition.  After the N-th episode partition p is back on rank p: the invariant the
+    next batch starts from (and `gather_table` collects from)."""
     if world <= 1:
         model.set_partition(1)
         train_fn()
-        return part_buf, gather_buf
+        return part_buf, recv_buf
     import torch
     import torch.distributed as dist
     d = dist_mod or dist
     pf = model.partition_floats(world)
-    if part_buf is None or gather_buf is None:
+    if part_buf is None or recv_buf is None or recv_buf.numel() != pf:
         dev = getattr(model, "torch_device", None) or "cpu"
         part_buf = torch.empty(pf, dtype=torch.float32, device=dev)
-        gather_buf = torch.empty(pf * world, dtype=torch.float32, device=dev)
+        recv_buf = torch.empty(pf, dtype=torch.float32, device=dev)
     for e in range(world):
         tgt = (rank + e) % world
         model.set_partition(world, rank, tgt)
         train_fn()
-        # every rank publishes the syn1neg partition it just trained; rank r trained partition (r + e) % world
-        model.export_partition(1, world, tgt, part_buf)
-        d.all_gather_into_tensor(gather_buf, part_buf)
-        _wait_device(gather_buf)
-        for r in range(world):
-            if r != rank:
-                model.import_partition(1, world, (r + e) % world, gather_buf[r * pf:(r + 1) * pf])
+        model.export_partition(1, world, tgt, part_buf)            # what this rank just trained ...
+        _ring_pass(part_buf, recv_buf, world, rank, d, transport)  # ... goes to rank-1; rank+1's arrives:
+        model.import_partition(1, world, (rank + 1 + e) % world, recv_buf)     # the partition of the NEXT episode
     model.set_partition(1)
-    return part_buf, gather_buf
+    return part_buf, recv_buf
 
 
 def gather_table(model, table, world, rank, part_buf=None, gather_buf=None, dist_mod=None):
-    """After training: every rank owns partition `rank` of `table` (0 = syn0); collect the others."""
+    """After training: every rank holds the current partition `rank` of `table` (0 = syn0, 1 = syn1neg); collect the others."""
     if world <= 1:
         return
     import torch
     import torch.distributed as dist
     d = dist_mod or dist
     pf = model.partition_floats(world)
-    if part_buf is None or gather_buf is None:
-        dev = getattr(model, "torch_device", None) or "cpu"
+    dev = getattr(model, "torch_device", None) or "cpu"
+    if part_buf is None or part_buf.numel() != pf:
         part_buf = torch.empty(pf, dtype=torch.float32, device=dev)
+    if gather_buf is None or gather_buf.numel() != pf * world:
         gather_buf = torch.empty(pf * world, dtype=torch.float32, device=dev)
     model.export_partition(table, world, rank, part_buf)
     d.all_gather_into_tensor(gather_buf, part_buf)
@@ -141,7 +176,8 @@ def fit_distributed(graph, n_walks, walk_len, cfg, world, rank, walk_seed, batch
             bufs = block_schedule_step(model, lambda: model.train(corpus, 0, n, walk_index_base=b0, epoch=ep, words_before=words_before,
                                                                   total_walks=n_walks), world, rank, *bufs, dist_mod=dist_mod)
             words_before += model.stats()["words"]
-    gather_table(model, 0, world, rank, *bufs, dist_mod=dist_mod)
+    gather_table(model, 0, world, rank, dist_mod=dist_mod)
+    gather_table(model, 1, world, rank, dist_mod=dist_mod)
     corpus.close()
     return model
 

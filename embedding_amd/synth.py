@@ -31,8 +31,10 @@ def flow_graph_numpy(R, T, mean_degree, seed=SEED, sigma=1.0, weight_mean=20.0, 
                 n_vertices=V, R=R, T=T)
 
 
-def flow_graph_torch(R, T, mean_degree, device, seed=SEED, sigma=1.0, weight_mean=20.0):
-    """Device generator (bench configs: 5 M .. 100 M edges never touch the host).  Returns torch tensors."""
+def flow_graph_torch(R, T, mean_degree, device, seed=SEED, sigma=1.0, weight_mean=20.0, dst="uniform"):
+    """Device generator (bench configs: 5 M .. 100 M edges never touch the host).  Returns torch tensors.
+    dst = "uniform": destination regions drawn uniformly (the configurations as SURVEY.md §8d specifies them: a flat vocabulary);
+    dst = "zipf": region of rank r drawn with P ~ 1/(r+1) — popular regions, what real trip data looks like: a skewed vocabulary."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -42,7 +44,14 @@ def flow_graph_torch(R, T, mean_degree, device, seed=SEED, sigma=1.0, weight_mea
     deg = torch.exp(mu + sigma * z).to(torch.int64).clamp_(1, R)
     E = int(deg.sum().item())
     src = torch.repeat_interleave(torch.arange(V, device=device, dtype=torch.int32), deg)
-    dst_region = torch.randint(0, R, (E,), generator=g, device=device, dtype=torch.int32)
+    if dst == "zipf":
+        ur = torch.rand(E, generator=g, device=device, dtype=torch.float32)
+        dst_region = (torch.exp(ur * float(np.log(R + 1.0))) - 1.0).to(torch.int64).clamp_(0, R - 1).to(torch.int32)
+        del ur
+    elif dst == "uniform":
+        dst_region = torch.randint(0, R, (E,), generator=g, device=device, dtype=torch.int32)
+    else:
+        raise ValueError("dst must be 'uniform' or 'zipf'")
     if T > 1:
         layer = torch.div(src, R, rounding_mode="floor")
         dst = ((layer + 1) % T) * R + dst_region

@@ -230,8 +230,8 @@ void dge_model_free(dge_model* m);
  * to the row of tgt_part nearest below it (rows are ordered by count: the frequency rank is kept).  Rank g of
  * N runs episodes e = 0..N-1 with (ctx_part, tgt_part) = (g, (g+e) % N) over the same global batch of
  * walks: the blocks of one episode are row-disjoint, after N episodes every pair was trained once.
- * Between episodes the ranks exchange the syn1neg partitions they trained (export -> all-gather ->
- * import); syn0 partitions are gathered once at the end.  n_parts <= 1 switches the filter off.
+ * After an episode a rank hands the syn1neg partition it trained to rank g-1, which trains it next (export -> point-to-point
+ * transfer -> import: a ring); syn0 partitions never leave their rank until the final gather.  n_parts <= 1 switches the filter off.
  * Policies under a partition: 0 (auto), 2, 3, 5, and 7 = row locks on syn1neg only, the pair's syn0 row by atomics. */
 int  dge_model_set_partition(dge_model* m, int32_t n_parts, int32_t ctx_part, int32_t tgt_part);
 /* floats of one packed partition buffer: ceil(V / n_parts) rows x row stride (same for every partition) */
@@ -260,9 +260,12 @@ int  dge_comm_unique_id(dge_unique_id* out);
 int  dge_comm_create(dge_comm** out, const dge_unique_id* id, int rank, int nranks, int device);
 void dge_comm_free(dge_comm* c);
 int  dge_model_allreduce_deltas(dge_model* m, dge_comm* c);
-/* block schedule with RCCL called from the library: after episode `episode` rank g publishes partition
- * (g + episode) % nranks of `table` (1 = syn1neg) and imports the other ranks'; table 0, episode 0 = final gather of syn0 */
-int  dge_model_exchange_partitions(dge_model* m, dge_comm* c, int table, int32_t episode);                /* needs dge_model_snapshot before the shard */
+/* block schedule with RCCL called from the library (N = nranks).  dge_model_ring_pass: after episode `episode` rank g hands the
+ * syn1neg partition it just trained, (g + episode) % N, to rank g-1 and takes (g + 1 + episode) % N — the one it trains next — from
+ * rank g+1 (ncclSend / ncclRecv).  dge_model_gather_table: every rank publishes partition `rank` of `table` (0 = syn0, 1 = syn1neg)
+ * and takes the others (all-gather): the end of training.  NOT YET RUN ON MORE THAN ONE GPU (README.md: verification status). */
+int  dge_model_ring_pass(dge_model* m, dge_comm* c, int32_t episode);
+int  dge_model_gather_table(dge_model* m, dge_comm* c, int table);
 
 /* ------------------------------------------------------------------------------------------------
  * Quality metric ("next" row of the scope table): pairwiseEstimator of P/embeddingEvaluation_tract.py:169-196 — for every

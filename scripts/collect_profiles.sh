@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the evidence behind one bench line on the GPU box:  scripts/collect_profiles.sh <tag> <kernel-substring> [bench.py args...]
+#   gpurun_out/prof_<tag>/bench.json            the bench line (HIP-event timing, cpu baseline skipped)
+#   gpurun_out/prof_<tag>/kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command
+#   gpurun_out/prof_<tag>/pmc.csv               FETCH_SIZE / WRITE_SIZE+TCC_EA0_ATOMIC / TCC_EA0_RDREQ+WRREQ, one pass each, digested per dispatch
+# Counters are collected in their own runs with --kernel-trace only (MI355X_MICROARCH.md, HBM section).
+set -e
+tag=$1; needle=$2; shift 2
+root=$(pwd); out=$root/gpurun_out/prof_$tag; mkdir -p $out
+export TMPDIR=/tmp
+python3 bench.py --no-cpu-baseline --steps 4 --warmup 1 "$@" > $out/bench.json 2> $out/bench.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 $root/bench.py --no-cpu-baseline --steps 4 --warmup 1 "$@" > $out/stats.log 2>&1
+cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+i=0
+for ctr in "FETCH_SIZE" "WRITE_SIZE TCC_EA0_ATOMIC_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+  name=$(echo $ctr | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc -o $name -- python3 $root/bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > $out/pmc_$name.log 2>&1
+done
+cd $root
+mkdir -p $out/flat; find $out/pmc -name "*.csv" -exec cp {} $out/flat/ \;
+python3 scripts/pmc_digest.py $out/flat "$needle" > $out/pmc.csv
+rm -rf $out/stats $out/pmc $out/flat
+head -3 $out/kernel_stats.csv; cat $out/bench.json | cut -c1-400

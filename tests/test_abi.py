@@ -71,12 +71,16 @@ def test_bench_workloads_and_traffic_table():
     import importlib.util, json
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
-    assert {"cfg1", "cfg2", "cfg3", "cfg5"} <= set(bench.WORKLOADS)
+    assert {"cfg1", "cfg2", "cfg3", "cfg3_zipf", "cfg5"} <= set(bench.WORKLOADS)
     w = bench.WORKLOADS["cfg3"]
     assert w["R"] * w["T"] == 1000008 and w["dim"] == 128 and w["negative"] == 5 and w["L"] == 24      # the configuration the metric is quoted on
     assert bench.measured_traffic("cfg3", "policy5", 1000.0) == 7319.0 * 1000.0
     assert bench.measured_traffic("cfg5", "policy7", 1.0) > 45056 and bench.measured_traffic("cfg3", "hs", 1.0) > 0
     assert bench.measured_traffic("cfg3", "policy99", 1.0) is None
+    table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    for name, wl in bench.WORKLOADS.items():                            # a default run of a named workload must find its counters
+        if "expect_policy" in wl:
+            assert "%s/policy%d" % (name, wl["expect_policy"]) in table, "profiles/traffic.json lacks %s/policy%d" % (name, wl["expect_policy"])
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert "edges" in base["metric"].lower() or "edges" in json.dumps(base).lower()
 

@@ -57,7 +57,7 @@ class FakeBlockModel:
         self.tab[table][part::n] = buf.numpy().reshape(-1, self.stride)[:rows]
 
 
-def _block_worker(rank, world, port, out_dir):
+def _block_worker(rank, world, port, out_dir, transport=None):
     import torch.distributed as dist
     from embedding_amd.distributed import block_schedule_step, gather_table
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -65,20 +65,23 @@ def _block_worker(rank, world, port, out_dir):
     m = FakeBlockModel(11, 4)                      # 11 rows: partitions of unequal size (padding in the packed buffers)
     bufs = (None, None)
     for _ in range(2):                             # two global batches
-        bufs = block_schedule_step(m, m.train, world, rank, *bufs)
+        bufs = block_schedule_step(m, m.train, world, rank, *bufs, transport=transport)
+    held = m.tab[1][rank::world].copy()            # ring invariant: after a whole batch, partition `rank` of syn1neg is home again
     gather_table(m, 0, world, rank)
+    gather_table(m, 1, world, rank)
+    assert np.array_equal(m.tab[1][rank::world], held)
     np.savez(os.path.join(out_dir, "b%d.npz" % rank), syn0=m.tab[0], syn1neg=m.tab[1], blocks=np.array(m.blocks), part=np.array(m.part))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_block_schedule_gloo(tmp_path, world):
+@pytest.mark.parametrize("world,transport", [(2, None), (3, None), (3, "allgather")])
+def test_block_schedule_gloo(tmp_path, world, transport):
     """Every (context partition, centre partition) block is trained exactly once per batch, by exactly one rank; the blocks
     of one episode are row-disjoint; all ranks end with identical tables."""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_block_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_block_worker, args=(world, port, str(tmp_path), transport), nprocs=world, join=True)
     r = [np.load(str(tmp_path / ("b%d.npz" % i))) for i in range(world)]
     seen = []
     for i in range(world):

@@ -318,9 +318,10 @@ def test_native_rccl_exchange_single_rank(dge, oracle):
     buf = torch.empty(b.sync_size(), dtype=torch.float32, device="cuda:0")
     b.export_delta(buf); b.import_delta(buf, 1.0)
     assert np.array_equal(bits(a.vectors()[0]), bits(b.vectors()[0])) and np.array_equal(bits(a.syn1neg()), bits(b.syn1neg()))
-    # the block schedule's partition exchange through the same communicator (one rank: the all-gather returns its own partition)
-    for table, episode in ((1, 0), (0, 0)):
-        dge._native.check(dge.lib.dge_model_exchange_partitions(a._h, comm, table, episode))
+    # the block schedule's ring pass and final gather through the same communicator (one rank: nothing moves)
+    dge._native.check(dge.lib.dge_model_ring_pass(a._h, comm, 0))
+    for table in (1, 0):
+        dge._native.check(dge.lib.dge_model_gather_table(a._h, comm, table))
     assert np.array_equal(bits(a.vectors()[0]), bits(b.vectors()[0])) and np.array_equal(bits(a.syn1neg()), bits(b.syn1neg()))
     dge.lib.dge_comm_free(comm)
 
