@@ -28,7 +28,7 @@ WORKLOADS = {
     "cfg3_zipf": dict(R=41667, T=24, mean_degree=100, dim=128, negative=5, L=24, walks_per_vertex=10, dst="zipf", expect_policy=7,
                       name="synthetic 1M-node / 100M-edge flow graph with Zipf-popular destinations, 24 timeslices, dim=128, K=5, L=W=24"),
     # BASELINE.json configs[1]: 100k-node / 5M-edge static graph, D=64, K=5
-    "cfg2": dict(R=100000, T=1, mean_degree=50, dim=64, negative=5, L=8, walks_per_vertex=10, expect_policy=2,
+    "cfg2": dict(R=100000, T=1, mean_degree=50, dim=64, negative=5, L=8, walks_per_vertex=10, expect_policy=8,
                  name="synthetic 100k-node / 5M-edge static flow graph, dim=64, K=5, L=W=8"),
     # BASELINE.json configs[4]: power-law 10M-node / 1B-edge dynamic graph, D=256, K=20 (8 GPUs in the config; runs on 1)
     "cfg5": dict(R=416667, T=24, n_edges=1_000_000_000, dim=256, negative=20, L=24, walks_per_vertex=1, powerlaw=True, expect_policy=7,
@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--force-exchange", action="store_true", help="run the delta exchange even with one rank (plumbing check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (debugging the multi-rank plumbing)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="dge_set_tuning knob for experiments (hot_rows, hs_drain, sorted_chunk, sorted_walks, ...)")
     ap.add_argument("--rendezvous-check", action="store_true",
                     help="ranks only meet (init_process_group, all-reduce, barrier) and rank 0 prints {\"n_gpus\": N, ...}: checks the "
                          "launcher on a box without a GPU; nothing is measured")
@@ -107,6 +109,10 @@ def main():
     import embedding_amd as E
     from embedding_amd import synth
     from embedding_amd.distributed import allreduce_counts, block_schedule_step, exchange_deltas, shard_plan
+
+    for kv in args.tune:
+        k, v = kv.split("=")
+        E._native.check(E.lib.dge_set_tuning(E.engine.TUNING_KNOBS[k], int(v)))
 
     def stage(msg):
         if rank == 0:
@@ -255,7 +261,8 @@ def main():
         sched = model.schedule()
         kernel_name = ("k_sgns_train<HS>" if args.hs else
                        {5: "k_sgns_train_locked", 6: "k_sgns_train_locked<strict>", 7: "k_sgns_train_locked<head rows by atomics>",
-                        2: "k_sgns_train<atomics>", 1: "k_sgns_train<row rmw>", 0: "k_sgns_train<in-order>"}[sched["update_policy"]])
+                        2: "k_sgns_train<atomics>", 1: "k_sgns_train<row rmw>", 0: "k_sgns_train<in-order>",
+                        8: "k_sorted_phase (owner-computes: emit + 2 sorts + 2 phases)"}[sched["update_policy"]])
         out = {
             "metric": "SGNS training edges/sec",
             "value": value,

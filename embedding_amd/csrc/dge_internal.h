@@ -94,7 +94,9 @@ struct dge_walks {
     int64_t n = 0;
     int32_t L = 0;
     int32_t* d = nullptr;
+    uint64_t gen = 0;          // changes whenever the library writes the corpus (a trainer may keep what it derived from an unchanged one)
 };
+uint64_t dge_next_generation();
 
 int dge_graph_ensure_csr(dge_graph* g);
 // launches the strided walk kernel on `stream`; rows [row0,row0+n) of out (row length L)

@@ -26,6 +26,7 @@ void dge_set_error(const char* fmt, ...) {
 
 extern "C" const char* dge_last_error(void) { return g_last_error.c_str(); }
 extern "C" int dge_version(void) { return DGE_VERSION; }
+uint64_t dge_next_generation() { static uint64_t g = 0; return ++g; }
 
 extern "C" int dge_device_count(int* n) {
     if (!n) DGE_FAIL(DGE_ERR_ARG, "dge_device_count: null output");
@@ -118,13 +119,23 @@ __global__ void k_topk_compact(const int64_t* row_ptr, const double* w_sorted, c
     outdeg[v] = dge_java8_stream_sum(w_out + nb, k);
 }
 
-// bulk addSourceVertex (J/LayeredGraph.java:180-189): one thread, because sourceWeightSum is a running sum
-__global__ void k_sources(const int32_t* srcv, int64_t S, const double* outdeg, double* src_w, int stream_sum, double* sum_out) {
+// bulk addSourceVertex (J/LayeredGraph.java:180-189).  The weights are gathered in parallel; sourceWeightSum is a running `+=` in
+// source order (or DoubleStream.sum(), a Kahan sum) — a sequential double sum by definition, taken by one lane over the gathered,
+// contiguous weights (the dependent gathers were what made the one-thread form slow: 14 ms at 100 k sources).
+__global__ void k_sources_gather(const int32_t* __restrict__ srcv, int64_t S, const double* __restrict__ outdeg, double* __restrict__ src_w) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S) src_w[i] = outdeg[srcv[i]];
+}
+__global__ void k_sources_sum(const double* __restrict__ src_w, int64_t S, int stream_sum, double* sum_out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     double s = 0.0;
-    for (int64_t i = 0; i < S; i++) { double d = outdeg[srcv[i]]; src_w[i] = d; s += d; }
     if (stream_sum) s = dge_java8_stream_sum(src_w, S);
+    else for (int64_t i = 0; i < S; i++) s += src_w[i];
     *sum_out = s;
+}
+static void launch_sources(hipStream_t st, const int32_t* srcv, int64_t S, const double* outdeg, double* src_w, int stream_sum, double* sum_out) {
+    if (S > 0) hipLaunchKernelGGL(k_sources_gather, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, srcv, S, outdeg, src_w);
+    hipLaunchKernelGGL(k_sources_sum, dim3(1), dim3(64), 0, st, src_w, S, stream_sum, sum_out);
 }
 
 // Vertex.initiateAliasTable for every vertex: one lane per table (J/LayeredGraph.java:197)
@@ -458,7 +469,7 @@ extern "C" int dge_graph_set_sources(dge_graph* g, const int32_t* v, int64_t n, 
     dge_tmp<double> d_sum;
     if ((rc = d_sum.alloc(1))) return rc;
     if (n) DGE_HIP(hipMemcpyAsync(g->d_srcv, v, n * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
-    hipLaunchKernelGGL(k_sources, dim3(1), dim3(64), 0, g->stream, g->d_srcv, n, g->d_outdeg, g->d_src_w, stream_sum, d_sum.p);
+    launch_sources(g->stream, g->d_srcv, n, g->d_outdeg, g->d_src_w, stream_sum, d_sum.p);
     DGE_HIP(hipMemcpyAsync(&g->src_weight_sum, d_sum.p, sizeof(double), hipMemcpyDeviceToHost, g->stream));
     DGE_HIP(hipStreamSynchronize(g->stream));
     g->S = n;
@@ -491,7 +502,7 @@ extern "C" int dge_graph_set_out_degree(dge_graph* g, const double* out_degree, 
         dge_tmp<double> d_sum;
         if ((rc = d_sum.alloc(1))) return rc;
         double sum = 0.0;
-        hipLaunchKernelGGL(k_sources, dim3(1), dim3(64), 0, g->stream, g->d_srcv, g->S, g->d_outdeg, g->d_src_w, g->src_stream_sum, d_sum.p);
+        launch_sources(g->stream, g->d_srcv, g->S, g->d_outdeg, g->d_src_w, g->src_stream_sum, d_sum.p);
         DGE_HIP(hipMemcpyAsync(&sum, d_sum.p, sizeof(double), hipMemcpyDeviceToHost, g->stream));
         DGE_HIP(hipStreamSynchronize(g->stream));
         if (!g->src_sum_fixed) g->src_weight_sum = sum;
@@ -571,7 +582,7 @@ extern "C" int dge_graph_keep_top_k(dge_graph* g, int32_t k) {
     if (g->S > 0) {
         dge_tmp<double> d_sum;
         if ((rc = d_sum.alloc(1))) return rc;
-        hipLaunchKernelGGL(k_sources, dim3(1), dim3(64), 0, g->stream, g->d_srcv, g->S, g->d_outdeg, g->d_src_w, 1, d_sum.p);
+        launch_sources(g->stream, g->d_srcv, g->S, g->d_outdeg, g->d_src_w, 1, d_sum.p);
         DGE_HIP(hipMemcpyAsync(&g->src_weight_sum, d_sum.p, sizeof(double), hipMemcpyDeviceToHost, g->stream));
         DGE_HIP(hipStreamSynchronize(g->stream));
         g->src_stream_sum = 1; g->src_sum_fixed = false;
@@ -771,7 +782,7 @@ extern "C" int dge_sample_walks_device(const dge_graph* g, int64_t n_walks, int3
     *out = nullptr;
     DGE_HIP(hipSetDevice(g->device));
     dge_walks* w = new dge_walks();
-    w->device = g->device; w->n = n_walks; w->L = max_len;
+    w->device = g->device; w->n = n_walks; w->L = max_len; w->gen = dge_next_generation();
     int rc = dge_dev_alloc(&w->d, (size_t)(n_walks * max_len));
     if (rc) { delete w; return rc; }
     rc = sample_walks_impl(g, n_walks, max_len, seed, rng_mode, first_index, w->d, draws_consumed);
@@ -796,6 +807,7 @@ extern "C" int dge_sample_walks_into(const dge_graph* g, dge_walks* w, int64_t r
     if (!g->alias_built) DGE_FAIL(DGE_ERR_STATE, "dge_sample_walks_into: alias tables not built");
     if (g->device != w->device) DGE_FAIL(DGE_ERR_ARG, "dge_sample_walks_into: graph and corpus live on different devices");
     DGE_HIP(hipSetDevice(g->device));
+    w->gen = dge_next_generation();
     int rc = dge_launch_walks_strided(g, g->stream, w->d + row0 * w->L, n_walks, w->L, seed, first_index, nullptr);
     if (rc) return rc;
     DGE_HIP(hipStreamSynchronize(g->stream));
@@ -808,7 +820,7 @@ extern "C" int dge_walks_from_host(int device, const int32_t* walks, int64_t n_w
     int rc = dge_require_device(device);
     if (rc) return rc;
     dge_walks* w = new dge_walks();
-    w->device = device; w->n = n_walks; w->L = max_len;
+    w->device = device; w->n = n_walks; w->L = max_len; w->gen = dge_next_generation();
     rc = dge_dev_alloc(&w->d, (size_t)(n_walks * max_len));
     if (rc) { delete w; return rc; }
     if (n_walks && hipMemcpy(w->d, walks, (size_t)(n_walks * max_len) * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
@@ -839,6 +851,7 @@ extern "C" int dge_walks_add_position_prefix(dge_walks* w, int32_t region_count)
     if (!w || region_count <= 0) DGE_FAIL(DGE_ERR_ARG, "dge_walks_add_position_prefix: bad argument");
     if ((int64_t)region_count * w->L > 0x7fffffffLL) DGE_FAIL(DGE_ERR_RANGE, "position prefix overflows int32 ids");
     DGE_HIP(hipSetDevice(w->device));
+    w->gen = dge_next_generation();
     if (w->n) hipLaunchKernelGGL(k_position_prefix, dim3(grid_for(w->n * w->L, 256)), dim3(256), 0, 0, w->d, w->n, w->L, region_count);
     DGE_HIP(hipDeviceSynchronize());
     return DGE_OK;

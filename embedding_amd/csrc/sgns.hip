@@ -25,60 +25,16 @@
 #include "dge_algos.h"
 #include "dge_internal.h"
 #include "sgns_kernels.h"
+#include "sgns_model.h"
 
 
-struct EventPair { hipEvent_t a, b; int kind; };
-
-// ablation / test knobs (dge_set_tuning): -1 = the library's own rule
-static int64_t g_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1};
+int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
-    g_tuning[knob] = value < 0 ? -1 : value;
+    g_dge_tuning[knob] = value < 0 ? -1 : value;
     return DGE_OK;
 }
 
-struct dge_model {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    dge_train_config cfg{};
-    int64_t V = 0;
-    int32_t D = 0, stride = 0, NV = 0;
-    int64_t T = 0;
-    int64_t total_words = 0;
-    double neg_collision = 1.0;                 // sum of squared negative-sampling probabilities: P(two draws hit one row)
-    int64_t hot_rows_auto = 0;                  // head rows that policy 7 keeps out of the lock protocol (see dge_model_create)
-    int64_t hot_rows_serial = 0;                // head rows whose own pairs, serialised by the row's lock, would outlast a launch
-    int n_cus = 256;
-    float *d_syn0 = nullptr, *d_syn1neg = nullptr, *d_snap = nullptr;
-    // hierarchical softmax (cfg.use_hs): inner-node table and the Huffman paths in CSR form
-    float* d_syn1 = nullptr;
-    int64_t* d_hs_off = nullptr; int32_t* d_hs_points = nullptr; uint64_t* d_hs_codes = nullptr;
-    std::vector<int64_t> h_hs_off; std::vector<int32_t> h_hs_points; std::vector<uint64_t> h_hs_codes;
-    std::vector<float> h_syn1;
-
-    int32_t* d_vocab_ids = nullptr;
-    int64_t* d_counts = nullptr;
-    int32_t* d_remap = nullptr;
-    int32_t* d_table = nullptr;
-    float* d_exp = nullptr;
-    // per-call work buffers
-    int64_t cap_rows = 0; int32_t cap_L = 0;
-    int32_t* d_sen = nullptr; int64_t* d_len = nullptr; int64_t* d_wb = nullptr;
-    void* d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
-    unsigned long long* d_counters = nullptr;   // [0]=pairs [1]=words
-    int* d_locks = nullptr;                     // commit-lock word per syn1neg row
-    // host mirrors for the read-back API
-    std::vector<float> h_syn0, h_syn1neg;
-    std::vector<int32_t> h_vocab_ids, h_table;
-    std::vector<int64_t> h_counts;
-    // stats
-    std::vector<EventPair> pending;
-    double kernel_ms = 0, walk_ms = 0;
-    int64_t launches = 0;
-    int last_policy = -1; int64_t last_workers = 0; int32_t last_hot_rows = 0;   // what the latest launch ran with
-    int32_t part_n = 1, part_ctx = 0, part_tgt = 0;                              // block schedule (dge_model_set_partition)
-};
 
 // ------------------------------------------------------------------------------------------ vocabulary
 __global__ void k_count_tokens(const int32_t* __restrict__ walks, int64_t n, int32_t NV, unsigned long long* counts) {
@@ -328,6 +284,7 @@ static void model_release(dge_model* m) {
     dge_dev_free(m->d_syn1); dge_dev_free(m->d_hs_off); dge_dev_free(m->d_hs_points); dge_dev_free(m->d_hs_codes);
     dge_dev_free(m->d_counts); dge_dev_free(m->d_remap); dge_dev_free(m->d_table); dge_dev_free(m->d_exp);
     dge_dev_free(m->d_sen); dge_dev_free(m->d_len); dge_dev_free(m->d_wb); dge_dev_free(m->d_scan_tmp); dge_dev_free(m->d_counters); dge_dev_free(m->d_locks);
+    dge_sorted_release(m);
     for (auto& e : m->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
 }
@@ -360,7 +317,7 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     int dch = (cfg->dim + 63) / 64;
     if (!dim_supported(dch)) dch = dch <= 6 ? 6 : 8;
     if (cfg->dim > 512) DGE_FAIL(DGE_ERR_ARG, "dge_model_create: dim %d > 512 is not supported", cfg->dim);
-    if (cfg->update_policy < 0 || cfg->update_policy == 4 || cfg->update_policy > 7) DGE_FAIL(DGE_ERR_ARG, "dge_model_create: unknown update_policy %d", cfg->update_policy);
+    if (cfg->update_policy < 0 || cfg->update_policy == 4 || cfg->update_policy > 8) DGE_FAIL(DGE_ERR_ARG, "dge_model_create: unknown update_policy %d", cfg->update_policy);
     if (cfg->use_hs && cfg->update_policy != 0 && cfg->update_policy != 2 && cfg->update_policy != 3)
         DGE_FAIL(DGE_ERR_ARG, "dge_model_create: use_hs runs under update_policy 0 (auto), 2 or 3, not %d", cfg->update_policy);
     int rc = dge_require_device(device);
@@ -426,6 +383,7 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
             double s2 = 0.0;
             for (int64_t i = 0; i < V; i++) { double q = pow((double)m->h_counts[(size_t)i], power) / twp; s2 += q * q; }
             m->neg_collision = s2;
+            m->row_share_max = std::max((double)m->h_counts[0] / (double)std::max<int64_t>(tw, 1), pow((double)m->h_counts[0], power) / twp);
             // Head of the vocabulary for the mixed policy (7).  A try-lock fails when another worker holds the row: per pair
             // ~5 syn1neg rows drawn with q_i (unigram^0.75) and one syn0 row that occurs with p_i (unigram), held for the whole
             // pair.  Expected failures per attempt with W workers ~ W * 5 * (sum q_i^2 + sum p_i^2) over the LOCKED rows; the
@@ -518,7 +476,7 @@ static int ensure_work(dge_model* m, int64_t n_rows, int32_t L) {
     DGE_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, m->d_len, m->d_wb, nr, m->stream));
     DGE_HIP(hipMalloc(&m->d_scan_tmp, bytes ? bytes : 1));
     m->scan_tmp_bytes = bytes;
-    m->cap_rows = nr; m->cap_L = nl;
+    m->cap_rows = nr; m->cap_L = nl; m->seen_gen = 0;
     return DGE_OK;
 }
 
@@ -562,14 +520,19 @@ static int timing_end(dge_model* m, EventPair& ev, int rc_so_far) {
 }
 
 static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32_t L, int64_t walk_index_base, int32_t epoch,
-                      int64_t words_before, double words_scale, int64_t total_walks) {
+                      int64_t words_before, double words_scale, int64_t total_walks, uint64_t corpus_gen) {
     if (n_rows == 0 || m->V == 0) return DGE_OK;
     int rc = ensure_work(m, n_rows, L);
     if (rc) return rc;
     hipStream_t st = m->stream;
-    hipLaunchKernelGGL(k_remap_compact, dim3(grid_for(n_rows, 256)), dim3(256), 0, st, d_rows, n_rows, L, m->d_remap, m->NV, m->d_sen, m->d_len);
-    size_t bytes = m->scan_tmp_bytes;
-    DGE_HIP(hipcub::DeviceScan::ExclusiveSum(m->d_scan_tmp, bytes, m->d_len, m->d_wb, n_rows, st));
+    // vocabulary rows of the walks, left-packed, and the words that precede each walk: kept while the same unchanged rows come again
+    // (the N episodes of a block-schedule batch train the same walks N times)
+    if (!(m->seen_rows == d_rows && m->seen_n == n_rows && m->seen_L == L && m->seen_gen == corpus_gen && corpus_gen != 0)) {
+        hipLaunchKernelGGL(k_remap_compact, dim3(grid_for(n_rows, 256)), dim3(256), 0, st, d_rows, n_rows, L, m->d_remap, m->NV, m->d_sen, m->d_len);
+        size_t bytes = m->scan_tmp_bytes;
+        DGE_HIP(hipcub::DeviceScan::ExclusiveSum(m->d_scan_tmp, bytes, m->d_len, m->d_wb, n_rows, st));
+        m->seen_rows = d_rows; m->seen_n = n_rows; m->seen_L = L; m->seen_gen = corpus_gen;
+    }
 
     TrainParams p;
     p.sen = m->d_sen; p.len = m->d_len; p.wb = m->d_wb;
@@ -588,11 +551,33 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt; p.syn0_free = 0;
     p.big_seg_shift = 0;
     p.filler_row = (int32_t)(0xFFFFFFF0u / ((uint32_t)m->stride * 4u)) - 1;      // offset + the largest in-row displacement stays below 2^32
-    if (g_tuning[DGE_TUNE_SEGMENT_SHIFT] >= 0) p.big_seg_shift = (int32_t)g_tuning[DGE_TUNE_SEGMENT_SHIFT];   // tests: several segments on a small table
+    if (g_dge_tuning[DGE_TUNE_SEGMENT_SHIFT] >= 0) p.big_seg_shift = (int32_t)g_dge_tuning[DGE_TUNE_SEGMENT_SHIFT];   // tests: several segments on a small table
     const bool part = m->part_n > 1;
     const bool hs = m->cfg.use_hs != 0;
     if (part && hs) DGE_FAIL(DGE_ERR_STATE, "the block schedule (dge_model_set_partition) cannot carry the hierarchical-softmax term: a Huffman path crosses every partition");
 
+    // auto: where the Hogwild kernels are bound by contention on a FLAT vocabulary — one too small for row locks (they fall back to
+    // atomics: cfg2), a block of a schedule of 4 and more ranks (V/N live rows per table) — the owner-computes schedule is the faster
+    // one at equal link-prediction AUC (one block of 8 ranks 5.7e8 vs 4.6e8 edges/s, a 100 k-row vocabulary at D = 128 6.8e8 vs 4.2e8:
+    // profiles/r02_quality_sorted.txt).  A skewed vocabulary stays with the mixed policy 7: a synchronous mini-batch hands a hot row
+    // thousands of terms at once with no feedback between them, and the embedding diverges (dge_sorted_batch_items).
+    bool sorted_auto = false;
+    if (m->cfg.update_policy == 0 && m->cfg.workers == 0 && !hs && (uint64_t)m->V * (uint64_t)m->stride * 4ull < 0xFFFFFFFFull) {
+        const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
+        const bool locks_work = m->V >= 262144 && (fail < 0.25 || m->hot_rows_auto <= m->V / 8);   // -> commit locks, all rows (5) or the tail (7)
+        if (part) sorted_auto = m->part_n >= 4 && dge_sorted_batch_items(m, m->part_n) > 0;
+        else sorted_auto = !locks_work && dge_sorted_batch_items(m, 1) > 0;                         // (what used to fall back to atomics)
+    }
+    if ((m->cfg.update_policy == 8 && m->cfg.workers != 1) || sorted_auto) {
+        // owner-computes schedule (sgns_sorted.hip): items sorted by row, no locks, no atomics, deterministic
+        if (hs) DGE_FAIL(DGE_ERR_ARG, "update_policy 8 does not carry the hierarchical-softmax term");
+        EventPair ev;
+        if ((rc = timing_begin(m, ev, 0))) return rc;
+        if ((rc = timing_end(m, ev, dge_sorted_train(m, p)))) return rc;
+        m->launches++;
+        m->last_policy = 8; m->last_workers = 0; m->last_hot_rows = 0;
+        return DGE_OK;
+    }
     int64_t workers;
     if (m->cfg.workers == 0) {
         // fill the device: 4 blocks of 16 workers per CU, but never more concurrent walks than half the vocabulary
@@ -623,10 +608,10 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         const double fail_all = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
         // a flat vocabulary with a few busy rows: only those; a skewed one: the whole head
         p.hot_rows = (int32_t)std::min<int64_t>((m->cfg.update_policy == 0 && fail_all < 0.25) ? m->hot_rows_serial : std::max(m->hot_rows_auto, m->hot_rows_serial), m->V);
-        if (g_tuning[DGE_TUNE_HOT_ROWS] >= 0) p.hot_rows = (int32_t)std::min<int64_t>(g_tuning[DGE_TUNE_HOT_ROWS], m->V);     // ablation knob
+        if (g_dge_tuning[DGE_TUNE_HOT_ROWS] >= 0) p.hot_rows = (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_HOT_ROWS], m->V);     // ablation knob
     }
     if (pol == 100 || (workers == 1 && pol != 5 && pol != 6 && pol != 7 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
-    if (pol == 3) pol = 0;
+    if (pol == 3 || pol == 8) pol = 0;          // (policy 8 with one worker: the in-order schedule)
     if (part && L > 64) DGE_FAIL(DGE_ERR_ARG, "the block schedule keeps a walk's tokens in registers: walks of up to 64 tokens, not %d", L);
     if (part) {
         // One block of the multi-GPU schedule: the live rows are V/part_n per table, so lock attempts collide part_n times
@@ -660,7 +645,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
             p.hs_n_hot = (int32_t)std::min<int64_t>(std::max<int64_t>(m->V - 1, 0), 30720 / row_b);
             p.hs_hot0 = (int32_t)(std::max<int64_t>(m->V - 1, 0) - p.hs_n_hot);
             p.hs_drain = 64;
-            if (g_tuning[DGE_TUNE_HS_DRAIN] >= 1) p.hs_drain = (int32_t)g_tuning[DGE_TUNE_HS_DRAIN];      // ablation knob
+            if (g_dge_tuning[DGE_TUNE_HS_DRAIN] >= 1) p.hs_drain = (int32_t)g_dge_tuning[DGE_TUNE_HS_DRAIN];      // ablation knob
             shmem = (size_t)p.hs_n_hot * (size_t)row_b;
         }
     }
@@ -669,7 +654,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
 
     // per-segment descriptors (TableView) for tables of 4 GiB and more; DGE_TUNE_FORCE_SEGMENTS selects that code path on small
     // tables too so that the parity tests can cover it
-    const bool big = (uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull || g_tuning[DGE_TUNE_FORCE_SEGMENTS] > 0;
+    const bool big = (uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull || g_dge_tuning[DGE_TUNE_FORCE_SEGMENTS] > 0;
     EventPair ev;
     if ((rc = timing_begin(m, ev, 0))) return rc;
     switch (m->stride / 64) {
@@ -694,7 +679,7 @@ extern "C" int dge_model_train(dge_model* m, const dge_walks* w, int64_t row0, i
     if (w->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_train: corpus and model live on different devices");
     DGE_HIP(hipSetDevice(m->device));
     if (total_walks <= 0) total_walks = w->n;
-    return train_rows(m, w->d + row0 * w->L, n_rows, w->L, walk_index_base, epoch, words_before, words_scale, total_walks);
+    return train_rows(m, w->d + row0 * w->L, n_rows, w->L, walk_index_base, epoch, words_before, words_scale, total_walks, w->gen);
 }
 
 extern "C" int dge_model_walk_and_train(dge_model* m, const dge_graph* g, dge_walks* w, int64_t row0, int64_t n_rows, int64_t walk_seed,
@@ -703,13 +688,14 @@ extern "C" int dge_model_walk_and_train(dge_model* m, const dge_graph* g, dge_wa
     if (!g->alias_built) DGE_FAIL(DGE_ERR_STATE, "dge_model_walk_and_train: alias tables not built");
     if (w->device != m->device || g->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_walk_and_train: handles live on different devices");
     DGE_HIP(hipSetDevice(m->device));
+    w->gen = dge_next_generation();
     EventPair ev;
     int rc = timing_begin(m, ev, 1);
     if (rc) return rc;
     rc = timing_end(m, ev, dge_launch_walks_strided(g, m->stream, w->d + row0 * w->L, n_rows, w->L, walk_seed, walk_index_base, nullptr));
     if (rc) return rc;
     if (total_walks <= 0) total_walks = w->n;
-    return train_rows(m, w->d + row0 * w->L, n_rows, w->L, walk_index_base, epoch, words_before, words_scale, total_walks);
+    return train_rows(m, w->d + row0 * w->L, n_rows, w->L, walk_index_base, epoch, words_before, words_scale, total_walks, w->gen);
 }
 
 extern "C" int dge_train_sgns_device(const dge_walks* w, const dge_train_config* cfg, dge_model** out) {

@@ -1,0 +1,66 @@
+// sgns_model.h — the trainer's handle (vocabulary + tables + per-call work buffers), shared by sgns.hip (host side of the C ABI)
+// and sgns_sorted.hip (the owner-computes schedule).
+#pragma once
+#include <vector>
+
+#include "dge_internal.h"
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+// ablation / test knobs (dge_set_tuning, include/dge.h): -1 = the library's own rule
+extern int64_t g_dge_tuning[DGE_TUNE_COUNT];
+
+struct dge_sorted_work;       // buffers of the owner-computes schedule (sgns_sorted.hip)
+
+struct dge_model {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    dge_train_config cfg{};
+    int64_t V = 0;
+    int32_t D = 0, stride = 0, NV = 0;
+    int64_t T = 0;
+    int64_t total_words = 0;
+    double row_share_max = 1.0;                 // largest share one row has of the tokens / of the negative draws
+    double neg_collision = 1.0;                 // sum of squared negative-sampling probabilities: P(two draws hit one row)
+    int64_t hot_rows_auto = 0;                  // head rows that policy 7 keeps out of the lock protocol (see dge_model_create)
+    int64_t hot_rows_serial = 0;                // head rows whose own pairs, serialised by the row's lock, would outlast a launch
+    int n_cus = 256;
+    float *d_syn0 = nullptr, *d_syn1neg = nullptr, *d_snap = nullptr;
+    // hierarchical softmax (cfg.use_hs): inner-node table and the Huffman paths in CSR form
+    float* d_syn1 = nullptr;
+    int64_t* d_hs_off = nullptr; int32_t* d_hs_points = nullptr; uint64_t* d_hs_codes = nullptr;
+    std::vector<int64_t> h_hs_off; std::vector<int32_t> h_hs_points; std::vector<uint64_t> h_hs_codes;
+    std::vector<float> h_syn1;
+
+    int32_t* d_vocab_ids = nullptr;
+    int64_t* d_counts = nullptr;
+    int32_t* d_remap = nullptr;
+    int32_t* d_table = nullptr;
+    float* d_exp = nullptr;
+    // per-call work buffers
+    int64_t cap_rows = 0; int32_t cap_L = 0;
+    int32_t* d_sen = nullptr; int64_t* d_len = nullptr; int64_t* d_wb = nullptr;
+    void* d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
+    unsigned long long* d_counters = nullptr;   // [0]=pairs [1]=words
+    int* d_locks = nullptr;                     // commit-lock word per syn1neg row
+    // host mirrors for the read-back API
+    std::vector<float> h_syn0, h_syn1neg;
+    std::vector<int32_t> h_vocab_ids, h_table;
+    std::vector<int64_t> h_counts;
+    // stats
+    std::vector<EventPair> pending;
+    double kernel_ms = 0, walk_ms = 0;
+    int64_t launches = 0;
+    int last_policy = -1; int64_t last_workers = 0; int32_t last_hot_rows = 0;   // what the latest launch ran with
+    int32_t part_n = 1, part_ctx = 0, part_tgt = 0;                              // block schedule (dge_model_set_partition)
+    const int32_t* seen_rows = nullptr; int64_t seen_n = 0; int32_t seen_L = 0; uint64_t seen_gen = 0;   // what d_sen/d_len/d_wb were derived from
+    dge_sorted_work* sorted = nullptr;                                           // update_policy 8 (allocated on first use)
+};
+
+// update_policy 8 (sgns_sorted.hip): one pass of the owner-computes schedule over compacted walks [0, n_rows) of m->d_sen
+struct TrainParams;
+int dge_sorted_train(dge_model* m, const TrainParams& p);
+// items of one synchronous mini-batch of that schedule for this model (0: its vocabulary is too skewed for the schedule)
+int64_t dge_sorted_batch_items(const dge_model* m, int part_n);
+void dge_sorted_release(dge_model* m);

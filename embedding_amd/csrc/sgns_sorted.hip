@@ -1,0 +1,565 @@
+// sgns_sorted.hip — update_policy 8: the OWNER-COMPUTES schedule of the skip-gram negative-sampling trainer (gfx950).
+//
+// The Hogwild kernels of sgns_kernels.h move every row a pair touches as a read-modify-write that must exclude other workers (row
+// locks) or combine at the memory side (float atomics).  That is the right shape while the tables are far larger than what is in
+// flight (cfg3: 0.8 of the HBM roofline).  It is the wrong shape when the LIVE rows are few: a 100 k-row vocabulary (cfg2), one block
+// of the 8-rank schedule (V/8 rows per table), the head of a skewed vocabulary.  By Little's law ~12 MB must be in flight to stream at
+// HBM rate; on a 25 MB table that is half the rows — exclusive access cannot be had, and the memory-side atomic rate (1.3 TB/s) is a
+// sixth of the plain rate.  Those tables fit the 256 MB Infinity Cache, so the remedy is to stop WRITING rows per update at all:
+//
+//   1. every (context row, target row, label) term of the batch becomes a 12-byte ITEM (k_sorted_emit) — the same pairs, window draws
+//      and negative draws as the other kernels make;
+//   2. the items are sorted by TARGET row (stable radix sort); a worker that owns a run of items of one row keeps that row in
+//      registers, reads the other side (syn0[context], read-only in this phase) through the caches, applies the row's updates one
+//      after the other exactly as the sequential loop would, and stores the row once (phase A).  The step g of every item is kept;
+//   3. the items are sorted by CONTEXT row; the owner of a context row sums g * syn1neg[target] over its items — the target rows as
+//      they stood BEFORE the mini-batch (phase A writes the moved rows to a shadow table that is committed afterwards): reading the
+//      moved rows instead would feed every item its own step back (a g^2 term along the context row, always of the same sign:
+//      measured, it wrecks the embedding) — and adds the sum to syn0[context] once (phase B).
+// No lock, no atomic, no lost update, and the result does not depend on how many workers ran: it is a deterministic function of the
+// batch, which the oracle restates bit for bit (oracle/dge_oracle.c: sorted_*), at FULL concurrency.
+// What it changes against the sequential loop: within one mini-batch (DGE_TUNE_SORTED_WALKS walks) the context rows are frozen while
+// the target rows move (phase A), and the context rows then take the sum of their terms (phase B) — a synchronous mini-batch, the
+// bounded staleness Hogwild has anyway (DL4J itself gathers 512 pairs per thread into one libnd4j aggregate batch).
+// Work units are CHUNKS of a fixed number of sorted items, not rows, so a hot row costs no more than a cold one: a row whose items
+// straddle chunk borders is processed as independent segments from the same starting row and their deltas are added in chunk order
+// by the owner of the row's first chunk (k_sorted_fixup).
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "sgns_kernels.h"
+#include "sgns_model.h"
+
+struct dge_sorted_work {
+    int64_t cap_units = 0;                       // (walk, centre) units the count buffers hold
+    int32_t* cnt = nullptr; int64_t* off = nullptr;
+    void* scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
+    int64_t cap_items = 0;                       // item slots of the two buffer pairs
+    int32_t *key0 = nullptr, *key1 = nullptr;
+    uint64_t *val0 = nullptr, *val1 = nullptr;
+    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    int64_t* seg = nullptr; int64_t cap_seg = 0; // first sorted position of every row (+ end): [0, V+2) by target, [V+2, 2V+4) by context
+    float* shadow = nullptr; int64_t cap_shadow = 0;   // the target rows as phase A leaves them, committed after phase B
+    float* scratch = nullptr; int64_t cap_scratch_rows = 0;
+    int64_t* d_marks = nullptr; int64_t cap_marks = 0;
+};
+
+void dge_sorted_release(dge_model* m) {
+    dge_sorted_work* s = m->sorted;
+    if (!s) return;
+    dge_dev_free(s->cnt); dge_dev_free(s->off); dge_dev_free(s->scan_tmp); dge_dev_free(s->key0); dge_dev_free(s->key1);
+    dge_dev_free(s->val0); dge_dev_free(s->val1); dge_dev_free(s->sort_tmp); dge_dev_free(s->seg); dge_dev_free(s->scratch); dge_dev_free(s->d_marks); dge_dev_free(s->shadow);
+    delete s;
+    m->sorted = nullptr;
+}
+
+struct SortedParams {
+    TrainParams t;
+    const int32_t* cnt; const int64_t* off;      // pairs per (walk, centre) unit, exclusive prefix
+    int64_t unit0, unit1;                        // units of this mini-batch
+    int64_t pair0;                               // off[unit0]
+    int32_t* key_out; uint64_t* val_out;         // emit / phase A output
+    const int32_t* key_in; const uint64_t* val_in;
+    const int64_t* seg;                          // seg[r] = first sorted position with key >= r; seg[V] = valid items
+    int64_t n_slots;                             // sorted array length (valid items first, then the skipped draws with key V)
+    int32_t chunk;                               // items per work unit
+    float* scratch;                              // [2 * chunks][stride]: deltas of the rows a chunk shares with its neighbours
+    float* shadow;                               // phase A writes the moved target rows here; phase B still reads the rows as they were
+};
+
+// the (walk, centre) unit's window: contexts c in [lo, hi] without i
+__device__ __forceinline__ void unit_window(const TrainParams& p, int64_t w, int i, int len, uint64_t& s, int& lo, int& hi) {
+    const int64_t gbase = (p.gidx_base + w) * (int64_t)p.L;
+    s = dge_mix64(p.seed + (uint64_t)(gbase + i));
+    s = s * DGE_W2V_MULT + 11;
+    const int radius = p.W - (int)(s % (uint64_t)p.W);
+    lo = max(0, i - radius);
+    hi = min(len - 1, i + radius);
+}
+
+// pairs of every (walk, centre) unit; totals of pairs and words for dge_model_stats
+__global__ void __launch_bounds__(256) k_sorted_count(TrainParams p, int32_t* cnt) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_units = p.n_rows * (int64_t)p.L;
+    int n = 0; long long words = 0;
+    if (u < n_units) {
+        const int64_t w = u / p.L; const int i = (int)(u % p.L);
+        const int len = (int)p.len[w];
+        const int32_t* sen = p.sen + w * p.L;
+        if (i == 0 && (p.part_n <= 1 || p.part_ctx == p.part_tgt)) words = len;
+        if (i < len && (p.part_n <= 1 || sen[i] % p.part_n == p.part_tgt)) {
+            uint64_t s; int lo, hi;
+            unit_window(p, w, i, len, s, lo, hi);
+            if (p.part_n <= 1) n = (hi - lo + 1) - 1;               // every token of the compacted walk is a context, but the centre itself
+            else for (int c = lo; c <= hi; c++) n += (c != i && sen[c] % p.part_n == p.part_ctx) ? 1 : 0;
+        }
+        cnt[u] = n;
+    }
+    long long pn = n;
+    for (int o = 32; o > 0; o >>= 1) { pn += __shfl_xor(pn, o); words += __shfl_xor(words, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (pn) atomicAdd(&p.counters[0], (unsigned long long)pn);
+        if (words) atomicAdd(&p.counters[1], (unsigned long long)words);
+    }
+}
+
+// the same counts with one thread per WALK (walks of up to 64 tokens: the partition tests become two bit masks over the walk's
+// tokens, a unit's pair count a popcount) — the block schedule visits every walk of the global batch for a few pairs each
+__global__ void __launch_bounds__(256) k_sorted_count_walks(TrainParams p, int32_t* cnt) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    long long pn = 0, words = 0;
+    if (w < p.n_rows) {
+        const int len = (int)p.len[w];
+        const int32_t* sen = p.sen + w * p.L;
+        uint64_t ctx_mask = 0, tgt_mask = 0;
+        if (p.part_n <= 1) ctx_mask = tgt_mask = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+        else for (int j = 0; j < len; j++) {
+            const int r = sen[j] % p.part_n;
+            ctx_mask |= (uint64_t)(r == p.part_ctx) << j; tgt_mask |= (uint64_t)(r == p.part_tgt) << j;
+        }
+        if (p.part_n <= 1 || p.part_ctx == p.part_tgt) words = len;
+        for (int i = 0; i < p.L; i++) {
+            int n = 0;
+            if (i < len && ((tgt_mask >> i) & 1ull)) {
+                uint64_t s; int lo, hi;
+                unit_window(p, w, i, len, s, lo, hi);
+                uint64_t wm = (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & (~0ull << lo) & ~(1ull << i);
+                n = __popcll(ctx_mask & wm);
+            }
+            cnt[w * p.L + i] = n;
+            pn += n;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { pn += __shfl_xor(pn, o); words += __shfl_xor(words, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (pn) atomicAdd(&p.counters[0], (unsigned long long)pn);
+        if (words) atomicAdd(&p.counters[1], (unsigned long long)words);
+    }
+}
+
+__global__ void k_sorted_marks(const int64_t* off, const int64_t* units, int n, int64_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = off[units[i]];
+}
+
+// items of one mini-batch: slot (pair - pair0) * (K+1) + d holds term d of the pair (d = 0: the centre, label 1; d >= 1: negative d).
+// A negative that drew the centre itself is not trained (word2vec): its slot gets the key V and sorts behind every row.
+// One 16-lane group per 16 (walk, centre) units; lane j draws negative j of a pair (the draws of k_sgns_train, stream for stream).
+__global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
+    const TrainParams& p = q.t;
+    const int lane = threadIdx.x & 15;
+    const int sh = threadIdx.x & 48;
+    // a group takes 16 consecutive units and works through those that have pairs (under the block schedule most have none)
+    const int64_t u0 = q.unit0 + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4) * 16;
+    if (u0 >= q.unit1) return;
+    const int my_cnt = u0 + lane < q.unit1 ? q.cnt[u0 + lane] : 0;
+    unsigned todo = (unsigned)(__ballot(my_cnt > 0) >> sh) & 0xFFFFu;
+    if (!todo) return;
+    // every lane prepares ITS unit (one round of loads for the whole group), the group then walks through the units' pairs
+    int64_t my_slot = 0; uint64_t my_s = 0; int my_lo = 0, my_hi = -1; float my_alpha = 0.f; int32_t my_word = -1;
+    if (my_cnt > 0) {
+        const int64_t u = u0 + lane;
+        const int64_t w = u / p.L; const int i = (int)(u % p.L);
+        const int len = (int)p.len[w];
+        my_word = p.sen[w * p.L + i];
+        unit_window(p, w, i, len, my_s, my_lo, my_hi);
+        const int64_t wbw = p.wb[w];
+        const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
+        my_alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
+        if (my_alpha < p.min_alpha) my_alpha = p.min_alpha;
+        my_slot = (q.off[u] - q.pair0) * (int64_t)(p.K + 1);
+    }
+    uint64_t mA = 1, cA = 0;
+    for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
+    const int K = p.K;
+    while (todo) {
+        const int ul = __builtin_ctz(todo); todo &= todo - 1;
+        const int64_t u = u0 + ul;
+        const int64_t w = u / p.L; const int i = (int)(u % p.L);
+        const int32_t* sen = p.sen + w * p.L;
+        const int32_t word = __shfl(my_word, ul, 16);
+        const int lo = __shfl(my_lo, ul, 16), hi = __shfl(my_hi, ul, 16);
+        const float alpha = __shfl(my_alpha, ul, 16);
+        uint64_t s = shfl16_u64(my_s, ul);
+        const uint64_t s_centre = s;
+        int64_t slot = (int64_t)shfl16_u64((uint64_t)my_slot, ul);
+        for (int c0 = lo; c0 <= hi; c0 += 16) {
+            // 16 candidate contexts at a time: lane j tests position c0 + j
+            const int cj = c0 + lane;
+            int32_t tok = -1;
+            if (cj <= hi && cj != i) { tok = sen[cj]; if (p.part_n > 1 && tok % p.part_n != p.part_ctx) tok = -1; }
+            unsigned live = (unsigned)(__ballot(tok >= 0) >> sh) & 0xFFFFu;
+            while (live) {
+                // up to 4 pairs per trip: their table look-ups are in flight together
+                int32_t lastv[4], tv[4]; int npair = 0;
+#pragma unroll
+                for (int z = 0; z < 4; z++) {
+                    lastv[z] = -1; tv[z] = -1;
+                    if (live) {
+                        const int cl = __builtin_ctz(live); live &= live - 1;
+                        lastv[z] = __shfl(tok, cl, 16);
+                        if (p.part_n > 1) s = dge_mix64(s_centre + (uint64_t)(c0 + cl));     // block schedule: every pair draws from its own stream
+                        if (K <= 16) {                                                    // (more negatives than lanes: one pair per trip, below)
+                            const uint64_t sl = s * mA + cA;
+                            if (lane < K) {
+                                int32_t t = p.table[(sl >> 16) % (uint64_t)p.T];
+                                if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                                tv[z] = t;
+                            }
+                            if (K > 0) s = shfl16_u64(sl, K - 1);
+                        }
+                        npair = z + 1;
+                        if (K > 16) break;
+                    }
+                }
+#pragma unroll
+                for (int z = 0; z < 4; z++) {
+                    if (z >= npair) break;
+                    const uint64_t hi32 = (uint64_t)(uint32_t)lastv[z] << 32;
+                    if (lane == 0) { q.key_out[slot] = word; q.val_out[slot] = hi32 | (uint64_t)__float_as_uint(alpha); }
+                    if (K <= 16) {
+                        if (lane < K) {
+                            int32_t t = tv[z];
+                            if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
+                            q.key_out[slot + 1 + lane] = t == word ? (int32_t)p.V : t;
+                            q.val_out[slot + 1 + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);      // label 0: the sign bit
+                        }
+                    } else {
+                        for (int kd = 0; kd < K; kd += 16) {
+                            const int kc = min(16, K - kd);
+                            const uint64_t sl = s * mA + cA;
+                            if (lane < kc) {
+                                int32_t t = p.table[(sl >> 16) % (uint64_t)p.T];
+                                if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                                if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
+                                q.key_out[slot + 1 + kd + lane] = t == word ? (int32_t)p.V : t;
+                                q.val_out[slot + 1 + kd + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);
+                            }
+                            s = shfl16_u64(sl, kc - 1);
+                        }
+                    }
+                    slot += K + 1;
+                }
+            }
+        }
+    }
+}
+
+// seg[r] = first position of the sorted keys that is >= r, r = 0 .. V+1  (seg[V] = number of valid items, seg[V+1] = n)
+__global__ void k_sorted_segments(const int32_t* __restrict__ keys, int64_t n, int64_t V, int64_t* seg) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > V + 1) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)keys[mid] < r) lo = mid + 1; else hi = mid; }
+    seg[r] = lo;
+}
+
+#define SORTED_PIPE 4      /* rows of the other side in flight per worker */
+
+// One worker (16 lanes) per chunk of sorted items.  PB == false (phase A): key = target row (owned, syn1neg), value = context row |
+// signed alpha; the row takes its updates in item order, the step g of every item goes out with (context, target) for phase B.
+// PB == true (phase B): key = context row (owned, syn0), value = target row | g; the row takes the sum of g * syn1neg[target].
+// A row that lies wholly inside the chunk is stored directly; a segment of a row shared with a neighbouring chunk leaves its DELTA in
+// scratch slot 2*chunk (the segment starts the chunk) or 2*chunk+1 (it ends the chunk), summed up by k_sorted_fixup.
+template <int DCH, bool PB>
+__global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
+    const TrainParams& p = q.t;
+    __shared__ float s_exp[EXP_TABLE_SIZE];
+    if (!PB) {
+        for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 15;
+    const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t start = chunk * q.chunk;
+    if (start >= q.n_slots) return;
+    const int64_t end = min(start + (int64_t)q.chunk, q.n_slots);
+    const int64_t n_valid = q.seg[p.V];
+    if (!PB)            // the slots behind the valid items (skipped draws) stay invalid for the second sort
+        for (int64_t x = max(start, n_valid) + lane; x < end; x += 16) { q.key_out[x] = (int32_t)p.V; q.val_out[x] = 0; }
+    if (start >= n_valid) return;
+    const int64_t stop = min(end, n_valid);
+
+    const TableView own = make_view(PB ? p.syn0 : p.syn1neg, p.V, p.stride);
+    const TableView oth = make_view(PB ? p.syn1neg : p.syn0, p.V, p.stride);
+    const TableView scr = make_view(q.scratch, 2 * ((q.n_slots + q.chunk - 1) / q.chunk), p.stride);
+    const TableView shd = make_view(q.shadow, p.V, p.stride);
+
+    int32_t cur = -1;
+    int64_t seg_start = start;
+    Row<DCH> h, d;                                 // the owned row as it moves (phase A), the delta of the open segment
+    row_zero(h); row_zero(d);
+
+    // close the open segment [seg_start, seg_end) of row `cur`
+#define SORTED_CLOSE(seg_end)                                                                                          \
+    do {                                                                                                               \
+        if (cur >= 0) {                                                                                                \
+            const bool whole = seg_start == q.seg[cur] && (seg_end) == q.seg[cur + 1];                                 \
+            if (whole) {                                                                                               \
+                if (PB) {                                                                                              \
+                    Row<DCH> r0;                                                                                       \
+                    rowA_load<DCH, 0, false>(r0, own, cur, lane);                                                      \
+                    _Pragma("unroll") for (int c_ = 0; c_ < DCH; c_++) {                                               \
+                        r0.v[c_].x += d.v[c_].x; r0.v[c_].y += d.v[c_].y; r0.v[c_].z += d.v[c_].z; r0.v[c_].w += d.v[c_].w; \
+                    }                                                                                                  \
+                    rowA_store<DCH, 0, false>(r0, own, cur, lane);                                                     \
+                } else rowA_store<DCH, 0, false>(h, shd, cur, lane);                                                   \
+            } else rowA_store<DCH, 0, false>(d, scr, (int32_t)(2 * chunk + (seg_start == start ? 0 : 1)), lane);      \
+        }                                                                                                              \
+    } while (0)
+
+    for (int64_t base = start; base < stop; base += 16) {
+        // 16 items at a time: lane l holds item base + l
+        const int64_t mine = base + lane;
+        int32_t k_l = -1; uint64_t v_l = 0;
+        if (mine < stop) { k_l = q.key_in[mine]; v_l = q.val_in[mine]; }
+        const int nb = (int)min((int64_t)16, stop - base);
+        for (int g0 = 0; g0 < nb; g0 += SORTED_PIPE) {
+            Row<DCH> o[SORTED_PIPE];
+            int32_t key[SORTED_PIPE]; uint32_t vhi[SORTED_PIPE], vlo[SORTED_PIPE];
+#pragma unroll
+            for (int z = 0; z < SORTED_PIPE; z++) {
+                const int src = min(g0 + z, nb - 1);
+                key[z] = __shfl(k_l, src, 16);
+                vhi[z] = (uint32_t)__shfl((int)(uint32_t)(v_l >> 32), src, 16);
+                vlo[z] = (uint32_t)__shfl((int)(uint32_t)v_l, src, 16);
+                rowA_load<DCH, 0, false>(o[z], oth, (int32_t)vhi[z], lane);
+            }
+#pragma unroll
+            for (int z = 0; z < SORTED_PIPE; z++) {
+                if (g0 + z >= nb) break;
+                const int64_t idx = base + g0 + z;
+                if (key[z] != cur) {
+                    SORTED_CLOSE(idx);
+                    cur = key[z]; seg_start = idx;
+                    row_zero(d);
+                    if (!PB) rowA_load<DCH, 0, false>(h, own, cur, lane);
+                }
+                if (PB) {
+                    row_axpy(d, __uint_as_float(vlo[z]), o[z]);
+                } else {
+                    const float a = __uint_as_float(vlo[z]);
+                    const float f = row_dot(h, o[z]);
+                    const float g = sgns_g(f, (vlo[z] >> 31) ? 0.0f : 1.0f, fabsf(a), s_exp);
+                    row_axpy(h, g, o[z]);
+                    row_axpy(d, g, o[z]);
+                    if (lane == 0) { q.key_out[idx] = (int32_t)vhi[z]; q.val_out[idx] = ((uint64_t)(uint32_t)key[z] << 32) | (uint64_t)__float_as_uint(g); }
+                }
+            }
+        }
+    }
+    SORTED_CLOSE(stop);
+#undef SORTED_CLOSE
+}
+
+// rows shared by several chunks: the worker of the chunk in which such a row BEGINS adds the deltas of all its segments, in chunk
+// order, to the row as it stood before the phase
+template <int DCH>
+__global__ void __launch_bounds__(256) k_sorted_fixup(SortedParams q, int phase_b) {
+    const TrainParams& p = q.t;
+    const int lane = threadIdx.x & 15;
+    const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t n_valid = q.seg[p.V];
+    const int64_t start = chunk * q.chunk;
+    if (start >= n_valid) return;
+    const int64_t end = min(start + (int64_t)q.chunk, n_valid);
+    const int32_t r = q.key_in[end - 1];                              // the row of the chunk's last item
+    const int64_t r0 = q.seg[r], r1 = q.seg[r + 1];
+    if (r1 <= end || r0 < start) return;                              // it ends here, or it began in an earlier chunk
+    const TableView own = make_view(phase_b ? p.syn0 : p.syn1neg, p.V, p.stride);
+    const TableView scr = make_view(q.scratch, 2 * ((q.n_slots + q.chunk - 1) / q.chunk), p.stride);
+    Row<DCH> row;
+    rowA_load<DCH, 0, false>(row, own, r, lane);
+    const int64_t c_hi = (r1 - 1) / q.chunk;
+    for (int64_t c = chunk; c <= c_hi; c++) {
+        Row<DCH> dd;
+        rowA_load<DCH, 0, false>(dd, scr, (int32_t)(2 * c + (r0 <= c * q.chunk ? 0 : 1)), lane);
+#pragma unroll
+        for (int x = 0; x < DCH; x++) { row.v[x].x += dd.v[x].x; row.v[x].y += dd.v[x].y; row.v[x].z += dd.v[x].z; row.v[x].w += dd.v[x].w; }
+    }
+    if (phase_b) rowA_store<DCH, 0, false>(row, own, r, lane);
+    else rowA_store<DCH, 0, false>(row, make_view(q.shadow, p.V, p.stride), r, lane);
+}
+
+// end of a mini-batch: the target rows that had items take the value phase A left in the shadow table
+template <int DCH>
+__global__ void __launch_bounds__(256) k_sorted_commit(SortedParams q, const int64_t* seg_a) {
+    const TrainParams& p = q.t;
+    const int lane = threadIdx.x & 15;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (r >= p.V || seg_a[r + 1] == seg_a[r]) return;
+    Row<DCH> row;
+    rowA_load<DCH, 0, false>(row, make_view(q.shadow, p.V, p.stride), (int32_t)r, lane);
+    rowA_store<DCH, 0, false>(row, make_view(p.syn1neg, p.V, p.stride), (int32_t)r, lane);
+}
+template <int DCH>
+static void launch_commit(const SortedParams& q, const int64_t* seg_a, hipStream_t st) {
+    hipLaunchKernelGGL((k_sorted_commit<DCH>), dim3((unsigned)((q.t.V * 16 + 255) / 256)), dim3(256), 0, st, q, seg_a);
+}
+static void launch_commit_any(int dch, const SortedParams& q, const int64_t* seg_a, hipStream_t st) {
+    switch (dch) {
+        case 1: launch_commit<1>(q, seg_a, st); break;
+        case 2: launch_commit<2>(q, seg_a, st); break;
+        case 3: launch_commit<3>(q, seg_a, st); break;
+        case 4: launch_commit<4>(q, seg_a, st); break;
+        case 6: launch_commit<6>(q, seg_a, st); break;
+        default: launch_commit<8>(q, seg_a, st); break;
+    }
+}
+
+// Items of one synchronous mini-batch.  Within a mini-batch the context rows are frozen and every row takes its terms without feedback
+// from the other side, so the size is set by TERMS PER LIVE ROW: measured (scripts/quality_sorted.py, profiles/r02_quality_sorted.txt)
+// the link-prediction AUC equals the atomics schedule's up to ~120 items per row and mini-batch, slips at ~460 and collapses at ~2300 —
+// and the HOTTEST row counts, not the average one: on a Zipf-popular graph a head row took > 1e5 terms of a 96-per-row mini-batch and
+// the tables went to NaN within an epoch.  Hence: 96 items per live row, at most 2048 for the hottest row, and no mini-batch below 1e6
+// items (the two sorts and ~16 launches per mini-batch need that much to pay): 0 = this vocabulary is too skewed or too small.
+int64_t dge_sorted_batch_items(const dge_model* m, int part_n) {
+    const int n = std::max(part_n, 1);
+    const int64_t live_rows = std::max<int64_t>(1, m->V / n);
+    const double hottest = std::min(1.0, m->row_share_max * (double)n);      // its share of one block's terms
+    int64_t items = std::min<int64_t>(96ll << 20, 96 * live_rows);
+    items = std::min<int64_t>(items, (int64_t)(2048.0 / std::max(hottest, 1e-12)));
+    return items >= (1 << 20) ? items : 0;
+}
+
+struct CastI64 { __host__ __device__ int64_t operator()(int32_t x) const { return (int64_t)x; } };
+typedef hipcub::TransformInputIterator<int64_t, CastI64, const int32_t*> CountIter;      // pair counts summed in 64 bits (an epoch-long launch has > 2^31 pairs)
+
+static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+template <int DCH>
+static void launch_phase(const SortedParams& q, bool phase_b, hipStream_t st) {
+    const int64_t chunks = (q.n_slots + q.chunk - 1) / q.chunk;
+    const unsigned blocks = grid_for(chunks * 16, 256);
+    if (phase_b) hipLaunchKernelGGL((k_sorted_phase<DCH, true>), dim3(blocks), dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((k_sorted_phase<DCH, false>), dim3(blocks), dim3(256), 0, st, q);
+    hipLaunchKernelGGL((k_sorted_fixup<DCH>), dim3(blocks), dim3(256), 0, st, q, phase_b ? 1 : 0);
+}
+static void launch_phase_any(int dch, const SortedParams& q, bool phase_b, hipStream_t st) {
+    switch (dch) {
+        case 1: launch_phase<1>(q, phase_b, st); break;
+        case 2: launch_phase<2>(q, phase_b, st); break;
+        case 3: launch_phase<3>(q, phase_b, st); break;
+        case 4: launch_phase<4>(q, phase_b, st); break;
+        case 6: launch_phase<6>(q, phase_b, st); break;
+        default: launch_phase<8>(q, phase_b, st); break;
+    }
+}
+
+int dge_sorted_train(dge_model* m, const TrainParams& p) {
+    if ((uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull)
+        DGE_FAIL(DGE_ERR_ARG, "update_policy 8 addresses a table through one descriptor: tables of 4 GiB and more are not supported");
+    if (m->cfg.use_hs) DGE_FAIL(DGE_ERR_ARG, "update_policy 8 does not carry the hierarchical-softmax term");
+    if (!m->sorted) m->sorted = new dge_sorted_work();
+    dge_sorted_work* s = m->sorted;
+    hipStream_t st = m->stream;
+    const int64_t n_units = p.n_rows * (int64_t)p.L;
+    const int K1 = p.K + 1;
+    int rc;
+    if (n_units + 1 > s->cap_units) {
+        DGE_HIP(hipStreamSynchronize(st));
+        dge_dev_free(s->cnt); dge_dev_free(s->off); dge_dev_free(s->scan_tmp); s->cnt = nullptr; s->off = nullptr; s->scan_tmp = nullptr; s->cap_units = 0;
+        if ((rc = dge_dev_alloc(&s->cnt, (size_t)n_units + 1))) return rc;
+        if ((rc = dge_dev_alloc(&s->off, (size_t)n_units + 1))) return rc;
+        size_t b = 0;
+        DGE_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b, CountIter(s->cnt, CastI64()), s->off, n_units + 1, st));
+        DGE_HIP(hipMalloc(&s->scan_tmp, b ? b : 1)); s->scan_tmp_bytes = b;
+        s->cap_units = n_units + 1;
+    }
+    // pairs of every (walk, centre) unit and their exclusive prefix (one extra zero unit carries the total)
+    DGE_HIP(hipMemsetAsync(s->cnt + n_units, 0, sizeof(int32_t), st));
+    if (p.L <= 64) hipLaunchKernelGGL(k_sorted_count_walks, dim3(grid_for(p.n_rows, 256)), dim3(256), 0, st, p, s->cnt);
+    else hipLaunchKernelGGL(k_sorted_count, dim3(grid_for(n_units, 256)), dim3(256), 0, st, p, s->cnt);
+    { size_t b = s->scan_tmp_bytes; DGE_HIP(hipcub::DeviceScan::ExclusiveSum(s->scan_tmp, b, CountIter(s->cnt, CastI64()), s->off, n_units + 1, st)); }
+
+    // mini-batches of whole walks (dge_sorted_batch_items: ~96 items per live row, the hottest row bounded)
+    int64_t total_pairs = 0;
+    DGE_HIP(hipMemcpyAsync(&total_pairs, s->off + n_units, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    DGE_HIP(hipStreamSynchronize(st));
+    if (total_pairs == 0) return DGE_OK;
+    int64_t want_items = dge_sorted_batch_items(m, p.part_n);
+    if (want_items == 0) want_items = 1 << 20;         // asked for explicitly on a vocabulary the rule would not pick it for: smallest mini-batches
+    const double items_per_walk = (double)total_pairs * K1 / (double)p.n_rows;
+    int64_t walks_per = std::max<int64_t>(1, (int64_t)((double)want_items / std::max(items_per_walk, 1e-9)));
+    if (g_dge_tuning[DGE_TUNE_SORTED_WALKS] > 0) walks_per = g_dge_tuning[DGE_TUNE_SORTED_WALKS];
+    walks_per = std::min(walks_per, p.n_rows);
+    const int64_t n_sub = (p.n_rows + walks_per - 1) / walks_per;
+    std::vector<int64_t> marks((size_t)n_sub + 1), h_off((size_t)n_sub + 1);
+    for (int64_t k = 0; k <= n_sub; k++) marks[(size_t)k] = std::min(k * walks_per, p.n_rows) * p.L;
+    if (n_sub + 1 > s->cap_marks) {
+        dge_dev_free(s->d_marks); s->d_marks = nullptr;
+        if ((rc = dge_dev_alloc(&s->d_marks, 2 * ((size_t)n_sub + 1)))) return rc;
+        s->cap_marks = n_sub + 1;
+    }
+    DGE_HIP(hipMemcpyAsync(s->d_marks, marks.data(), ((size_t)n_sub + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_sorted_marks, dim3(grid_for(n_sub + 1, 256)), dim3(256), 0, st, s->off, s->d_marks, (int)(n_sub + 1), s->d_marks + n_sub + 1);
+    DGE_HIP(hipMemcpyAsync(h_off.data(), s->d_marks + n_sub + 1, ((size_t)n_sub + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    DGE_HIP(hipStreamSynchronize(st));
+
+    int64_t max_slots = 0;
+    for (int64_t k = 0; k < n_sub; k++) max_slots = std::max(max_slots, (h_off[(size_t)k + 1] - h_off[(size_t)k]) * K1);
+    if (max_slots >= 0x7fffffffll) DGE_FAIL(DGE_ERR_ARG, "update_policy 8: a mini-batch of %lld items; set fewer walks per mini-batch", (long long)max_slots);
+    int chunk = 256;
+    if (g_dge_tuning[DGE_TUNE_SORTED_CHUNK] > 0) chunk = (int)std::min<int64_t>(g_dge_tuning[DGE_TUNE_SORTED_CHUNK], 1 << 20);
+    int end_bit = 1;
+    while (end_bit < 31 && (1ll << end_bit) <= (int64_t)m->V) end_bit++;      // keys are 0 .. V (V = a skipped draw)
+    if (max_slots > s->cap_items) {
+        dge_dev_free(s->key0); dge_dev_free(s->key1); dge_dev_free(s->val0); dge_dev_free(s->val1); dge_dev_free(s->sort_tmp);
+        s->key0 = s->key1 = nullptr; s->val0 = s->val1 = nullptr; s->sort_tmp = nullptr; s->cap_items = 0;
+        const int64_t cap = max_slots + max_slots / 8 + 1024;
+        if ((rc = dge_dev_alloc(&s->key0, (size_t)cap))) return rc;
+        if ((rc = dge_dev_alloc(&s->key1, (size_t)cap))) return rc;
+        if ((rc = dge_dev_alloc(&s->val0, (size_t)cap))) return rc;
+        if ((rc = dge_dev_alloc(&s->val1, (size_t)cap))) return rc;
+        size_t b = 0;
+        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b, s->key0, s->key1, s->val0, s->val1, (int)std::min<int64_t>(cap, 0x7fffffff), 0, 31, st));
+        DGE_HIP(hipMalloc(&s->sort_tmp, b ? b : 1)); s->sort_tmp_bytes = b;
+        s->cap_items = cap;
+    }
+    if (m->V + 2 > s->cap_seg) {
+        dge_dev_free(s->seg); s->seg = nullptr;
+        if ((rc = dge_dev_alloc(&s->seg, 2 * ((size_t)m->V + 2)))) return rc;
+        s->cap_seg = m->V + 2;
+    }
+    if (m->V > s->cap_shadow) {
+        dge_dev_free(s->shadow); s->shadow = nullptr;
+        if ((rc = dge_dev_alloc(&s->shadow, (size_t)m->V * (size_t)m->stride + 64))) return rc;
+        s->cap_shadow = m->V;
+    }
+    const int64_t need_rows = 2 * ((s->cap_items + chunk - 1) / chunk) + 2;
+    if (need_rows > s->cap_scratch_rows) {
+        dge_dev_free(s->scratch); s->scratch = nullptr;
+        if ((uint64_t)need_rows * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull) DGE_FAIL(DGE_ERR_ARG, "update_policy 8: chunk size %d too small for %lld items", chunk, (long long)s->cap_items);
+        if ((rc = dge_dev_alloc(&s->scratch, (size_t)need_rows * (size_t)m->stride))) return rc;
+        s->cap_scratch_rows = need_rows;
+    }
+
+    SortedParams q;
+    q.t = p; q.cnt = s->cnt; q.off = s->off; q.seg = s->seg; q.chunk = chunk; q.scratch = s->scratch; q.shadow = s->shadow;
+    int64_t* const seg_a = s->seg; int64_t* const seg_b = s->seg + m->V + 2;
+    const int dch = m->stride / 64;
+    for (int64_t k = 0; k < n_sub; k++) {
+        const int64_t n = (h_off[(size_t)k + 1] - h_off[(size_t)k]) * K1;
+        if (n == 0) continue;
+        q.unit0 = marks[(size_t)k]; q.unit1 = marks[(size_t)k + 1]; q.pair0 = h_off[(size_t)k]; q.n_slots = n;
+        // items -> (key0, val0); sorted by target row -> (key1, val1)
+        q.key_out = s->key0; q.val_out = s->val0;
+        hipLaunchKernelGGL(k_sorted_emit, dim3(grid_for(q.unit1 - q.unit0 + 15, 256)), dim3(256), 0, st, q);      // one 16-lane group per 16 units
+        size_t b = s->sort_tmp_bytes;
+        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp, b, s->key0, s->key1, s->val0, s->val1, (int)n, 0, end_bit, st));
+        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(m->V + 2, 256)), dim3(256), 0, st, s->key1, n, m->V, seg_a);
+        // phase A: target rows move (into the shadow table); (context, target | g) -> (key0, val0)
+        q.key_in = s->key1; q.val_in = s->val1; q.key_out = s->key0; q.val_out = s->val0; q.seg = seg_a;
+        launch_phase_any(dch, q, false, st);
+        // sorted by context row -> (key1, val1); phase B: context rows take their sums
+        b = s->sort_tmp_bytes;
+        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp, b, s->key0, s->key1, s->val0, s->val1, (int)n, 0, end_bit, st));
+        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(m->V + 2, 256)), dim3(256), 0, st, s->key1, n, m->V, seg_b);
+        q.seg = seg_b;
+        launch_phase_any(dch, q, true, st);            // reads the target rows as they stood BEFORE the mini-batch
+        launch_commit_any(dch, q, seg_a, st);
+    }
+    DGE_HIP(hipGetLastError());
+    return DGE_OK;
+}

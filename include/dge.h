@@ -123,6 +123,8 @@ int  dge_sample_walks_into(const dge_graph* g, dge_walks* w, int64_t row0, int64
                            int64_t first_index);
 int  dge_walks_from_host(int device, const int32_t* walks, int64_t n_walks, int32_t max_len, dge_walks** out);
 int  dge_walks_to_host(const dge_walks* w, int32_t* out, int64_t cap_elems);
+/* d_ptr: the corpus in device memory, READ-ONLY for the caller: a trainer keeps what it derived from a corpus the library has not
+ * written since (vocabulary rows, word offsets) */
 int  dge_walks_info(const dge_walks* w, int64_t* n_walks, int32_t* max_len, const int32_t** d_ptr);
 /* SpatialGraph's position prefix "j-name" (J/SpatialGraph.java:105-108): token j of each walk becomes
  * j*region_count + id, i.e. lands in layer j of the cross-time id space. */
@@ -150,8 +152,9 @@ typedef struct dge_train_config {
                                 0 = auto: 5 when the vocabulary has >= 262144 rows and its negative-sampling
                                     distribution is flat enough for lock attempts to succeed (expected failure
                                     rate < 0.25) and no single row is busy enough to serialise its pairs behind its lock
-                                    (workers x p_row <= 0.5); 7 when such rows exist or a head of at most V/8 rows carries the
-                                    skew; else 2;
+                                    (workers x p_row <= 0.5); otherwise (a skewed vocabulary, a small one, a block of a schedule of
+                                    >= 4 ranks) 8 when the tables are below 4 GiB and there are >= 32768 live rows; else 7 / 2 as
+                                    before (a head of at most V/8 rows carries the skew / everything by atomics);
                                 1 = agent-scope row read-modify-write, write-through (last writer of a row wins);
                                 2 = agent-scope loads + memory-side float atomics (no update is lost);
                                 3 = plain cached accesses (debug only: every XCD trains a private stale copy);
@@ -162,7 +165,13 @@ typedef struct dge_train_config {
                                     is ever lost);
                                 7 = as 5, but the head of the vocabulary (the rows many workers want at once; how many
                                     is derived from the counts) stays out of the lock protocol and takes atomics as in 2.
-                                workers == 1 with policy 0/3 is the in-order schedule with plain accesses. */
+                                8 = owner-computes: every (context, target, label) term of a mini-batch becomes an item; items
+                                    sorted by target row are applied by the row's owner in order, then sorted by context row and
+                                    summed — no locks, no atomics, no lost update; the result is a deterministic function of the
+                                    batch whatever the worker count (bit-exact against the oracle at full concurrency).  Within a
+                                    mini-batch (~100 items per live row) the other table is read as it stood before the
+                                    mini-batch.  Tables below 4 GiB, no hierarchical softmax.
+                                workers == 1 with policy 0/3/8 is the in-order schedule with plain accesses. */
     int32_t use_hs;          /* .useHierarchicSoftmax(b): 0 = negative sampling only (the north-star path);
                                 1 = the hierarchical-softmax term as well, before the negatives of each pair — what
                                 DL4J's builder leaves on when J/DeepWalk.java:73-76 does not call it.  Huffman codes over
@@ -232,7 +241,7 @@ void dge_model_free(dge_model* m);
  * walks: the blocks of one episode are row-disjoint, after N episodes every pair was trained once.
  * After an episode a rank hands the syn1neg partition it trained to rank g-1, which trains it next (export -> point-to-point
  * transfer -> import: a ring); syn0 partitions never leave their rank until the final gather.  n_parts <= 1 switches the filter off.
- * Policies under a partition: 0 (auto), 2, 3, 5, and 7 = row locks on syn1neg only, the pair's syn0 row by atomics. */
+ * Policies under a partition: 0 (auto), 2, 3, 5, 8, and 7 = row locks on syn1neg only, the pair's syn0 row by atomics. */
 int  dge_model_set_partition(dge_model* m, int32_t n_parts, int32_t ctx_part, int32_t tgt_part);
 /* floats of one packed partition buffer: ceil(V / n_parts) rows x row stride (same for every partition) */
 int  dge_model_partition_floats(const dge_model* m, int32_t n_parts, int64_t* n_floats);
@@ -285,7 +294,9 @@ enum {
     DGE_TUNE_HS_DRAIN = 1,        /* hierarchical softmax: additions between drains of an LDS accumulator (default 64) */
     DGE_TUNE_FORCE_SEGMENTS = 2,  /* > 0: address the tables through per-segment descriptors as tables of >= 4 GiB are (parity tests) */
     DGE_TUNE_SEGMENT_SHIFT = 3,   /* rows per descriptor segment = 2^value (with FORCE_SEGMENTS: many segments on a small table) */
-    DGE_TUNE_COUNT = 4
+    DGE_TUNE_SORTED_CHUNK = 4,    /* update_policy 8: items per work unit (default 256); a row's item list longer than what is left of a unit is split */
+    DGE_TUNE_SORTED_WALKS = 5,    /* update_policy 8: walks per synchronous mini-batch (default: as many as the item buffers hold) */
+    DGE_TUNE_COUNT = 6
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
 

@@ -505,6 +505,27 @@ static inline float dot_lane16(const float* a, const float* b, int D) {
     return p[0];
 }
 
+/* lane order of the kernels that move rows as 16 bytes per lane (k_sgns_train_locked, k_sorted_phase): lane j owns elements
+ * {64c + 4j + e : e = 0..3} of chunk c */
+static inline float dot_lane16A(const float* a, const float* b, int D) {
+    float p[16];
+    for (int j = 0; j < 16; j++) {
+        float acc = 0.0f;
+        for (int c = 0; c * 64 < D; c++)
+            for (int e = 0; e < 4; e++) {
+                int idx = c * 64 + 4 * j + e;
+                if (idx < D) acc = fmaf(a[idx], b[idx], acc);
+            }
+        p[j] = acc;
+    }
+    for (int s = 1; s < 16; s <<= 1) {
+        float q[16];
+        for (int j = 0; j < 16; j++) q[j] = p[j] + p[j ^ s];
+        memcpy(p, q, sizeof(p));
+    }
+    return p[0];
+}
+
 static inline float alpha_for(const orc_train_config* cfg, int64_t words_done, int64_t total_words_all) {
     /* word2vec.c: alpha = starting_alpha * (1 - word_count_actual / (iter*train_words + 1)), floored.
      * DL4J floors at minLearningRate (absolute). Evaluated per walk from the exact count of in-vocab
@@ -644,6 +665,140 @@ static int64_t train_walk(const orc_train_config* cfg, orc_model* m, const int32
     return pairs;
 }
 
+/* ---- update_policy 8: the owner-computes schedule (embedding_amd/csrc/sgns_sorted.hip), one block over walks [0, n_walks) ---- */
+typedef struct { int32_t key, other; float x; } so_item;      /* key = owning row, other = the row of the other table, x = signed alpha / g */
+
+static void so_stable_sort(const so_item* in, so_item* out, int64_t n, int64_t V, int64_t* seg /* [V+1] */) {
+    for (int64_t r = 0; r <= V; r++) seg[r] = 0;
+    for (int64_t i = 0; i < n; i++) seg[in[i].key + 1]++;
+    for (int64_t r = 0; r < V; r++) seg[r + 1] += seg[r];
+    int64_t* fill = (int64_t*)malloc((size_t)(V + 1) * sizeof(int64_t));
+    memcpy(fill, seg, (size_t)(V + 1) * sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++) out[fill[in[i].key]++] = in[i];
+    free(fill);
+}
+
+/* one phase over sorted items: own = the table whose rows are owned (phase A: syn1neg, phase B: syn0), oth = the other one */
+static void so_phase(const orc_train_config* cfg, int phase_b, float* own, float* own_out, const float* oth, so_item* it, int64_t n, const int64_t* seg, int D) {
+    const int64_t C = cfg->sorted_chunk;
+    const int64_t n_chunks = (n + C - 1) / C;
+    float* scratch = (float*)calloc((size_t)(2 * n_chunks + 2) * D, sizeof(float));
+    float* h = (float*)malloc((size_t)D * sizeof(float)); float* d = (float*)malloc((size_t)D * sizeof(float));
+    for (int64_t c = 0; c < n_chunks; c++) {
+        const int64_t start = c * C, stop = start + C < n ? start + C : n;
+        int64_t s0 = start;
+        while (s0 < stop) {
+            const int32_t row = it[s0].key;
+            int64_t s1 = s0;
+            while (s1 < stop && it[s1].key == row) s1++;
+            float* r = own + (int64_t)row * D;
+            for (int k = 0; k < D; k++) { h[k] = r[k]; d[k] = 0.0f; }
+            for (int64_t i = s0; i < s1; i++) {
+                const float* o = oth + (int64_t)it[i].other * D;
+                if (phase_b) {
+                    for (int k = 0; k < D; k++) d[k] = fmaf(it[i].x, o[k], d[k]);
+                } else {
+                    const float a = fabsf(it[i].x), label = signbit(it[i].x) ? 0.0f : 1.0f;
+                    const float f = dot_lane16A(h, o, D);
+                    float g;
+                    if (f > MAX_EXP) g = (label - 1) * a;
+                    else if (f < -MAX_EXP) g = (label - 0) * a;
+                    else {
+                        int idx = (int)((f + MAX_EXP) * (EXP_TABLE_SIZE / MAX_EXP / 2));
+                        if (idx < 0) idx = 0;
+                        if (idx > EXP_TABLE_SIZE - 1) idx = EXP_TABLE_SIZE - 1;
+                        g = (label - g_exp_table[idx]) * a;
+                    }
+                    for (int k = 0; k < D; k++) { h[k] = fmaf(g, o[k], h[k]); d[k] = fmaf(g, o[k], d[k]); }
+                    it[i].x = g;                                   /* kept for phase B */
+                }
+            }
+            const int whole = s0 == seg[row] && s1 == seg[row + 1];
+            if (whole) { float* ro = own_out + (int64_t)row * D; for (int k = 0; k < D; k++) ro[k] = phase_b ? r[k] + d[k] : h[k]; }
+            else memcpy(scratch + (2 * c + (s0 == start ? 0 : 1)) * D, d, (size_t)D * sizeof(float));
+            s0 = s1;
+        }
+    }
+    /* rows shared by several chunks: deltas added in chunk order to the row as it stood before the phase */
+    for (int64_t c = 0; c < n_chunks; c++) {
+        const int64_t start = c * C, end = start + C < n ? start + C : n;
+        const int32_t row = it[end - 1].key;
+        const int64_t r0 = seg[row], r1 = seg[row + 1];
+        if (r1 <= end || r0 < start) continue;
+        const float* r = own + (int64_t)row * D; float* ro = own_out + (int64_t)row * D;
+        for (int k = 0; k < D; k++) h[k] = r[k];
+        for (int64_t cc = c; cc <= (r1 - 1) / C; cc++) {
+            const float* dd = scratch + (2 * cc + (r0 <= cc * C ? 0 : 1)) * D;
+            for (int k = 0; k < D; k++) h[k] += dd[k];
+        }
+        for (int k = 0; k < D; k++) ro[k] = h[k];
+    }
+    free(scratch); free(h); free(d);
+}
+
+static int64_t train_block_sorted(const orc_train_config* cfg, orc_model* m, const int32_t* sen, const int64_t* wb, int64_t n_walks,
+                                  int32_t max_len, int ep, int64_t total_walks, int64_t all_words, int part_ctx, int part_tgt) {
+    const int D = cfg->dim, W = cfg->window, K = cfg->negative;
+    const int64_t V = m->V, T = m->table_size;
+    const int PN = cfg->part_n > 1 ? cfg->part_n : 1;
+    const int64_t per = cfg->sorted_walks > 0 ? cfg->sorted_walks : n_walks;
+    int64_t pairs = 0;
+    int64_t* seg = (int64_t*)malloc((size_t)(V + 2) * sizeof(int64_t));
+    for (int64_t w0 = 0; w0 < n_walks; w0 += per) {
+        const int64_t w1 = w0 + per < n_walks ? w0 + per : n_walks;
+        int64_t cap = 1024, n = 0;
+        so_item* a = (so_item*)malloc((size_t)cap * sizeof(so_item));
+        for (int64_t w = w0; w < w1; w++) {
+            int32_t buf[4096]; int len = 0;
+            for (int j = 0; j < max_len && len < 4096; j++) { int32_t r = sen[w * max_len + j]; if (r >= 0) buf[len++] = r; }
+            const float alpha = alpha_for(cfg, (int64_t)ep * m->total_words + cfg->words_before + wb[w], all_words);
+            const int64_t gbase = (((int64_t)ep * total_walks) + cfg->walk_index_base + w) * (int64_t)max_len;
+            for (int i = 0; i < len; i++) {
+                const int32_t word = buf[i];
+                if (PN > 1 && word % PN != part_tgt) continue;
+                uint64_t s = orc_mix64(cfg->seed + (uint64_t)(gbase + i));
+                s = s * W2V_MULT + 11;
+                const int b = (int)(s % (uint64_t)W);
+                const uint64_t s_centre = s;
+                for (int aa = b; aa < W * 2 + 1 - b; aa++) {
+                    if (aa == W) continue;
+                    const int c = i - W + aa;
+                    if (c < 0 || c >= len) continue;
+                    const int32_t last = buf[c];
+                    if (PN > 1) { if (last % PN != part_ctx) continue; s = orc_mix64(s_centre + (uint64_t)c); }
+                    if (n + K + 1 > cap) { cap = cap * 2 + K + 1; a = (so_item*)realloc(a, (size_t)cap * sizeof(so_item)); }
+                    a[n].key = word; a[n].other = last; a[n].x = alpha; n++;
+                    for (int dd = 0; dd < K; dd++) {
+                        s = s * W2V_MULT + 11;
+                        int64_t target = m->table[(s >> 16) % (uint64_t)T];
+                        if (target == 0 && V > 1) target = (int64_t)(s % (uint64_t)(V - 1)) + 1;
+                        if (PN > 1) { target = target / PN * PN + part_tgt; if (target >= V) target -= PN; }
+                        if (target == word) continue;
+                        a[n].key = (int32_t)target; a[n].other = last; a[n].x = -alpha; n++;
+                    }
+                    pairs++;
+                }
+            }
+        }
+        if (n > 0) {
+            so_item* b2 = (so_item*)malloc((size_t)n * sizeof(so_item));
+            so_stable_sort(a, b2, n, V, seg);                                    /* by target row */
+            /* phase A leaves the moved target rows in a shadow table: phase B reads the rows as they stood before the mini-batch */
+            float* shadow = (float*)malloc((size_t)(V * D + 1) * sizeof(float));
+            memcpy(shadow, m->syn1neg, (size_t)(V * D) * sizeof(float));
+            so_phase(cfg, 0, m->syn1neg, shadow, m->syn0, b2, n, seg, D);
+            for (int64_t i = 0; i < n; i++) { int32_t t = b2[i].key; b2[i].key = b2[i].other; b2[i].other = t; }     /* (context, target, g) in phase-A order */
+            so_stable_sort(b2, a, n, V, seg);                                    /* by context row */
+            so_phase(cfg, 1, m->syn0, m->syn0, m->syn1neg, a, n, seg, D);
+            memcpy(m->syn1neg, shadow, (size_t)(V * D) * sizeof(float));         /* commit */
+            free(shadow); free(b2);
+        }
+        free(a);
+    }
+    free(seg);
+    return pairs;
+}
+
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 int orc_train_sgns(const int32_t* walks, int64_t n_walks, int32_t max_len,
@@ -738,6 +893,10 @@ int orc_train_sgns(const int32_t* walks, int64_t n_walks, int32_t max_len,
     for (int ep = 0; ep < cfg->epochs; ep++)
     for (int blk = 0; blk < PN * PN; blk++) {
         const int part_ctx = blk % PN, part_tgt = (blk % PN + blk / PN) % PN;     /* episode blk / PN, rank blk % PN */
+        if (cfg->sorted_chunk > 0) {
+            pairs += train_block_sorted(cfg, m, sen, wb, n_walks, max_len, ep, total_walks, all_words, part_ctx, part_tgt);
+            continue;
+        }
         int nt = cfg->threads > 1 ? cfg->threads : 1;
 #ifdef _OPENMP
 #pragma omp parallel num_threads(nt) reduction(+ : pairs)

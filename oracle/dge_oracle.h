@@ -83,6 +83,13 @@ typedef struct orc_train_config {
     int32_t part_n;          /* > 1: the multi-GPU block schedule (include/dge.h, dge_model_set_partition) run sequentially —
                                 per epoch, episodes e = 0..N-1, ranks g = 0..N-1: the block (contexts in partition g,
                                 centres and negatives in partition (g+e) % N) over all walks */
+    int32_t sorted_chunk;    /* > 0: the OWNER-COMPUTES schedule of update_policy 8 (embedding_amd/csrc/sgns_sorted.hip) restated
+                                sequentially: per mini-batch every (context, target, label) term becomes an item; items sorted by target
+                                row, a row's items applied in order by chunks of sorted_chunk items (a row that straddles chunk
+                                borders: independent segments from the same starting row, deltas added in chunk order), the step g
+                                of every item kept; items sorted by context row, every context row takes the sum of g * target row.
+                                Lane order of the 16-byte-per-lane row layout.  Deterministic whatever the worker count. */
+    int32_t sorted_walks;    /* walks per synchronous mini-batch (0 = all walks of the launch) */
 } orc_train_config;
 
 typedef struct orc_model orc_model;

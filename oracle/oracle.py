@@ -28,6 +28,7 @@ class TrainConfig(C.Structure):
         ("seed", C.c_uint64), ("table_size", C.c_int64), ("arith", C.c_int32), ("n_vertices", C.c_int32),
         ("walk_index_base", C.c_int64), ("total_walks", C.c_int64), ("total_words", C.c_int64),
         ("words_before", C.c_int64), ("use_hs", C.c_int32), ("part_n", C.c_int32),
+        ("sorted_chunk", C.c_int32), ("sorted_walks", C.c_int32),
     ]
 
 
@@ -237,11 +238,12 @@ class Model:
 
 def train_sgns(walks, n_vertices, dim, window, negative=5, min_count=2, epochs=1, threads=1, alpha=0.025,
                min_alpha=1e-4, seed=1, table_size=100_000_000, arith=0, walk_index_base=0, total_walks=0,
-               total_words=0, words_before=0, use_hs=False, part_n=0):
+               total_words=0, words_before=0, use_hs=False, part_n=0, sorted_chunk=0, sorted_walks=0):
     walks = np.ascontiguousarray(walks, np.int32)
     n, L = walks.shape
     cfg = TrainConfig(dim, window, negative, min_count, epochs, threads, alpha, min_alpha, seed, table_size,
-                      arith, n_vertices, walk_index_base, total_walks, total_words, words_before, int(bool(use_hs)), int(part_n))
+                      arith, n_vertices, walk_index_base, total_walks, total_words, words_before, int(bool(use_hs)), int(part_n),
+                      int(sorted_chunk), int(sorted_walks))
     h = C.c_void_p(0)
     rc = lib().orc_train_sgns(_ptr(walks), n, L, C.byref(cfg), C.byref(h))
     if rc != 0:

@@ -107,8 +107,9 @@ def test_cfg5_shaped_graph_and_one_worker_mixed_policy(cfg5_small, dge, oracle):
 
 def test_cfg5_shaped_auto_schedule_resolves_to_the_mixed_policy(dge):
     """configs[4] at 1/10 (1 M vertices, 100 M edges, 1 M walks, D = 256, K = 20): `update_policy = 0` must pick the mixed policy 7
-    THROUGH THE AUTO RULE (skewed vocabulary of >= 262 144 rows, head derived from the counts), train exactly the pairs that the
-    lossless atomics schedule (policy 2) trains, stay finite, and predict held-out walk steps as well as policy 2 does."""
+    THROUGH THE AUTO RULE (skewed vocabulary of >= 262 144 rows, head derived from the counts; the owner-computes schedule is not
+    for skewed vocabularies), train exactly the pairs that the lossless atomics schedule (policy 2) trains, stay finite, and predict
+    held-out walk steps as well as policy 2 does."""
     import torch
     from embedding_amd import synth
     R, T, L, D, K = 41666, 24, 24, 256, 20
@@ -135,3 +136,30 @@ def test_cfg5_shaped_auto_schedule_resolves_to_the_mixed_policy(dge):
     assert res[0]["pairs"] == res[2]["pairs"] > 3.0e8
     assert res[0]["auc"] > res[2]["auc"] - 0.01 and res[2]["auc"] > 0.6, res
     assert res[0]["rate"] > res[2]["rate"], res                         # and the auto choice is the faster one
+
+
+def test_cfg2_shaped_auto_schedule_resolves_to_owner_computes(dge):
+    """configs[1] (100 k vertices, 5 M edges, static, D = 64, K = 5, L = W = 8): a flat vocabulary too small for row locks — auto must
+    resolve to the owner-computes schedule (8), train the pairs the atomics schedule (2) trains, and predict held-out steps as well."""
+    import torch
+    from embedding_amd import synth
+    R, L, D, K = 100_000, 8, 64, 5
+    G = synth.flow_graph_torch(R, 1, 50, "cuda:0")
+    g = dge.DeviceGraph(0); g.add_edges_device(G["src"], G["dst"], G["w"]); g.set_sources(np.arange(R, dtype=np.int32)); del G
+    g.build_alias(False)
+    corpus = g.sample_walks_device(1_000_000, L, seed=5)
+    counts = torch.zeros(R, dtype=torch.int64, device="cuda:0"); corpus.count_tokens(R, counts)
+    test = g.sample_walks(50_000, L, seed=99, rng_mode=1)
+    res = {}
+    for pol in (0, 2):
+        m = dge.SgnsModel.create(dge.make_config(D, L, R, negative=K, workers=0, update_policy=pol, epochs=1, seed=1), counts, 0)
+        for b in range(10):                                               # ten launches of 100 k walks, as bench.py steps through an epoch
+            m.train(corpus, b * 100_000, 100_000, walk_index_base=b * 100_000, total_walks=1_000_000)
+        st, sch = m.stats(), m.schedule()
+        s0, vid = m.vectors(); s1 = m.syn1neg()
+        assert np.isfinite(s0).all() and np.isfinite(s1).all()
+        res[pol] = dict(pairs=st["pairs"], sch=sch, auc=link_auc(s0, s1, vid, test, R), rate=st["pairs"] / (st["kernel_ms"] * 1e-3))
+        m.close()
+    assert res[0]["sch"]["update_policy"] == 8 and res[2]["sch"]["update_policy"] == 2, res
+    assert res[0]["pairs"] == res[2]["pairs"] > 4.0e7
+    assert res[0]["auc"] > res[2]["auc"] - 0.01, res
