@@ -1,6 +1,6 @@
 """Digest rocprofv3 --pmc passes (…_counter_collection.csv + …_kernel_trace.csv) into one small table per kernel of interest:
 pass, dispatch, kernel, counter, value (summed over the rows rocprofv3 emits per dispatch), grid, workgroup, duration.
-Usage: python scripts/pmc_digest.py <dir> <kernel-substring> > profiles/<name>.csv"""
+Usage: python scripts/pmc_digest.py <dir> <kernel-substring>[|<substring>...] > profiles/<name>.csv"""
 import csv, glob, os, sys
 
 d, needle = sys.argv[1], sys.argv[2]
@@ -14,7 +14,7 @@ for cc in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
             dur[r.get("Dispatch_Id")] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     acc = {}
     for r in csv.DictReader(open(cc)):
-        if needle not in r["Kernel_Name"]:
+        if not any(nd in r["Kernel_Name"] for nd in needle.split("|")):
             continue
         key = (r["Dispatch_Id"], r["Kernel_Name"], r["Counter_Name"], r["Grid_Size"], r["Workgroup_Size"])
         acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"])
