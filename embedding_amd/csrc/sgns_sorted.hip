@@ -35,11 +35,17 @@ struct dge_sorted_work {
     int64_t cap_units = 0;                       // (walk, centre) units the count buffers hold
     int32_t* cnt = nullptr; int64_t* off = nullptr;
     void* scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
-    int64_t cap_items = 0;                       // item slots of the two buffer pairs
-    int32_t *key0 = nullptr, *key1 = nullptr;
-    uint64_t *val0 = nullptr, *val1 = nullptr;
-    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
-    int64_t* seg = nullptr; int64_t cap_seg = 0; // first sorted position of every row (+ end): [0, V+2) by target, [V+2, 2V+4) by context
+    // Two buffer sets: while mini-batch k runs its phases on the model's stream (bound by the caches), mini-batch k+1 is emitted and
+    // sorted by target row on a second stream (bound by table look-up latency and by HBM): set k % 2 holds (key0, val0) = emitted items,
+    // later phase A's output; (key1, val1) = the sorted items of whichever phase runs
+    int64_t cap_items = 0;                       // item slots of every array
+    int32_t *key0[2] = {nullptr, nullptr}, *key1[2] = {nullptr, nullptr};
+    uint64_t *val0[2] = {nullptr, nullptr}, *val1[2] = {nullptr, nullptr};
+    void* sort_tmp[2] = {nullptr, nullptr}; size_t sort_tmp_bytes = 0;        // [0]: second stream (sort by target), [1]: model's stream (sort by context)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool set_used[2] = {false, false};
+    int64_t* seg = nullptr; int64_t cap_seg = 0; // first sorted position of every row (+ end): by target for set 0, set 1; by context
     float* shadow = nullptr; int64_t cap_shadow = 0;   // the target rows as phase A leaves them, committed after phase B
     float* scratch = nullptr; int64_t cap_scratch_rows = 0;
     int64_t* d_marks = nullptr; int64_t cap_marks = 0;
@@ -48,8 +54,13 @@ struct dge_sorted_work {
 void dge_sorted_release(dge_model* m) {
     dge_sorted_work* s = m->sorted;
     if (!s) return;
-    dge_dev_free(s->cnt); dge_dev_free(s->off); dge_dev_free(s->scan_tmp); dge_dev_free(s->key0); dge_dev_free(s->key1);
-    dge_dev_free(s->val0); dge_dev_free(s->val1); dge_dev_free(s->sort_tmp); dge_dev_free(s->seg); dge_dev_free(s->scratch); dge_dev_free(s->d_marks); dge_dev_free(s->shadow);
+    if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
+    for (int x = 0; x < 2; x++) {
+        dge_dev_free(s->key0[x]); dge_dev_free(s->key1[x]); dge_dev_free(s->val0[x]); dge_dev_free(s->val1[x]); dge_dev_free(s->sort_tmp[x]);
+        if (s->ev_ready[x]) (void)hipEventDestroy(s->ev_ready[x]);
+        if (s->ev_done[x]) (void)hipEventDestroy(s->ev_done[x]);
+    }
+    dge_dev_free(s->cnt); dge_dev_free(s->off); dge_dev_free(s->scan_tmp); dge_dev_free(s->seg); dge_dev_free(s->scratch); dge_dev_free(s->d_marks); dge_dev_free(s->shadow);
     delete s;
     m->sorted = nullptr;
 }
@@ -500,26 +511,40 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     int64_t max_slots = 0;
     for (int64_t k = 0; k < n_sub; k++) max_slots = std::max(max_slots, (h_off[(size_t)k + 1] - h_off[(size_t)k]) * K1);
     if (max_slots >= 0x7fffffffll) DGE_FAIL(DGE_ERR_ARG, "update_policy 8: a mini-batch of %lld items; set fewer walks per mini-batch", (long long)max_slots);
-    int chunk = 256;
+    int chunk = 128;                     // (64 .. 256 measure alike; 512 and up lose: fewer work units than the device holds)
     if (g_dge_tuning[DGE_TUNE_SORTED_CHUNK] > 0) chunk = (int)std::min<int64_t>(g_dge_tuning[DGE_TUNE_SORTED_CHUNK], 1 << 20);
     int end_bit = 1;
     while (end_bit < 31 && (1ll << end_bit) <= (int64_t)m->V) end_bit++;      // keys are 0 .. V (V = a skipped draw)
+    if (!s->aux) {
+        DGE_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+        for (int x = 0; x < 2; x++) {
+            DGE_HIP(hipEventCreateWithFlags(&s->ev_ready[x], hipEventDisableTiming));
+            DGE_HIP(hipEventCreateWithFlags(&s->ev_done[x], hipEventDisableTiming));
+        }
+    }
     if (max_slots > s->cap_items) {
-        dge_dev_free(s->key0); dge_dev_free(s->key1); dge_dev_free(s->val0); dge_dev_free(s->val1); dge_dev_free(s->sort_tmp);
-        s->key0 = s->key1 = nullptr; s->val0 = s->val1 = nullptr; s->sort_tmp = nullptr; s->cap_items = 0;
+        DGE_HIP(hipStreamSynchronize(s->aux));
         const int64_t cap = max_slots + max_slots / 8 + 1024;
-        if ((rc = dge_dev_alloc(&s->key0, (size_t)cap))) return rc;
-        if ((rc = dge_dev_alloc(&s->key1, (size_t)cap))) return rc;
-        if ((rc = dge_dev_alloc(&s->val0, (size_t)cap))) return rc;
-        if ((rc = dge_dev_alloc(&s->val1, (size_t)cap))) return rc;
         size_t b = 0;
-        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b, s->key0, s->key1, s->val0, s->val1, (int)std::min<int64_t>(cap, 0x7fffffff), 0, 31, st));
-        DGE_HIP(hipMalloc(&s->sort_tmp, b ? b : 1)); s->sort_tmp_bytes = b;
+        for (int x = 0; x < 2; x++) {
+            dge_dev_free(s->key0[x]); dge_dev_free(s->key1[x]); dge_dev_free(s->val0[x]); dge_dev_free(s->val1[x]); dge_dev_free(s->sort_tmp[x]);
+            s->key0[x] = s->key1[x] = nullptr; s->val0[x] = s->val1[x] = nullptr; s->sort_tmp[x] = nullptr;
+        }
+        s->cap_items = 0; s->set_used[0] = s->set_used[1] = false;
+        for (int x = 0; x < 2; x++) {
+            if ((rc = dge_dev_alloc(&s->key0[x], (size_t)cap))) return rc;
+            if ((rc = dge_dev_alloc(&s->key1[x], (size_t)cap))) return rc;
+            if ((rc = dge_dev_alloc(&s->val0[x], (size_t)cap))) return rc;
+            if ((rc = dge_dev_alloc(&s->val1[x], (size_t)cap))) return rc;
+            DGE_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b, s->key0[x], s->key1[x], s->val0[x], s->val1[x], (int)std::min<int64_t>(cap, 0x7fffffff), 0, 31, st));
+            DGE_HIP(hipMalloc(&s->sort_tmp[x], b ? b : 1));
+        }
+        s->sort_tmp_bytes = b;
         s->cap_items = cap;
     }
     if (m->V + 2 > s->cap_seg) {
         dge_dev_free(s->seg); s->seg = nullptr;
-        if ((rc = dge_dev_alloc(&s->seg, 2 * ((size_t)m->V + 2)))) return rc;
+        if ((rc = dge_dev_alloc(&s->seg, 3 * ((size_t)m->V + 2)))) return rc;
         s->cap_seg = m->V + 2;
     }
     if (m->V > s->cap_shadow) {
@@ -537,28 +562,36 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
 
     SortedParams q;
     q.t = p; q.cnt = s->cnt; q.off = s->off; q.seg = s->seg; q.chunk = chunk; q.scratch = s->scratch; q.shadow = s->shadow;
-    int64_t* const seg_a = s->seg; int64_t* const seg_b = s->seg + m->V + 2;
+    int64_t* const seg_a[2] = {s->seg, s->seg + m->V + 2}; int64_t* const seg_b = s->seg + 2 * (m->V + 2);
     const int dch = m->stride / 64;
+    // (the offsets were read back above: everything the second stream reads — counts, offsets, walks, the unigram table — is in place)
+    int64_t live = 0;
     for (int64_t k = 0; k < n_sub; k++) {
         const int64_t n = (h_off[(size_t)k + 1] - h_off[(size_t)k]) * K1;
         if (n == 0) continue;
+        const int x = (int)(live++ & 1);
         q.unit0 = marks[(size_t)k]; q.unit1 = marks[(size_t)k + 1]; q.pair0 = h_off[(size_t)k]; q.n_slots = n;
-        // items -> (key0, val0); sorted by target row -> (key1, val1)
-        q.key_out = s->key0; q.val_out = s->val0;
-        hipLaunchKernelGGL(k_sorted_emit, dim3(grid_for(q.unit1 - q.unit0 + 15, 256)), dim3(256), 0, st, q);      // one 16-lane group per 16 units
+        // second stream: items -> (key0, val0); sorted by target row -> (key1, val1); row segments
+        if (s->set_used[x]) DGE_HIP(hipStreamWaitEvent(s->aux, s->ev_done[x], 0));         // the mini-batch that held this set has finished
+        q.key_out = s->key0[x]; q.val_out = s->val0[x];
+        hipLaunchKernelGGL(k_sorted_emit, dim3(grid_for(q.unit1 - q.unit0 + 15, 256)), dim3(256), 0, s->aux, q);      // one 16-lane group per 16 units
         size_t b = s->sort_tmp_bytes;
-        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp, b, s->key0, s->key1, s->val0, s->val1, (int)n, 0, end_bit, st));
-        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(m->V + 2, 256)), dim3(256), 0, st, s->key1, n, m->V, seg_a);
-        // phase A: target rows move (into the shadow table); (context, target | g) -> (key0, val0)
-        q.key_in = s->key1; q.val_in = s->val1; q.key_out = s->key0; q.val_out = s->val0; q.seg = seg_a;
+        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp[0], b, s->key0[x], s->key1[x], s->val0[x], s->val1[x], (int)n, 0, end_bit, s->aux));
+        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(m->V + 2, 256)), dim3(256), 0, s->aux, s->key1[x], n, m->V, seg_a[x]);
+        DGE_HIP(hipEventRecord(s->ev_ready[x], s->aux));
+        // model's stream — phase A: target rows move (into the shadow table); (context, target | g) -> (key0, val0)
+        DGE_HIP(hipStreamWaitEvent(st, s->ev_ready[x], 0));
+        q.key_in = s->key1[x]; q.val_in = s->val1[x]; q.key_out = s->key0[x]; q.val_out = s->val0[x]; q.seg = seg_a[x];
         launch_phase_any(dch, q, false, st);
         // sorted by context row -> (key1, val1); phase B: context rows take their sums
         b = s->sort_tmp_bytes;
-        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp, b, s->key0, s->key1, s->val0, s->val1, (int)n, 0, end_bit, st));
-        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(m->V + 2, 256)), dim3(256), 0, st, s->key1, n, m->V, seg_b);
+        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp[1], b, s->key0[x], s->key1[x], s->val0[x], s->val1[x], (int)n, 0, end_bit, st));
+        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(m->V + 2, 256)), dim3(256), 0, st, s->key1[x], n, m->V, seg_b);
         q.seg = seg_b;
         launch_phase_any(dch, q, true, st);            // reads the target rows as they stood BEFORE the mini-batch
-        launch_commit_any(dch, q, seg_a, st);
+        launch_commit_any(dch, q, seg_a[x], st);
+        DGE_HIP(hipEventRecord(s->ev_done[x], st));
+        s->set_used[x] = true;
     }
     DGE_HIP(hipGetLastError());
     return DGE_OK;

@@ -294,7 +294,7 @@ enum {
     DGE_TUNE_HS_DRAIN = 1,        /* hierarchical softmax: additions between drains of an LDS accumulator (default 64) */
     DGE_TUNE_FORCE_SEGMENTS = 2,  /* > 0: address the tables through per-segment descriptors as tables of >= 4 GiB are (parity tests) */
     DGE_TUNE_SEGMENT_SHIFT = 3,   /* rows per descriptor segment = 2^value (with FORCE_SEGMENTS: many segments on a small table) */
-    DGE_TUNE_SORTED_CHUNK = 4,    /* update_policy 8: items per work unit (default 256); a row's item list longer than what is left of a unit is split */
+    DGE_TUNE_SORTED_CHUNK = 4,    /* update_policy 8: items per work unit (default 128); a row's item list longer than what is left of a unit is split */
     DGE_TUNE_SORTED_WALKS = 5,    /* update_policy 8: walks per synchronous mini-batch (default: as many as the item buffers hold) */
     DGE_TUNE_COUNT = 6
 };
