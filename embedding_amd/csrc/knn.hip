@@ -3,13 +3,13 @@
 // scipy-cosine distance, NaN -> 2).  A "next" row of SURVEY.md §8f, not part of the training hot path; it serves as the
 // statistical parity check between training schedules at sizes where the Python loop (O(n^2) scipy calls) is hopeless.
 //
-// One workgroup = 64 query rows.  The strip of similarities S[64 x n] = Xq . X^T is produced tile by tile (64 columns)
-// with the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (4 waves = 2x2 sub-tiles of 32x32; the query fragment of
-// a wave stays in registers for the whole strip, the column tile is staged in LDS), and is consumed immediately: all 256
-// threads test the tile's 64 x 64 similarities against each row's current k-th best (a threshold that only tightens, so
-// nothing that belongs in the list is missed), and one lane per query row then inserts the few columns that passed, in
-// column order, into that row's k best (distance ascending, index ascending among equals) in LDS.
-// Nothing of size n^2 ever reaches HBM.
+// One workgroup = 128 query rows (4 waves x 32 rows, the query fragments stay in registers for the whole strip).  The strip of
+// similarities S[128 x n] = Xq . X^T is produced 64 columns at a time with the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32
+// (a wave: its 32 rows x the tile's 2 x 32 columns, two accumulators); the column tile comes from LDS, the NEXT tile's 16-byte global
+// loads are issued before the matrix loop and land in LDS after it.  The similarities never leave the accumulator registers: every
+// lane tests its 32 values against the current k-th best of their rows (a threshold that only tightens, so nothing that belongs in
+// a list is missed) and the few that pass are inserted into the row's k best in LDS under a per-row lock, ordered by (distance,
+// index) — the order of insertion does not matter.  Nothing of size n^2 ever reaches HBM.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -29,94 +29,156 @@ __global__ void k_row_norms(const float* __restrict__ x, int n, int D, float* __
     inv_norm[r] = s > 0.0 ? (float)(1.0 / sqrt(s)) : 0.0f;       // 0 marks a zero vector: cosine undefined -> distance 2
 }
 
+// rows scaled to unit norm and zero-padded to Dp floats (a zero vector stays zero: inv_norm 0 marks it)
+__global__ void k_normalise(const float* __restrict__ x, const float* __restrict__ inv_norm, int n, int D, int Dp, float* __restrict__ xn) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * Dp) return;
+    const int r = (int)(i / Dp), c = (int)(i % Dp);
+    xn[i] = c < D ? x[(size_t)r * D + c] * inv_norm[r] : 0.0f;
+}
+
+// (d, col) < (d2, col2): distance ascending, smaller index first among equals
+__device__ __forceinline__ bool knn_less(float d, int col, float d2, int col2) { return d < d2 || (d == d2 && (unsigned)col < (unsigned)col2); }
+
 template <int DH>   // DH = D_padded / 2 = MFMA steps per tile
-__global__ void __launch_bounds__(256)
-k_knn_strip(const float* __restrict__ x, const float* __restrict__ inv_norm, int n, int D, int k, int32_t* __restrict__ out_idx,
+__global__ void __launch_bounds__(256, 2)
+k_knn_strip(const float* __restrict__ xn, const float* __restrict__ inv_norm, int n, int k, int32_t* __restrict__ out_idx,
             float* __restrict__ out_dist) {
     extern __shared__ float lds[];
-    const int Dp = DH * 2;
-    float* Bs = lds;                              // [64][Dp + 1]   column tile, row-major per column vector
-    float* Ss = Bs + 64 * (Dp + 1);               // [64][65]       similarities of the tile
-    float* Ld = Ss + 64 * 65;                     // [64][k]        running best distances (pitch k: two workgroups fit a CU and overlap their phases)
-    int32_t* Li = (int32_t*)(Ld + 64 * k);        // [64][k]        their indices
-    uint32_t* Ms = (uint32_t*)(Li + 64 * k);      // [64][4]     per row and 16-column quarter: columns that beat the row's threshold
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-    const int q0 = blockIdx.x * 64;
+    constexpr int Dp = DH * 2;
+    constexpr int NPF = Dp / 16;                  // float4 loads per thread and tile: 64 columns x Dp floats / 256 threads
+    float* Bs = lds;                              // [64][Dp + 1]   column tile (odd pitch: conflict-free fragment reads)
+    float* Ld = Bs + 64 * (Dp + 1);               // [128][k]       running best distances
+    int32_t* Li = (int32_t*)(Ld + 128 * k);       // [128][k]       their indices (-1: empty, sorts last)
+    int* Lk = (int*)(Li + 128 * k);               // [128]          per-row locks
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int q0 = blockIdx.x * 128;
+    const int cb = 0, ce = n;
 
-    // query fragment: lane holds A[row = lane%32][kk = 2*j + lane/32] for j = 0..DH-1, scaled to unit norm
+    // query fragment: lane holds A[row = lane%32][kk = 2*j + lane/32] for j = 0..DH-1
     float a[DH];
     {
-        const int row = q0 + wr * 32 + (lane & 31);
-        const float sc = row < n ? inv_norm[row] : 0.0f;
+        const int row = q0 + wave * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < DH; j++) a[j] = row < n ? xn[(size_t)row * Dp + 2 * j + (lane >> 5)] : 0.0f;
+    }
+    for (int i = t; i < 128 * k; i += 256) { Ld[i] = 3.0f; Li[i] = -1; }     // 3 > any cosine distance
+    if (t < 128) Lk[t] = 0;
+
+    float4 pf[NPF];
+    auto fetch = [&](int c0) {                    // tile c0 .. c0+63: thread takes float4 number t + 256*i
+#pragma unroll
+        for (int i = 0; i < NPF; i++) {
+            const int f = t + 256 * i, c = f / (Dp / 4), kq = f % (Dp / 4), col = c0 + c;
+            pf[i] = col < ce ? *(const float4*)(xn + (size_t)col * Dp + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPF; i++) {
+            const int f = t + 256 * i, c = f / (Dp / 4), kq = f % (Dp / 4);
+            float* d = Bs + c * (Dp + 1) + 4 * kq;
+            d[0] = pf[i].x; d[1] = pf[i].y; d[2] = pf[i].z; d[3] = pf[i].w;
+        }
+    };
+    fetch(cb);
+    __syncthreads();
+    stash();
+    __syncthreads();
+
+    for (int c0 = cb; c0 < ce; c0 += 64) {
+        if (c0 + 64 < ce) fetch(c0 + 64);                         // in flight during the matrix loop
+        v16f acc0 = {0}, acc1 = {0};
+        const float* b0 = Bs + (lane & 31) * (Dp + 1) + (lane >> 5);
+        const float* b1 = b0 + 32 * (Dp + 1);
 #pragma unroll
         for (int j = 0; j < DH; j++) {
-            const int kk = 2 * j + (lane >> 5);
-            a[j] = (row < n && kk < D) ? x[(size_t)row * D + kk] * sc : 0.0f;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[2 * j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[2 * j], acc1, 0, 0, 0);
+            if ((j & 7) == 7) asm volatile("" ::: "memory");      // keeps the scheduler from hoisting all 2*DH fragment reads at once (spills)
         }
-    }
-    for (int i = t; i < 64 * k; i += 256) { Ld[i] = 3.0f; Li[i] = -1; }     // 3 > any cosine distance
-
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        __syncthreads();                                          // previous tile fully consumed
-        for (int i = t; i < 64 * Dp; i += 256) {                   // stage the normalised column vectors
-            const int c = i / Dp, kk = i - c * Dp, col = c0 + c;
-            Bs[c * (Dp + 1) + kk] = (col < n && kk < D) ? x[(size_t)col * D + kk] * inv_norm[col] : 0.0f;
+        // accumulator register v of a lane is S[8*(v/4) + 4*(lane/32) + v%4][lane%32] of the 32x32 sub-tile.
+        // Common path: 32 compares against the rows' k-th best -> a bit mask (bit 2v + sub); nothing else is touched.
+        uint32_t hits = 0;
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const int rl = wave * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), q = q0 + rl;
+            const float thr_d = Ld[rl * k + k - 1]; const int thr_i = Li[rl * k + k - 1];
+            const int c_lo = c0 + (lane & 31), c_hi = c_lo + 32;
+            if (q < n && c_lo < ce && c_lo != q && knn_less(1.0f - acc0[v], c_lo, thr_d, thr_i)) hits |= 1u << (2 * v);
+            if (q < n && c_hi < ce && c_hi != q && knn_less(1.0f - acc1[v], c_hi, thr_d, thr_i)) hits |= 2u << (2 * v);
         }
-        __syncthreads();
-        v16f acc = {0};
-        const float* bcol = Bs + (wc * 32 + (lane & 31)) * (Dp + 1) + (lane >> 5);
+        // Rare path (after the lists have warmed up: a handful per tile): one candidate per lane and trip, inserted under its row's lock
+        while (__any(hits != 0)) {
+            bool pending = hits != 0;
+            const int bit = pending ? __builtin_ctz(hits) : 0;
+            hits &= hits - 1;
+            const int v = bit >> 1, sub = bit & 1;
+            float sv = 0.f;
 #pragma unroll
-        for (int j = 0; j < DH; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bcol[2 * j], acc, 0, 0, 0);
-        // accumulator register v of a lane is S[8*(v/4) + 4*(lane/32) + v%4][lane%32] of the wave's 32x32 sub-tile
-#pragma unroll
-        for (int v = 0; v < 16; v++)
-            Ss[(wr * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3)) * 65 + wc * 32 + (lane & 31)] = acc[v];
-        __syncthreads();
-        {   // filter: thread (row r, quarter qd) tests 16 columns against the row's k-th best as it stands before this tile
-            const int r = t & 63, qd = t >> 6, q = q0 + r;
-            uint32_t m = 0;
-            if (q < n) {
-                const bool qzero = inv_norm[q] == 0.0f;
-                const float thr = Ld[r * k + k - 1];
-                for (int cc = 0; cc < 16; cc++) {
-                    const int c = qd * 16 + cc, col = c0 + c;
-                    if (col >= n || col == q) continue;
-                    const float d = (qzero || inv_norm[col] == 0.0f) ? 2.0f : 1.0f - Ss[r * 65 + c];
-                    if (d < thr) m |= 1u << cc;
+            for (int x = 0; x < 16; x++) if (x == v) sv = sub ? acc1[x] : acc0[x];
+            const int rl = wave * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), q = q0 + rl;
+            const int col = c0 + sub * 32 + (lane & 31);
+            float d = 1.0f - sv;
+            if (pending && (inv_norm[q] == 0.0f || inv_norm[col] == 0.0f)) d = 2.0f;      // cosine undefined -> distance 2
+            while (__any(pending)) {
+                if (pending && atomicCAS(&Lk[rl], 0, 1) == 0) {
+                    float* ld = Ld + rl * k; int32_t* li = Li + rl * k;
+                    if (knn_less(d, col, ld[k - 1], li[k - 1])) {
+                        int pos = k - 1;
+                        while (pos > 0 && knn_less(d, col, ld[pos - 1], li[pos - 1])) { ld[pos] = ld[pos - 1]; li[pos] = li[pos - 1]; pos--; }
+                        ld[pos] = d; li[pos] = col;
+                    }
+                    __threadfence_block();
+                    atomicExch(&Lk[rl], 0);
+                    pending = false;
                 }
             }
-            Ms[r * 4 + qd] = m;
         }
+        __syncthreads();                                          // every wave has finished with this tile
+        if (c0 + 64 < ce) stash();
         __syncthreads();
-        if (t < 64 && q0 + t < n) {                               // one lane per query row inserts what passed, in column order
-            const int q = q0 + t;
-            const bool qzero = inv_norm[q] == 0.0f;
-            float* ld = Ld + t * k; int32_t* li = Li + t * k;
-            uint64_t mask = (uint64_t)Ms[t * 4] | ((uint64_t)Ms[t * 4 + 1] << 16) | ((uint64_t)Ms[t * 4 + 2] << 32) | ((uint64_t)Ms[t * 4 + 3] << 48);
-            while (mask) {
-                const int c = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const int col = c0 + c;
-                float d = (qzero || inv_norm[col] == 0.0f) ? 2.0f : 1.0f - Ss[t * 65 + c];
-                if (!(d < ld[k - 1])) continue;                   // ties keep the earlier (smaller) index: stable order
-                int p = k - 1;
-                while (p > 0 && d < ld[p - 1]) { ld[p] = ld[p - 1]; li[p] = li[p - 1]; p--; }
-                ld[p] = d; li[p] = col;
-            }
-        }
     }
-    __syncthreads();
-    for (int i = t; i < 64 * k; i += 256) {
+    for (int i = t; i < 128 * k; i += 256) {
         const int r = i / k, j = i - r * k;
         if (q0 + r < n) { out_idx[(size_t)(q0 + r) * k + j] = Li[r * k + j]; out_dist[(size_t)(q0 + r) * k + j] = Ld[r * k + j]; }
     }
 }
 
+// (Cutting a strip into column segments for more work units than the 326 row blocks of a 41 667-row slice was tried and is slower, 18 against
+// 11.5 ms: every segment starts with empty lists, and a row's insertions — ~k ln(columns / k) per scan, each under the row's lock — multiply.)
 template <int DH>
-static void launch_knn(const float* x, const float* inv, int n, int D, int k, int32_t* oi, float* od, hipStream_t st) {
-    const size_t lds = (size_t)(64 * (2 * DH + 1) + 64 * 65 + 64 * k * 2 + 64 * 4) * sizeof(float);
+static int launch_knn(const float* xn, const float* inv, int n, int k, int32_t* oi, float* od, hipStream_t st) {
+    const size_t lds = (size_t)(64 * (2 * DH + 1) + 128 * k * 2 + 128) * sizeof(float);
+    if (lds > 160 * 1024) return -1;
     (void)hipFuncSetAttribute((const void*)k_knn_strip<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_knn_strip<DH>), dim3((n + 63) / 64), dim3(256), lds, st, x, inv, n, D, k, oi, od);
+    hipLaunchKernelGGL((k_knn_strip<DH>), dim3((n + 127) / 128), dim3(256), lds, st, xn, inv, n, k, oi, od);
+    return 0;
+}
+
+// device form: x [n x D] in device memory -> lists in device memory
+static int knn_device(const float* d_x, int n, int D, int k, float* d_inv, float* d_xn, int32_t* d_oi, float* d_od, double* ms_kernel) {
+    const int dh = (D + 1) / 2 <= 16 ? 16 : ((D + 1) / 2 <= 32 ? 32 : ((D + 1) / 2 <= 64 ? 64 : 128));
+    const int Dp = 2 * dh;
+    hipLaunchKernelGGL(k_row_norms, dim3((n + 255) / 256), dim3(256), 0, 0, d_x, n, D, d_inv);
+    hipLaunchKernelGGL(k_normalise, dim3((unsigned)(((size_t)n * Dp + 255) / 256)), dim3(256), 0, 0, d_x, d_inv, n, D, Dp, d_xn);
+    hipEvent_t e0, e1;
+    DGE_HIP(hipEventCreate(&e0)); DGE_HIP(hipEventCreate(&e1));
+    DGE_HIP(hipEventRecord(e0, 0));
+    int rc;
+    if (dh == 16) rc = launch_knn<16>(d_xn, d_inv, n, k, d_oi, d_od, 0);
+    else if (dh == 32) rc = launch_knn<32>(d_xn, d_inv, n, k, d_oi, d_od, 0);
+    else if (dh == 64) rc = launch_knn<64>(d_xn, d_inv, n, k, d_oi, d_od, 0);
+    else rc = launch_knn<128>(d_xn, d_inv, n, k, d_oi, d_od, 0);
+    DGE_HIP(hipEventRecord(e1, 0));
+    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); DGE_FAIL(DGE_ERR_ARG, "dge_knn_cosine: k = %d with dim = %d needs more than the 160 KB of LDS", k, D); }
+    DGE_HIP(hipGetLastError());
+    DGE_HIP(hipDeviceSynchronize());
+    float ms = 0.f;
+    DGE_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms_kernel) *ms_kernel = ms;
+    return DGE_OK;
 }
 
 // features: host float32 [n x D]; out_idx / out_dist: host [n x k].  Slots beyond n-1 neighbours hold -1 / 3.0.
@@ -128,29 +190,64 @@ extern "C" int dge_knn_cosine(int device, const float* features, int32_t n, int3
     if (D > KNN_MAX_D) DGE_FAIL(DGE_ERR_ARG, "dge_knn_cosine: dim = %d exceeds %d", D, KNN_MAX_D);
     int rc = dge_require_device(device);
     if (rc) return rc;
-    dge_tmp<float> d_x, d_inv, d_od; dge_tmp<int32_t> d_oi;
+    dge_tmp<float> d_x, d_inv, d_od, d_xn; dge_tmp<int32_t> d_oi;
     if ((rc = d_x.alloc((size_t)n * D))) return rc;
+    if ((rc = d_xn.alloc((size_t)n * 256))) return rc;
     if ((rc = d_inv.alloc((size_t)n))) return rc;
     if ((rc = d_od.alloc((size_t)n * k))) return rc;
     if ((rc = d_oi.alloc((size_t)n * k))) return rc;
     DGE_HIP(hipMemcpy(d_x.p, features, (size_t)n * D * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_row_norms, dim3((n + 255) / 256), dim3(256), 0, 0, d_x.p, n, D, d_inv.p);
-    hipEvent_t e0, e1;
-    DGE_HIP(hipEventCreate(&e0)); DGE_HIP(hipEventCreate(&e1));
-    DGE_HIP(hipEventRecord(e0, 0));
-    const int dh = (D + 1) / 2;
-    if (dh <= 16) launch_knn<16>(d_x.p, d_inv.p, n, D, k, d_oi.p, d_od.p, 0);
-    else if (dh <= 32) launch_knn<32>(d_x.p, d_inv.p, n, D, k, d_oi.p, d_od.p, 0);
-    else if (dh <= 64) launch_knn<64>(d_x.p, d_inv.p, n, D, k, d_oi.p, d_od.p, 0);
-    else launch_knn<128>(d_x.p, d_inv.p, n, D, k, d_oi.p, d_od.p, 0);
-    DGE_HIP(hipEventRecord(e1, 0));
-    DGE_HIP(hipGetLastError());
-    DGE_HIP(hipDeviceSynchronize());
-    float ms = 0.f;
-    DGE_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (ms_kernel) *ms_kernel = ms;
+    if ((rc = knn_device(d_x.p, n, D, k, d_inv.p, d_xn.p, d_oi.p, d_od.p, ms_kernel))) return rc;
     DGE_HIP(hipMemcpy(out_idx, d_oi.p, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost));
     DGE_HIP(hipMemcpy(out_dist, d_od.p, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost));
+    return DGE_OK;
+}
+
+// nDCG@k of the reference's evaluation (P/embeddingEvaluation_tract.py:249-260) on the device: relevance of neighbour j of region r =
+// 1 - gnd_dist[r][j] (cosine distance in the GROUND features, a zero vector at distance 2), DCG = sum_i relv_i / log2(i + 1) over the k
+// nearest neighbours of r in the ESTIMATED features, normalised by the DCG of the ground truth's own k nearest; mean over the regions.
+__global__ void k_ndcg(const float* __restrict__ gn, const float* __restrict__ ginv, int Dp, int n, int k, const int32_t* __restrict__ est_idx,
+                       const float* __restrict__ gnd_dist, double* __restrict__ ratio) {
+    const int r = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    double dcg = 0.0, dmax = 0.0;
+    for (int i = 0; i < k; i++) {
+        const int j = est_idx[(size_t)r * k + i];
+        if (j < 0) break;
+        float acc = 0.f;
+        for (int c = lane; c < Dp; c += 64) acc = fmaf(gn[(size_t)r * Dp + c], gn[(size_t)j * Dp + c], acc);
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        const double dist = (ginv[r] == 0.0f || ginv[j] == 0.0f) ? 2.0 : 1.0 - (double)acc;
+        dcg += (1.0 - dist) / log2((double)(i + 2));
+        dmax += (1.0 - (double)gnd_dist[(size_t)r * k + i]) / log2((double)(i + 2));
+    }
+    if (lane == 0) ratio[r] = dmax != 0.0 ? dcg / dmax : 0.0;
+}
+
+extern "C" int dge_ndcg_at_k(int device, const float* features, int32_t dim, const float* gnd_features, int32_t gnd_dim, int32_t n, int32_t k,
+                             double* ndcg, double* ms_kernels) {
+    if (!features || !gnd_features || !ndcg || n <= 1 || dim <= 0 || gnd_dim <= 0 || k <= 0) DGE_FAIL(DGE_ERR_ARG, "dge_ndcg_at_k: bad argument");
+    if (k > KNN_MAX_K || k > n - 1) DGE_FAIL(DGE_ERR_ARG, "dge_ndcg_at_k: k = %d must be <= %d and < n", k, KNN_MAX_K);
+    if (dim > KNN_MAX_D || gnd_dim > KNN_MAX_D) DGE_FAIL(DGE_ERR_ARG, "dge_ndcg_at_k: dim exceeds %d", KNN_MAX_D);
+    int rc = dge_require_device(device);
+    if (rc) return rc;
+    dge_tmp<float> d_x, d_g, d_inv, d_ginv, d_xn, d_gn, d_od, d_god; dge_tmp<int32_t> d_oi, d_goi; dge_tmp<double> d_ratio;
+    if ((rc = d_x.alloc((size_t)n * dim)) || (rc = d_g.alloc((size_t)n * gnd_dim)) || (rc = d_inv.alloc(n)) || (rc = d_ginv.alloc(n)) ||
+        (rc = d_xn.alloc((size_t)n * 256)) || (rc = d_gn.alloc((size_t)n * 256)) || (rc = d_od.alloc((size_t)n * k)) || (rc = d_god.alloc((size_t)n * k)) ||
+        (rc = d_oi.alloc((size_t)n * k)) || (rc = d_goi.alloc((size_t)n * k)) || (rc = d_ratio.alloc(n))) return rc;
+    DGE_HIP(hipMemcpy(d_x.p, features, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice));
+    DGE_HIP(hipMemcpy(d_g.p, gnd_features, (size_t)n * gnd_dim * sizeof(float), hipMemcpyHostToDevice));
+    double ms1 = 0, ms2 = 0;
+    if ((rc = knn_device(d_x.p, n, dim, k, d_inv.p, d_xn.p, d_oi.p, d_od.p, &ms1))) return rc;
+    if ((rc = knn_device(d_g.p, n, gnd_dim, k, d_ginv.p, d_gn.p, d_goi.p, d_god.p, &ms2))) return rc;
+    const int gdh = (gnd_dim + 1) / 2 <= 16 ? 16 : ((gnd_dim + 1) / 2 <= 32 ? 32 : ((gnd_dim + 1) / 2 <= 64 ? 64 : 128));
+    hipLaunchKernelGGL(k_ndcg, dim3((n + 3) / 4), dim3(256), 0, 0, d_gn.p, d_ginv.p, 2 * gdh, n, k, d_oi.p, d_god.p, d_ratio.p);
+    DGE_HIP(hipGetLastError());
+    std::vector<double> ratio((size_t)n);
+    DGE_HIP(hipMemcpy(ratio.data(), d_ratio.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    double s = 0.0;
+    for (int r = 0; r < n; r++) s += ratio[(size_t)r];
+    *ndcg = s / (double)n;
+    if (ms_kernels) *ms_kernels = ms1 + ms2;
     return DGE_OK;
 }

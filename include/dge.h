@@ -284,6 +284,11 @@ int  dge_model_gather_table(dge_model* m, dge_comm* c, int table);
  * ---------------------------------------------------------------------------------------------- */
 int  dge_knn_cosine(int device, const float* features, int32_t n, int32_t dim, int32_t k, int32_t* out_idx, float* out_dist,
                     double* ms_kernel);
+/* ndcg_atK of P/embeddingEvaluation_tract.py:249-260 wholly on the device: the k nearest neighbours of every region in `features`
+ * [n x dim] are scored with relevance 1 - (cosine distance in gnd_features [n x gnd_dim]), DCG = sum_i relv_i / log2(i + 1), normalised
+ * by the DCG of the ground features' own k nearest; *ndcg = mean over the n regions (rows of the two arrays are the same regions). */
+int  dge_ndcg_at_k(int device, const float* features, int32_t dim, const float* gnd_features, int32_t gnd_dim, int32_t n, int32_t k,
+                   double* ndcg, double* ms_kernels);
 
 /* ------------------------------------------------------------------------------------------------
  * Ablation / test knobs of the trainer (process-wide, not thread-safe; nothing in a normal run sets them).  value < 0 puts

@@ -79,3 +79,62 @@ def test_two_rank_fit_in_batches_matches_one_process(dge, oracle, tmp_path):
     h = _run(tmp_path / "hog", nb, 64)
     assert np.array_equal(bits(h[0]["syn0"]), bits(h[1]["syn0"]))
     assert float(np.median(cosine_rows(h[0]["syn0"], want0))) > 0.99
+
+
+def _rank_nccl(rank, world, port, out_dir):
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import embedding_amd as dge
+    from embedding_amd.distributed import fit_distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:%d" % rank))
+    src, dst, w, sources = layered_graph(R=R, T=T, deg=5, seed=0)
+    g = dge.DeviceGraph(rank); g.add_edges(src, dst, w); g.set_sources(sources); g.build_alias(True)
+    cfg = dge.make_config(DIM, T, R * T, workers=1, table_size=20011)
+    m = fit_distributed(g, N_WALKS, T, cfg, world, rank, walk_seed=11, batch_walks=N_WALKS, device=rank)
+    syn0, vid = m.vectors()
+    np.savez(os.path.join(out_dir, "n%d.npz" % rank), syn0=syn0, syn1neg=m.syn1neg(), vid=vid)
+    # the library's own RCCL calls (hosts without torch.distributed): the id travels through torch here, any channel would do
+    uid = (C.c_char * 128)()
+    if rank == 0:
+        dge._native.check(dge.lib.dge_comm_unique_id(uid))
+    t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).cuda(rank)
+    dist.broadcast(t, 0)
+    uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+    comm = C.c_void_p(0)
+    dge._native.check(dge.lib.dge_comm_create(C.byref(comm), uid, rank, world, rank))
+    corpus = g.sample_walks_device(N_WALKS, T, seed=11, rng_mode=1)
+    counts = torch.zeros(R * T, dtype=torch.int64, device="cuda:%d" % rank); corpus.count_tokens(R * T, counts)
+    m2 = dge.SgnsModel.create(cfg, counts, rank)
+    for e in range(world):
+        m2.set_partition(world, rank, (rank + e) % world)
+        m2.train(corpus, total_walks=N_WALKS)
+        dge._native.check(dge.lib.dge_model_ring_pass(m2._h, comm, e))
+    m2.set_partition(1)
+    for table in (0, 1):
+        dge._native.check(dge.lib.dge_model_gather_table(m2._h, comm, table))
+    np.savez(os.path.join(out_dir, "c%d.npz" % rank), syn0=m2.vectors()[0], syn1neg=m2.syn1neg())
+    dge.lib.dge_comm_free(comm)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gpus_over_rccl(dge, oracle, tmp_path):
+    """TWO GPUs, backend nccl (= RCCL): fit_distributed over torch.distributed's point-to-point ring, and the library's own
+    dge_comm_* / dge_model_ring_pass / dge_model_gather_table, both against the oracle's sequential run of the 2 x 2 blocks, bit for bit.
+    Skipped on a one-GPU box (the build boxes): the first place this can run is a multi-GPU node."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rank_nccl, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    walks = _graph(dge).sample_walks(N_WALKS, T, seed=11, rng_mode=1)
+    om = oracle.train_sgns(walks, R * T, DIM, T, table_size=20011, arith=1, part_n=2)
+    for tag in ("n", "c"):
+        for r in range(2):
+            d = np.load(str(tmp_path / ("%s%d.npz" % (tag, r))))
+            assert np.array_equal(bits(d["syn0"]), bits(om.syn0)) and np.array_equal(bits(d["syn1neg"]), bits(om.syn1neg)), (tag, r)

@@ -51,8 +51,13 @@ def test_knn_feeds_ndcg_and_scales(dge):
     dcg_max = {r: ev.dcg_at_k(10, gnd[r], gnb[r]) for r in rids}
     gpu = ev.ndcg_at_k(10, rids, {r: idx[r].tolist() for r in rids}, gnd, dcg_max)
     assert abs(gpu - host) < 1e-6
+    dev, _ = ev.ndcg_against_gpu(g, f, k=10)                   # the whole metric on the device (dge_ndcg_at_k)
+    assert abs(dev - host) < 1e-5, (dev, host)
+    f2 = f.copy(); f2[3] = 0.0                                 # a zero ground vector: its neighbours are at distance 2 (relevance -1)
+    assert abs(ev.ndcg_against_gpu(g, f2, k=10)[0] - ev.ndcg_against(g, f2, rids, k=10)) < 1e-5
     big = rng.normal(size=(41667, 128)).astype(np.float32)
     idx, dist, ms = ev.knn_cosine_gpu(big, 10)
     flops = 2.0 * 41667 * 41667 * 128
     print("knn 41667 x 128: %.1f ms, %.1f TFLOP/s (f32 MFMA peak 157)" % (ms, flops / ms / 1e9))
     assert ms < 1000 and (idx >= 0).all() and (np.diff(dist, axis=1) >= 0).all()
+    assert flops / ms / 1e9 > 35.0, "below a quarter of the f32 MFMA peak"
