@@ -49,12 +49,15 @@ struct dge_tmp {
     operator T*() const { return p; }
 };
 
-// One alias slot as the walk kernel reads it: 16 bytes, one dwordx4 load per step.
-// nbr_alias already resolves alias[i] to the neighbour it points at ("alias == -1" -> nbr itself).
-struct __attribute__((aligned(16))) dge_slot {
+// One alias slot as the walk kernel reads it: 32 bytes (two 16-byte loads of one aligned sector), the ONLY memory access of a walk
+// step.  nbr_alias already resolves alias[i] to the neighbour it points at ("alias == -1" -> nbr itself), and the slot carries the
+// row bounds of both candidates, so the next step needs no row_ptr look-up: one dependent round trip per step instead of two.
+struct __attribute__((aligned(32))) dge_slot {
     double prob;
     int32_t nbr;
     int32_t nbr_alias;
+    uint32_t base, k;               // edges of nbr:       [base, base + k)   (the store holds fewer than 2^32 edges)
+    uint32_t base_alias, k_alias;   // edges of nbr_alias
 };
 
 struct dge_graph {

@@ -154,12 +154,14 @@ __global__ void k_alias_vertices(int32_t V, const int64_t* row_ptr, const double
         s.prob = prob[b + i];
         s.nbr = nbr[b + i];
         s.nbr_alias = a >= 0 ? nbr[b + a] : nbr[b + i];   // "no alias" -> stay in slot i
+        s.base = (uint32_t)row_ptr[s.nbr]; s.k = (uint32_t)(row_ptr[s.nbr + 1] - row_ptr[s.nbr]);
+        s.base_alias = (uint32_t)row_ptr[s.nbr_alias]; s.k_alias = (uint32_t)(row_ptr[s.nbr_alias + 1] - row_ptr[s.nbr_alias]);
         slots[b + i] = s;
     }
 }
 
 // the same pairing over the source vertices, weight = outDegree (J/LayeredGraph.java:199-225)
-__global__ void k_alias_sources(int64_t S, const double* src_w, double total, const int32_t* srcv, double* prob, int32_t* alias,
+__global__ void k_alias_sources(int64_t S, const double* src_w, double total, const int32_t* srcv, const int64_t* row_ptr, double* prob, int32_t* alias,
                                 dge_slot* slots, int exact, uint64_t* bs_scratch, int32_t* vose_scratch) {
     if (blockIdx.x != 0 || threadIdx.x != 0 || S == 0) return;
     if (exact) dge_alias_reference(src_w, S, total, prob, alias, bs_scratch);
@@ -170,17 +172,24 @@ __global__ void k_alias_sources(int64_t S, const double* src_w, double total, co
         s.prob = prob[i];
         s.nbr = srcv[i];
         s.nbr_alias = a >= 0 ? srcv[a] : srcv[i];
+        s.base = (uint32_t)row_ptr[s.nbr]; s.k = (uint32_t)(row_ptr[s.nbr + 1] - row_ptr[s.nbr]);
+        s.base_alias = (uint32_t)row_ptr[s.nbr_alias]; s.k_alias = (uint32_t)(row_ptr[s.nbr_alias + 1] - row_ptr[s.nbr_alias]);
         slots[i] = s;
     }
 }
 
 // ------------------------------------------------------------------------------------------ walk sampler
-// One draw (J/LayeredGraph.java:104-116): x -> slot -> neighbour.  One 16-B slot load.
-__device__ __forceinline__ int32_t walk_pick(const dge_slot* __restrict__ slots, int64_t base, int64_t k, double x) {
+// One draw (J/LayeredGraph.java:104-116): x -> slot -> neighbour, and the neighbour's own row bounds (b, k) for the next draw.
+// One 32-byte slot: the step's only memory access.
+__device__ __forceinline__ int32_t walk_pick(const dge_slot* __restrict__ slots, int64_t base, int64_t k, double x, int64_t& nb, int64_t& nk) {
     double y;
     int64_t i = dge_alias_slot(x, k, &y);
-    dge_slot s = slots[base + i];
-    return y < s.prob ? s.nbr : s.nbr_alias;
+    const uint4* p = reinterpret_cast<const uint4*>(slots + base + i);
+    const uint4 lo = p[0], hi = p[1];
+    const double prob = __hiloint2double((int)lo.y, (int)lo.x);
+    const bool first = y < prob;
+    nb = first ? hi.x : hi.z; nk = first ? hi.y : hi.w;
+    return (int32_t)(first ? lo.z : lo.w);
 }
 
 // sampleVertexSequence (J/LayeredGraph.java:232-252), one lane per walk.  Walk i consumes the draws
@@ -204,15 +213,14 @@ k_walks(const int64_t* __restrict__ row_ptr, const dge_slot* __restrict__ slots,
         int len = 0;
         if (S > 0) {
             double x = dge_jr_next_double(s);
-            int32_t v = walk_pick(src_slots, 0, S, x);
+            int64_t b, k;
+            int32_t v = walk_pick(src_slots, 0, S, x, b, k);
             row[0] = v;
             len = 1;
             for (; len < L; len++) {
-                int64_t b = row_ptr[v];
-                int64_t k = row_ptr[v + 1] - b;
                 if (k == 0) break;                      // dead end: no draw (J/LayeredGraph.java:106-107)
                 x = dge_jr_next_double(s);
-                v = walk_pick(slots, b, k, x);
+                v = walk_pick(slots, b, k, x, b, k);
                 row[len] = v;
             }
         }
@@ -243,13 +251,13 @@ __global__ void k_walks_sequential(const int64_t* row_ptr, const dge_slot* slots
         int len = 0;
         if (S > 0 && L > 0) {
             double x = dge_jr_next_double(s); draws++;
-            int32_t v = walk_pick(src_slots, 0, S, x);
+            int64_t b, k;
+            int32_t v = walk_pick(src_slots, 0, S, x, b, k);
             row[0] = v; len = 1;
             for (; len < L; len++) {
-                int64_t b = row_ptr[v], k = row_ptr[v + 1] - b;
                 if (k == 0) break;
                 x = dge_jr_next_double(s); draws++;
-                v = walk_pick(slots, b, k, x);
+                v = walk_pick(slots, b, k, x, b, k);
                 row[len] = v;
             }
         }
@@ -299,7 +307,8 @@ __global__ void k_seq_starts(const uint8_t* __restrict__ lens, int64_t N, int64_
 __global__ void k_sample_next(const int64_t* row_ptr, const dge_slot* slots, int32_t v, double x, int32_t* out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     int64_t b = row_ptr[v], k = row_ptr[v + 1] - b;
-    *out = k == 0 ? -1 : walk_pick(slots, b, k, x);
+    int64_t nb, nk;
+    *out = k == 0 ? -1 : walk_pick(slots, b, k, x, nb, nk);
 }
 
 __global__ void k_position_prefix(int32_t* walks, int64_t n, int32_t L, int32_t R) {
@@ -617,7 +626,7 @@ extern "C" int dge_graph_build_alias(dge_graph* g, int exact) {
                            g->d_outdeg, g->d_prob, g->d_alias, g->d_slots, exact, d_bs.p, d_vs.p);
     DGE_HIP(hipStreamSynchronize(g->stream));
     if (S > 0)
-        hipLaunchKernelGGL(k_alias_sources, dim3(1), dim3(64), 0, g->stream, S, g->d_src_w, g->src_weight_sum, g->d_srcv,
+        hipLaunchKernelGGL(k_alias_sources, dim3(1), dim3(64), 0, g->stream, S, g->d_src_w, g->src_weight_sum, g->d_srcv, g->d_row_ptr,
                            g->d_src_prob, g->d_src_alias, g->d_src_slots, exact, d_bs.p, d_vs.p);
     DGE_HIP(hipStreamSynchronize(g->stream));
     DGE_HIP(hipGetLastError());
