@@ -398,7 +398,8 @@ template <int DCH>
 __global__ void __launch_bounds__(256) k_sorted_commit(SortedParams q, const int64_t* seg_a) {
     const TrainParams& p = q.t;
     const int lane = threadIdx.x & 15;
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    // under the block schedule only the rows of the target partition can have moved
+    const int64_t r = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4) * max(p.part_n, 1) + (p.part_n > 1 ? p.part_tgt : 0);
     if (r >= p.V || seg_a[r + 1] == seg_a[r]) return;
     Row<DCH> row;
     rowA_load<DCH, 0, false>(row, make_view(q.shadow, p.V, p.stride), (int32_t)r, lane);
@@ -406,7 +407,8 @@ __global__ void __launch_bounds__(256) k_sorted_commit(SortedParams q, const int
 }
 template <int DCH>
 static void launch_commit(const SortedParams& q, const int64_t* seg_a, hipStream_t st) {
-    hipLaunchKernelGGL((k_sorted_commit<DCH>), dim3((unsigned)((q.t.V * 16 + 255) / 256)), dim3(256), 0, st, q, seg_a);
+    const int64_t rows = (q.t.V + std::max(q.t.part_n, 1) - 1) / std::max(q.t.part_n, 1);
+    hipLaunchKernelGGL((k_sorted_commit<DCH>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, q, seg_a);
 }
 static void launch_commit_any(int dch, const SortedParams& q, const int64_t* seg_a, hipStream_t st) {
     switch (dch) {
@@ -423,13 +425,13 @@ static void launch_commit_any(int dch, const SortedParams& q, const int64_t* seg
 // from the other side, so the size is set by TERMS PER LIVE ROW: measured (scripts/quality_sorted.py, profiles/r02_quality_sorted.txt)
 // the link-prediction AUC equals the atomics schedule's up to ~120 items per row and mini-batch, slips at ~460 and collapses at ~2300 —
 // and the HOTTEST row counts, not the average one: on a Zipf-popular graph a head row took > 1e5 terms of a 96-per-row mini-batch and
-// the tables went to NaN within an epoch.  Hence: 96 items per live row, at most 2048 for the hottest row, and no mini-batch below 1e6
+// the tables went to NaN within an epoch.  Hence: 128 items per live row, at most 2048 for the hottest row, and no mini-batch below 1e6
 // items (the two sorts and ~16 launches per mini-batch need that much to pay): 0 = this vocabulary is too skewed or too small.
 int64_t dge_sorted_batch_items(const dge_model* m, int part_n) {
     const int n = std::max(part_n, 1);
     const int64_t live_rows = std::max<int64_t>(1, m->V / n);
     const double hottest = std::min(1.0, m->row_share_max * (double)n);      // its share of one block's terms
-    int64_t items = std::min<int64_t>(96ll << 20, 96 * live_rows);
+    int64_t items = std::min<int64_t>(96ll << 20, 128 * live_rows);
     items = std::min<int64_t>(items, (int64_t)(2048.0 / std::max(hottest, 1e-12)));
     return items >= (1 << 20) ? items : 0;
 }
