@@ -557,7 +557,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     if (part && hs) DGE_FAIL(DGE_ERR_STATE, "the block schedule (dge_model_set_partition) cannot carry the hierarchical-softmax term: a Huffman path crosses every partition");
 
     // auto: where the Hogwild kernels are bound by contention on a FLAT vocabulary — one too small for row locks (they fall back to
-    // atomics: cfg2), a block of a schedule of 4 and more ranks (V/N live rows per table) — the owner-computes schedule is the faster
+    // atomics: cfg2), a block of a schedule of 3 and more ranks (V/N live rows per table) — the owner-computes schedule is the faster
     // one at equal link-prediction AUC (one block of 8 ranks 5.7e8 vs 4.6e8 edges/s, a 100 k-row vocabulary at D = 128 6.8e8 vs 4.2e8:
     // profiles/r02_quality_sorted.txt).  A skewed vocabulary stays with the mixed policy 7: a synchronous mini-batch hands a hot row
     // thousands of terms at once with no feedback between them, and the embedding diverges (dge_sorted_batch_items).
@@ -565,7 +565,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     if (m->cfg.update_policy == 0 && m->cfg.workers == 0 && !hs && (uint64_t)m->V * (uint64_t)m->stride * 4ull < 0xFFFFFFFFull) {
         const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
         const bool locks_work = m->V >= 262144 && (fail < 0.25 || m->hot_rows_auto <= m->V / 8);   // -> commit locks, all rows (5) or the tail (7)
-        if (part) sorted_auto = m->part_n >= 4 && dge_sorted_batch_items(m, m->part_n) > 0;
+        if (part) sorted_auto = m->part_n >= 3 && dge_sorted_batch_items(m, m->part_n) > 0;         // (N = 2: equal to the locks, N = 3: 6.8e8 vs 6.1e8)
         else sorted_auto = !locks_work && dge_sorted_batch_items(m, 1) > 0;                         // (what used to fall back to atomics)
     }
     if ((m->cfg.update_policy == 8 && m->cfg.workers != 1) || sorted_auto) {
