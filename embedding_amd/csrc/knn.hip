@@ -3,11 +3,11 @@
 // scipy-cosine distance, NaN -> 2).  A "next" row of SURVEY.md §8f, not part of the training hot path; it serves as the
 // statistical parity check between training schedules at sizes where the Python loop (O(n^2) scipy calls) is hopeless.
 //
-// One workgroup = 128 query rows (4 waves x 32 rows, the query fragments stay in registers for the whole strip).  The strip of
-// similarities S[128 x n] = Xq . X^T is produced 64 columns at a time with the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32
-// (a wave: its 32 rows x the tile's 2 x 32 columns, two accumulators); the column tile comes from LDS, the NEXT tile's 16-byte global
+// One workgroup = 64 query rows (4 waves x 16 rows, the query fragments stay in registers for the whole strip).  The strip of
+// similarities S[64 x n] = Xq . X^T is produced 64 columns at a time with the exact-f32 matrix instruction v_mfma_f32_16x16x4_f32
+// (a wave: its 16 rows x the tile's 4 x 16 columns, four accumulators); the column tile comes from LDS, the NEXT tile's 16-byte global
 // loads are issued before the matrix loop and land in LDS after it.  The similarities never leave the accumulator registers: every
-// lane tests its 32 values against the current k-th best of their rows (a threshold that only tightens, so nothing that belongs in
+// lane tests its 16 values against the current k-th best of their rows (a threshold that only tightens, so nothing that belongs in
 // a list is missed) and the few that pass are inserted into the row's k best in LDS under a per-row lock, ordered by (distance,
 // index) — the order of insertion does not matter.  Nothing of size n^2 ever reaches HBM.
 #include <hip/hip_runtime.h>
@@ -17,7 +17,6 @@
 
 #include "dge_internal.h"
 
-typedef float v16f __attribute__((ext_vector_type(16)));
 #define KNN_MAX_K 64
 #define KNN_MAX_D 256
 
@@ -40,30 +39,36 @@ __global__ void k_normalise(const float* __restrict__ x, const float* __restrict
 // (d, col) < (d2, col2): distance ascending, smaller index first among equals
 __device__ __forceinline__ bool knn_less(float d, int col, float d2, int col2) { return d < d2 || (d == d2 && (unsigned)col < (unsigned)col2); }
 
-template <int DH>   // DH = D_padded / 2 = MFMA steps per tile
-__global__ void __launch_bounds__(256, 2)
+// 16 query rows per wave, not 32 (v_mfma_f32_32x32x2_f32, round 1): a wave is bound to one of the device's 1 024 SIMDs, so 32-row waves put
+// ceil(n / 32 / 1024) whole wave strips on the busiest SIMD — 2 at n = 41 667 where the mean is 1.27 (measured 50.7 TFLOP/s against 86.9 at
+// n = 65 536, where every SIMD has 2) — and 16-row waves ceil(n / 16 / 1024) half-size ones (3 at n = 41 667: 74.5 TFLOP/s); the query fragment
+// is half as many registers (three workgroups a compute unit instead of two), the columns are streamed from L2 / the Infinity Cache twice as often.
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int DH>   // DH = D_padded / 2
+__global__ void __launch_bounds__(256, DH >= 128 ? 2 : 3)      // (D = 256: the column tile is 66 KB, two workgroups a compute unit anyway)
 k_knn_strip(const float* __restrict__ xn, const float* __restrict__ inv_norm, int n, int k, int32_t* __restrict__ out_idx,
-            float* __restrict__ out_dist) {
+              float* __restrict__ out_dist) {
     extern __shared__ float lds[];
-    constexpr int Dp = DH * 2;
+    constexpr int Dp = DH * 2, P = Dp + 4;        // pitch of a column in LDS: 16-byte rows, and 4*col + kk is a different bank for every lane
     constexpr int NPF = Dp / 16;                  // float4 loads per thread and tile: 64 columns x Dp floats / 256 threads
-    float* Bs = lds;                              // [64][Dp + 1]   column tile (odd pitch: conflict-free fragment reads)
-    float* Ld = Bs + 64 * (Dp + 1);               // [128][k]       running best distances
-    int32_t* Li = (int32_t*)(Ld + 128 * k);       // [128][k]       their indices (-1: empty, sorts last)
-    int* Lk = (int*)(Li + 128 * k);               // [128]          per-row locks
+    constexpr int NS = Dp / 4;                    // MFMA steps per tile and column block
+    float* Bs = lds;                              // [64][P]        column tile
+    float* Ld = Bs + 64 * P;                      // [64][k]        running best distances
+    int32_t* Li = (int32_t*)(Ld + 64 * k);        // [64][k]        their indices (-1: empty, sorts last)
+    int* Lk = (int*)(Li + 64 * k);                // [64]           per-row locks
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int q0 = blockIdx.x * 128;
-    const int cb = 0, ce = n;
+    const int q0 = blockIdx.x * 64;
+    const int ce = n;
 
-    // query fragment: lane holds A[row = lane%32][kk = 2*j + lane/32] for j = 0..DH-1
-    float a[DH];
+    // query fragment: lane holds A[row = lane%16][kk = 4*j + lane/16] for j = 0..NS-1
+    float a[NS];
     {
-        const int row = q0 + wave * 32 + (lane & 31);
+        const int row = q0 + wave * 16 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < DH; j++) a[j] = row < n ? xn[(size_t)row * Dp + 2 * j + (lane >> 5)] : 0.0f;
+        for (int j = 0; j < NS; j++) a[j] = row < n ? xn[(size_t)row * Dp + 4 * j + (lane >> 4)] : 0.0f;
     }
-    for (int i = t; i < 128 * k; i += 256) { Ld[i] = 3.0f; Li[i] = -1; }     // 3 > any cosine distance
-    if (t < 128) Lk[t] = 0;
+    for (int i = t; i < 64 * k; i += 256) { Ld[i] = 3.0f; Li[i] = -1; }      // 3 > any cosine distance
+    if (t < 64) Lk[t] = 0;
 
     float4 pf[NPF];
     auto fetch = [&](int c0) {                    // tile c0 .. c0+63: thread takes float4 number t + 256*i
@@ -77,48 +82,48 @@ k_knn_strip(const float* __restrict__ xn, const float* __restrict__ inv_norm, in
 #pragma unroll
         for (int i = 0; i < NPF; i++) {
             const int f = t + 256 * i, c = f / (Dp / 4), kq = f % (Dp / 4);
-            float* d = Bs + c * (Dp + 1) + 4 * kq;
-            d[0] = pf[i].x; d[1] = pf[i].y; d[2] = pf[i].z; d[3] = pf[i].w;
+            *(float4*)(Bs + c * P + 4 * kq) = pf[i];
         }
     };
-    fetch(cb);
+    fetch(0);
     __syncthreads();
     stash();
     __syncthreads();
 
-    for (int c0 = cb; c0 < ce; c0 += 64) {
+    for (int c0 = 0; c0 < ce; c0 += 64) {
         if (c0 + 64 < ce) fetch(c0 + 64);                         // in flight during the matrix loop
-        v16f acc0 = {0}, acc1 = {0};
-        const float* b0 = Bs + (lane & 31) * (Dp + 1) + (lane >> 5);
-        const float* b1 = b0 + 32 * (Dp + 1);
+        v4f acc[4] = {{0}, {0}, {0}, {0}};
+        const float* b = Bs + (lane & 15) * P + (lane >> 4);      // B[kk = 4*j + lane/16][col = 16*cb + lane%16]
 #pragma unroll
-        for (int j = 0; j < DH; j++) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[2 * j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[2 * j], acc1, 0, 0, 0);
-            if ((j & 7) == 7) asm volatile("" ::: "memory");      // keeps the scheduler from hoisting all 2*DH fragment reads at once (spills)
+        for (int j = 0; j < NS; j++) {
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[cb * 16 * P + 4 * j], acc[cb], 0, 0, 0);
+            if ((j & 7) == 7) asm volatile("" ::: "memory");      // keeps the scheduler from hoisting every fragment read at once
         }
-        // accumulator register v of a lane is S[8*(v/4) + 4*(lane/32) + v%4][lane%32] of the 32x32 sub-tile.
-        // Common path: 32 compares against the rows' k-th best -> a bit mask (bit 2v + sub); nothing else is touched.
+        // accumulator register v of column block cb is S[4*(lane/16) + v][16*cb + lane%16].  Common path: 16 compares against the rows' k-th
+        // best -> a bit mask (bit 4*cb + v); nothing else is touched.
         uint32_t hits = 0;
 #pragma unroll
-        for (int v = 0; v < 16; v++) {
-            const int rl = wave * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), q = q0 + rl;
+        for (int v = 0; v < 4; v++) {
+            const int rl = wave * 16 + 4 * (lane >> 4) + v, q = q0 + rl;
             const float thr_d = Ld[rl * k + k - 1]; const int thr_i = Li[rl * k + k - 1];
-            const int c_lo = c0 + (lane & 31), c_hi = c_lo + 32;
-            if (q < n && c_lo < ce && c_lo != q && knn_less(1.0f - acc0[v], c_lo, thr_d, thr_i)) hits |= 1u << (2 * v);
-            if (q < n && c_hi < ce && c_hi != q && knn_less(1.0f - acc1[v], c_hi, thr_d, thr_i)) hits |= 2u << (2 * v);
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) {
+                const int col = c0 + 16 * cb + (lane & 15);
+                if (q < n && col < ce && col != q && knn_less(1.0f - acc[cb][v], col, thr_d, thr_i)) hits |= 1u << (4 * cb + v);
+            }
         }
         // Rare path (after the lists have warmed up: a handful per tile): one candidate per lane and trip, inserted under its row's lock
         while (__any(hits != 0)) {
             bool pending = hits != 0;
             const int bit = pending ? __builtin_ctz(hits) : 0;
             hits &= hits - 1;
-            const int v = bit >> 1, sub = bit & 1;
+            const int v = bit & 3, cb = bit >> 2;
             float sv = 0.f;
 #pragma unroll
-            for (int x = 0; x < 16; x++) if (x == v) sv = sub ? acc1[x] : acc0[x];
-            const int rl = wave * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), q = q0 + rl;
-            const int col = c0 + sub * 32 + (lane & 31);
+            for (int x = 0; x < 16; x++) if (x == bit) sv = acc[x >> 2][x & 3];
+            const int rl = wave * 16 + 4 * (lane >> 4) + v, q = q0 + rl;
+            const int col = c0 + 16 * cb + (lane & 15);
             float d = 1.0f - sv;
             if (pending && (inv_norm[q] == 0.0f || inv_norm[col] == 0.0f)) d = 2.0f;      // cosine undefined -> distance 2
             while (__any(pending)) {
@@ -139,20 +144,21 @@ k_knn_strip(const float* __restrict__ xn, const float* __restrict__ inv_norm, in
         if (c0 + 64 < ce) stash();
         __syncthreads();
     }
-    for (int i = t; i < 128 * k; i += 256) {
+    for (int i = t; i < 64 * k; i += 256) {
         const int r = i / k, j = i - r * k;
         if (q0 + r < n) { out_idx[(size_t)(q0 + r) * k + j] = Li[r * k + j]; out_dist[(size_t)(q0 + r) * k + j] = Ld[r * k + j]; }
     }
 }
 
 // (Cutting a strip into column segments for more work units than the 326 row blocks of a 41 667-row slice was tried and is slower, 18 against
-// 11.5 ms: every segment starts with empty lists, and a row's insertions — ~k ln(columns / k) per scan, each under the row's lock — multiply.)
+// 11.5 ms: every segment starts with empty lists, and a row's insertions — ~k ln(columns / k) per scan, each under the row's lock — multiply.
+// So was giving the waves of a 64-row workgroup one half of every column tile each: one accumulator per wave, 41.7 against 50.7 TFLOP/s.)
 template <int DH>
 static int launch_knn(const float* xn, const float* inv, int n, int k, int32_t* oi, float* od, hipStream_t st) {
-    const size_t lds = (size_t)(64 * (2 * DH + 1) + 128 * k * 2 + 128) * sizeof(float);
+    const size_t lds = (size_t)(64 * (2 * DH + 4) + 64 * k * 2 + 64) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     (void)hipFuncSetAttribute((const void*)k_knn_strip<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_knn_strip<DH>), dim3((n + 127) / 128), dim3(256), lds, st, xn, inv, n, k, oi, od);
+    hipLaunchKernelGGL((k_knn_strip<DH>), dim3((n + 63) / 64), dim3(256), lds, st, xn, inv, n, k, oi, od);
     return 0;
 }
 

@@ -60,4 +60,4 @@ def test_knn_feeds_ndcg_and_scales(dge):
     flops = 2.0 * 41667 * 41667 * 128
     print("knn 41667 x 128: %.1f ms, %.1f TFLOP/s (f32 MFMA peak 157)" % (ms, flops / ms / 1e9))
     assert ms < 1000 and (idx >= 0).all() and (np.diff(dist, axis=1) >= 0).all()
-    assert flops / ms / 1e9 > 35.0, "below a quarter of the f32 MFMA peak"
+    assert flops / ms / 1e9 > 55.0, "below 35 % of the f32 MFMA peak"
