@@ -565,7 +565,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     if (m->cfg.update_policy == 0 && m->cfg.workers == 0 && !hs && (uint64_t)m->V * (uint64_t)m->stride * 4ull < 0xFFFFFFFFull) {
         const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
         const bool locks_work = m->V >= 262144 && (fail < 0.25 || m->hot_rows_auto <= m->V / 8);   // -> commit locks, all rows (5) or the tail (7)
-        if (part) sorted_auto = m->part_n >= 3 && dge_sorted_batch_items(m, m->part_n) > 0;         // (N = 2: equal to the locks, N = 3: 6.8e8 vs 6.1e8)
+        if (part) sorted_auto = m->part_n >= 3 && dge_sorted_batch_items(m, m->part_n) > 0;         // (per rank on cfg3, owner-computes vs locks: N = 2 7.2e8 vs 7.7e8, N = 4 7.1e8 vs 5.9e8, N = 8 6.4e8 vs 4.0e8)
         else sorted_auto = !locks_work && dge_sorted_batch_items(m, 1) > 0;                         // (what used to fall back to atomics)
     }
     if ((m->cfg.update_policy == 8 && m->cfg.workers != 1) || sorted_auto) {

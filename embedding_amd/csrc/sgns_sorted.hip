@@ -25,6 +25,7 @@
 // straddle chunk borders is processed as independent segments from the same starting row and their deltas are added in chunk order
 // by the owner of the row's first chunk (k_sorted_fixup).
 #include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 
@@ -72,11 +73,15 @@ struct SortedParams {
     int64_t pair0;                               // off[unit0]
     int32_t* key_out; uint64_t* val_out;         // emit / phase A output
     const int32_t* key_in; const uint64_t* val_in;
-    const int64_t* seg;                          // seg[r] = first sorted position with key >= r; seg[V] = valid items
+    const int64_t* seg;                          // seg[k] = first sorted position with key >= k; seg[Vk] = valid items
     int64_t n_slots;                             // sorted array length (valid items first, then the skipped draws with key V)
     int32_t chunk;                               // items per work unit
     float* scratch;                              // [2 * chunks][stride]: deltas of the rows a chunk shares with its neighbours
     float* shadow;                               // phase A writes the moved target rows here; phase B still reads the rows as they were
+    // sort keys: row / kdiv.  Under the block schedule only rows = part (mod part_n) occur on either side, so the keys lose log2(part_n) bits
+    // (the 125 k live rows of an 8-rank block: 17 bits instead of 20, two sort passes instead of three); row = key * kdiv + the side's part.
+    int32_t kdiv, kpart_tgt, kpart_ctx;
+    int32_t Vk;                                  // keys are 0 .. Vk - 1; Vk = a skipped draw (sorts behind every row)
 };
 
 // the (walk, centre) unit's window: contexts c in [lo, hi] without i
@@ -228,12 +233,12 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
                 for (int z = 0; z < 4; z++) {
                     if (z >= npair) break;
                     const uint64_t hi32 = (uint64_t)(uint32_t)lastv[z] << 32;
-                    if (lane == 0) { q.key_out[slot] = word; q.val_out[slot] = hi32 | (uint64_t)__float_as_uint(alpha); }
+                    if (lane == 0) { q.key_out[slot] = word / q.kdiv; q.val_out[slot] = hi32 | (uint64_t)__float_as_uint(alpha); }
                     if (K <= 16) {
                         if (lane < K) {
                             int32_t t = tv[z];
                             if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
-                            q.key_out[slot + 1 + lane] = t == word ? (int32_t)p.V : t;
+                            q.key_out[slot + 1 + lane] = t == word ? q.Vk : t / q.kdiv;
                             q.val_out[slot + 1 + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);      // label 0: the sign bit
                         }
                     } else {
@@ -244,7 +249,7 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
                                 int32_t t = p.table[(sl >> 16) % (uint64_t)p.T];
                                 if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                                 if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
-                                q.key_out[slot + 1 + kd + lane] = t == word ? (int32_t)p.V : t;
+                                q.key_out[slot + 1 + kd + lane] = t == word ? q.Vk : t / q.kdiv;
                                 q.val_out[slot + 1 + kd + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);
                             }
                             s = shfl16_u64(sl, kc - 1);
@@ -257,7 +262,7 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
     }
 }
 
-// seg[r] = first position of the sorted keys that is >= r, r = 0 .. V+1  (seg[V] = number of valid items, seg[V+1] = n)
+// seg[k] = first position of the sorted keys that is >= k, k = 0 .. Vk+1  (seg[Vk] = number of valid items, seg[Vk+1] = n)
 __global__ void k_sorted_segments(const int32_t* __restrict__ keys, int64_t n, int64_t V, int64_t* seg) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > V + 1) return;
@@ -286,9 +291,9 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
     const int64_t start = chunk * q.chunk;
     if (start >= q.n_slots) return;
     const int64_t end = min(start + (int64_t)q.chunk, q.n_slots);
-    const int64_t n_valid = q.seg[p.V];
+    const int64_t n_valid = q.seg[q.Vk];
     if (!PB)            // the slots behind the valid items (skipped draws) stay invalid for the second sort
-        for (int64_t x = max(start, n_valid) + lane; x < end; x += 16) { q.key_out[x] = (int32_t)p.V; q.val_out[x] = 0; }
+        for (int64_t x = max(start, n_valid) + lane; x < end; x += 16) { q.key_out[x] = q.Vk; q.val_out[x] = 0; }
     if (start >= n_valid) return;
     const int64_t stop = min(end, n_valid);
 
@@ -297,7 +302,9 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
     const TableView scr = make_view(q.scratch, 2 * ((q.n_slots + q.chunk - 1) / q.chunk), p.stride);
     const TableView shd = make_view(q.shadow, p.V, p.stride);
 
-    int32_t cur = -1;
+    const int32_t kpart = PB ? q.kpart_ctx : q.kpart_tgt;
+#define OWN_ROW(k_) ((k_) * q.kdiv + kpart)
+    int32_t cur = -1;                              // key of the open segment
     int64_t seg_start = start;
     Row<DCH> h, d;                                 // the owned row as it moves (phase A), the delta of the open segment
     row_zero(h); row_zero(d);
@@ -310,12 +317,12 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
             if (whole) {                                                                                               \
                 if (PB) {                                                                                              \
                     Row<DCH> r0;                                                                                       \
-                    rowA_load<DCH, 0, false>(r0, own, cur, lane);                                                      \
+                    rowA_load<DCH, 0, false>(r0, own, OWN_ROW(cur), lane);                                             \
                     _Pragma("unroll") for (int c_ = 0; c_ < DCH; c_++) {                                               \
                         r0.v[c_].x += d.v[c_].x; r0.v[c_].y += d.v[c_].y; r0.v[c_].z += d.v[c_].z; r0.v[c_].w += d.v[c_].w; \
                     }                                                                                                  \
-                    rowA_store<DCH, 0, false>(r0, own, cur, lane);                                                     \
-                } else rowA_store<DCH, 0, false>(h, shd, cur, lane);                                                   \
+                    rowA_store<DCH, 0, false>(r0, own, OWN_ROW(cur), lane);                                            \
+                } else rowA_store<DCH, 0, false>(h, shd, OWN_ROW(cur), lane);                                          \
             } else rowA_store<DCH, 0, false>(d, scr, (int32_t)(2 * chunk + (seg_start == start ? 0 : 1)), lane);      \
         }                                                                                                              \
     } while (0)
@@ -345,7 +352,7 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
                     SORTED_CLOSE(idx);
                     cur = key[z]; seg_start = idx;
                     row_zero(d);
-                    if (!PB) rowA_load<DCH, 0, false>(h, own, cur, lane);
+                    if (!PB) rowA_load<DCH, 0, false>(h, own, OWN_ROW(cur), lane);
                 }
                 if (PB) {
                     row_axpy(d, __uint_as_float(vlo[z]), o[z]);
@@ -355,13 +362,14 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
                     const float g = sgns_g(f, (vlo[z] >> 31) ? 0.0f : 1.0f, fabsf(a), s_exp);
                     row_axpy(h, g, o[z]);
                     row_axpy(d, g, o[z]);
-                    if (lane == 0) { q.key_out[idx] = (int32_t)vhi[z]; q.val_out[idx] = ((uint64_t)(uint32_t)key[z] << 32) | (uint64_t)__float_as_uint(g); }
+                    if (lane == 0) { q.key_out[idx] = (int32_t)vhi[z] / q.kdiv; q.val_out[idx] = ((uint64_t)(uint32_t)OWN_ROW(key[z]) << 32) | (uint64_t)__float_as_uint(g); }
                 }
             }
         }
     }
     SORTED_CLOSE(stop);
 #undef SORTED_CLOSE
+#undef OWN_ROW
 }
 
 // rows shared by several chunks: the worker of the chunk in which such a row BEGINS adds the deltas of all its segments, in chunk
@@ -371,12 +379,13 @@ __global__ void __launch_bounds__(256) k_sorted_fixup(SortedParams q, int phase_
     const TrainParams& p = q.t;
     const int lane = threadIdx.x & 15;
     const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int64_t n_valid = q.seg[p.V];
+    const int64_t n_valid = q.seg[q.Vk];
     const int64_t start = chunk * q.chunk;
     if (start >= n_valid) return;
     const int64_t end = min(start + (int64_t)q.chunk, n_valid);
-    const int32_t r = q.key_in[end - 1];                              // the row of the chunk's last item
-    const int64_t r0 = q.seg[r], r1 = q.seg[r + 1];
+    const int32_t kr = q.key_in[end - 1];                             // the key of the chunk's last item, its row
+    const int32_t r = kr * q.kdiv + (phase_b ? q.kpart_ctx : q.kpart_tgt);
+    const int64_t r0 = q.seg[kr], r1 = q.seg[kr + 1];
     if (r1 <= end || r0 < start) return;                              // it ends here, or it began in an earlier chunk
     const TableView own = make_view(phase_b ? p.syn0 : p.syn1neg, p.V, p.stride);
     const TableView scr = make_view(q.scratch, 2 * ((q.n_slots + q.chunk - 1) / q.chunk), p.stride);
@@ -398,17 +407,17 @@ template <int DCH>
 __global__ void __launch_bounds__(256) k_sorted_commit(SortedParams q, const int64_t* seg_a) {
     const TrainParams& p = q.t;
     const int lane = threadIdx.x & 15;
-    // under the block schedule only the rows of the target partition can have moved
-    const int64_t r = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4) * max(p.part_n, 1) + (p.part_n > 1 ? p.part_tgt : 0);
-    if (r >= p.V || seg_a[r + 1] == seg_a[r]) return;
+    // (under the block schedule only the rows of the target partition have keys)
+    const int64_t kr = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (kr >= q.Vk || seg_a[kr + 1] == seg_a[kr]) return;
+    const int64_t r = kr * q.kdiv + q.kpart_tgt;
     Row<DCH> row;
     rowA_load<DCH, 0, false>(row, make_view(q.shadow, p.V, p.stride), (int32_t)r, lane);
     rowA_store<DCH, 0, false>(row, make_view(p.syn1neg, p.V, p.stride), (int32_t)r, lane);
 }
 template <int DCH>
 static void launch_commit(const SortedParams& q, const int64_t* seg_a, hipStream_t st) {
-    const int64_t rows = (q.t.V + std::max(q.t.part_n, 1) - 1) / std::max(q.t.part_n, 1);
-    hipLaunchKernelGGL((k_sorted_commit<DCH>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, q, seg_a);
+    hipLaunchKernelGGL((k_sorted_commit<DCH>), dim3((unsigned)(((int64_t)q.Vk * 16 + 255) / 256)), dim3(256), 0, st, q, seg_a);
 }
 static void launch_commit_any(int dch, const SortedParams& q, const int64_t* seg_a, hipStream_t st) {
     switch (dch) {
@@ -437,6 +446,23 @@ int64_t dge_sorted_batch_items(const dge_model* m, int part_n) {
 }
 
 struct CastI64 { __host__ __device__ int64_t operator()(int32_t x) const { return (int64_t)x; } };
+// The item sorts.  rocprim's onesweep sorts 8 key bits per pass; row numbers of 17 .. 18 bits (cfg2; a block of the 8- or 4-rank schedule) take
+// 3 passes there and 2 with 9-bit digits (scripts/micro/sort_bits.hip: 48 M items of 17 bits 1.01 ms against 1.15, 12.8 M 0.31 against 0.37;
+// 10-bit digits lose more per pass than they save).
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<512, 12>, 9,
+                                                                       rocprim::block_radix_rank_algorithm::match>> SortWide;
+static hipError_t sort_items(void* tmp, size_t& bytes, const int32_t* k_in, int32_t* k_out, const uint64_t* v_in, uint64_t* v_out, int64_t n, int end_bit, hipStream_t st) {
+    if (end_bit > 16 && end_bit <= 18) return rocprim::radix_sort_pairs<SortWide>(tmp, bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)end_bit, st);
+    return rocprim::radix_sort_pairs(tmp, bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)end_bit, st);
+}
+static size_t sort_items_tmp_bytes(int64_t cap) {
+    size_t a = 0, b = 0;
+    (void)sort_items(nullptr, a, nullptr, nullptr, nullptr, nullptr, cap, 18, 0);
+    (void)sort_items(nullptr, b, nullptr, nullptr, nullptr, nullptr, cap, 31, 0);
+    return std::max(a, b);
+}
+
 typedef hipcub::TransformInputIterator<int64_t, CastI64, const int32_t*> CountIter;      // pair counts summed in 64 bits (an epoch-long launch has > 2^31 pairs)
 
 static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
@@ -515,8 +541,10 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     if (max_slots >= 0x7fffffffll) DGE_FAIL(DGE_ERR_ARG, "update_policy 8: a mini-batch of %lld items; set fewer walks per mini-batch", (long long)max_slots);
     int chunk = 128;                     // (64 .. 256 measure alike; 512 and up lose: fewer work units than the device holds)
     if (g_dge_tuning[DGE_TUNE_SORTED_CHUNK] > 0) chunk = (int)std::min<int64_t>(g_dge_tuning[DGE_TUNE_SORTED_CHUNK], 1 << 20);
+    const int kdiv = std::max(p.part_n, 1);
+    const int64_t Vk = (m->V + kdiv - 1) / kdiv;
     int end_bit = 1;
-    while (end_bit < 31 && (1ll << end_bit) <= (int64_t)m->V) end_bit++;      // keys are 0 .. V (V = a skipped draw)
+    while (end_bit < 31 && (1ll << end_bit) <= Vk) end_bit++;                 // keys are 0 .. Vk (Vk = a skipped draw)
     if (!s->aux) {
         DGE_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
         for (int x = 0; x < 2; x++) {
@@ -538,16 +566,17 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
             if ((rc = dge_dev_alloc(&s->key1[x], (size_t)cap))) return rc;
             if ((rc = dge_dev_alloc(&s->val0[x], (size_t)cap))) return rc;
             if ((rc = dge_dev_alloc(&s->val1[x], (size_t)cap))) return rc;
-            DGE_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b, s->key0[x], s->key1[x], s->val0[x], s->val1[x], (int)std::min<int64_t>(cap, 0x7fffffff), 0, 31, st));
+            b = sort_items_tmp_bytes(cap);
             DGE_HIP(hipMalloc(&s->sort_tmp[x], b ? b : 1));
         }
         s->sort_tmp_bytes = b;
         s->cap_items = cap;
     }
-    if (m->V + 2 > s->cap_seg) {
+    if (Vk + 2 > s->cap_seg) {
+        DGE_HIP(hipStreamSynchronize(s->aux));
         dge_dev_free(s->seg); s->seg = nullptr;
-        if ((rc = dge_dev_alloc(&s->seg, 3 * ((size_t)m->V + 2)))) return rc;
-        s->cap_seg = m->V + 2;
+        if ((rc = dge_dev_alloc(&s->seg, 3 * ((size_t)Vk + 2)))) return rc;
+        s->cap_seg = Vk + 2;
     }
     if (m->V > s->cap_shadow) {
         dge_dev_free(s->shadow); s->shadow = nullptr;
@@ -564,7 +593,8 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
 
     SortedParams q;
     q.t = p; q.cnt = s->cnt; q.off = s->off; q.seg = s->seg; q.chunk = chunk; q.scratch = s->scratch; q.shadow = s->shadow;
-    int64_t* const seg_a[2] = {s->seg, s->seg + m->V + 2}; int64_t* const seg_b = s->seg + 2 * (m->V + 2);
+    q.kdiv = kdiv; q.kpart_tgt = p.part_n > 1 ? p.part_tgt : 0; q.kpart_ctx = p.part_n > 1 ? p.part_ctx : 0; q.Vk = (int32_t)Vk;
+    int64_t* const seg_a[2] = {s->seg, s->seg + Vk + 2}; int64_t* const seg_b = s->seg + 2 * (Vk + 2);
     const int dch = m->stride / 64;
     // (the offsets were read back above: everything the second stream reads — counts, offsets, walks, the unigram table — is in place)
     int64_t live = 0;
@@ -578,8 +608,8 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         q.key_out = s->key0[x]; q.val_out = s->val0[x];
         hipLaunchKernelGGL(k_sorted_emit, dim3(grid_for(q.unit1 - q.unit0 + 15, 256)), dim3(256), 0, s->aux, q);      // one 16-lane group per 16 units
         size_t b = s->sort_tmp_bytes;
-        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp[0], b, s->key0[x], s->key1[x], s->val0[x], s->val1[x], (int)n, 0, end_bit, s->aux));
-        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(m->V + 2, 256)), dim3(256), 0, s->aux, s->key1[x], n, m->V, seg_a[x]);
+        DGE_HIP(sort_items(s->sort_tmp[0], b, s->key0[x], s->key1[x], s->val0[x], s->val1[x], n, end_bit, s->aux));
+        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(Vk + 2, 256)), dim3(256), 0, s->aux, s->key1[x], n, Vk, seg_a[x]);
         DGE_HIP(hipEventRecord(s->ev_ready[x], s->aux));
         // model's stream — phase A: target rows move (into the shadow table); (context, target | g) -> (key0, val0)
         DGE_HIP(hipStreamWaitEvent(st, s->ev_ready[x], 0));
@@ -587,8 +617,8 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         launch_phase_any(dch, q, false, st);
         // sorted by context row -> (key1, val1); phase B: context rows take their sums
         b = s->sort_tmp_bytes;
-        DGE_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp[1], b, s->key0[x], s->key1[x], s->val0[x], s->val1[x], (int)n, 0, end_bit, st));
-        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(m->V + 2, 256)), dim3(256), 0, st, s->key1[x], n, m->V, seg_b);
+        DGE_HIP(sort_items(s->sort_tmp[1], b, s->key0[x], s->key1[x], s->val0[x], s->val1[x], n, end_bit, st));
+        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(Vk + 2, 256)), dim3(256), 0, st, s->key1[x], n, Vk, seg_b);
         q.seg = seg_b;
         launch_phase_any(dch, q, true, st);            // reads the target rows as they stood BEFORE the mini-batch
         launch_commit_any(dch, q, seg_a[x], st);

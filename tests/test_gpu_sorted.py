@@ -51,6 +51,21 @@ def test_owner_computes_ragged_walks_holes_and_tiny_vocabularies(dge, oracle):
         assert np.array_equal(bits(s0), bits(om.syn0)) and np.array_equal(bits(dm.syn1neg()), bits(om.syn1neg)), (NV, L, D, W, kw)
 
 
+def test_owner_computes_row_numbers_of_17_and_18_bits(dge, oracle):
+    """Vocabularies of 2^16 .. 2^18 rows are sorted with 9-bit digits (two passes instead of three): same items, same order, same bits."""
+    rng = np.random.default_rng(17)
+    for NV in (70_000, 140_000, 262_144):
+        ids = rng.integers(0, NV, (3000, 12)).astype(np.int32)
+        ids[:, 0] = rng.integers(0, 40, 3000)                      # a few busy rows whose item lists span work units
+        kw = dict(negative=5, min_count=1, epochs=1, seed=NV, table_size=100_003)
+        om = oracle.train_sgns(ids, NV, 8, 4, sorted_chunk=64, sorted_walks=1000, **kw)
+        with dge.tuning(sorted_chunk=64, sorted_walks=1000):
+            dm = dge.SgnsModel.fit(ids, dge.make_config(8, 4, NV, workers=0, update_policy=8, **kw), 0)
+        s0, vid = dm.vectors()
+        assert np.array_equal(vid, om.vocab_ids) and dm.stats()["pairs"] == om.pairs, NV
+        assert np.array_equal(bits(s0), bits(om.syn0)) and np.array_equal(bits(dm.syn1neg()), bits(om.syn1neg)), NV
+
+
 def test_owner_computes_under_the_block_schedule(dge, oracle):
     """N = 3 ranks on one device, every block a device-filling owner-computes launch: bit-identical to the oracle running the 3 x 3
     blocks one after the other with the same schedule."""
