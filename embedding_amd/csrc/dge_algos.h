@@ -235,13 +235,17 @@ DGE_HD void dge_alias_vose(const double* w, int64_t k, double total, double* pro
         alias[i] = -1; prob[i] = p;
         if (p < 1.0) scratch[ns++] = (int32_t)i; else scratch[k - 1 - (nl++)] = (int32_t)i;
     }
+    // (a large slot that stays >= 1 would go back on top of its stack and be taken again at once: it stays in registers instead)
     while (ns > 0 && nl > 0) {
-        int32_t s = scratch[--ns];
-        int32_t l = scratch[k - nl]; nl--;
-        alias[s] = l;
-        double pl = (prob[l] + prob[s]) - 1.0;
-        prob[l] = pl;
-        if (pl < 1.0) scratch[ns++] = l; else scratch[k - 1 - (nl++)] = l;
+        const int32_t l = scratch[k - nl]; nl--;
+        double pl = prob[l];
+        for (;;) {
+            const int32_t s = scratch[--ns];
+            alias[s] = l;
+            pl = (pl + prob[s]) - 1.0;
+            if (pl < 1.0) { prob[l] = pl; scratch[ns++] = l; break; }
+            if (ns == 0) { prob[l] = pl; scratch[k - 1 - (nl++)] = l; break; }
+        }
     }
     while (ns > 0) { int32_t s = scratch[--ns]; prob[s] = 1.0; }
     while (nl > 0) { int32_t l = scratch[k - nl]; nl--; prob[l] = 1.0; }

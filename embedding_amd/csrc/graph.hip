@@ -138,45 +138,131 @@ static void launch_sources(hipStream_t st, const int32_t* srcv, int64_t S, const
     hipLaunchKernelGGL(k_sources_sum, dim3(1), dim3(64), 0, st, src_w, S, stream_sum, sum_out);
 }
 
-// Vertex.initiateAliasTable for every vertex: one lane per table (J/LayeredGraph.java:197)
-__global__ void k_alias_vertices(int32_t V, const int64_t* row_ptr, const double* w, const int32_t* nbr, const double* outdeg,
-                                 double* prob, int32_t* alias, dge_slot* slots, int exact, uint64_t* bs_scratch,
-                                 int32_t* vose_scratch) {
+// dge_alias_vose (dge_algos.h) by one WAVE, for tables of thousands of slots (hub vertices of a power-law graph, the source table): the same
+// stacks, the same pops and pushes in the same order, the same arithmetic — but every value the serial loop would fetch through two dependent
+// loads per step (a stack entry, then its prob) comes from a 64-entry register window over the top of its stack, refilled by all lanes at once.
+// What a pop can see that a window cannot hold — the large that has just dropped below 1 and lies on top of the small stack — stays in
+// registers (`pend`).  All 64 lanes must call it with the same arguments; control flow is wave-uniform.
+#define ALIAS_WAVE_MIN 1024         /* tables from this size on (Vose order) take the wave form */
+__device__ __forceinline__ int32_t wave_pick(int32_t v, int idx) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(idx)); }
+__device__ __forceinline__ double wave_pick(double v, int idx) {
+    const int i = __builtin_amdgcn_readfirstlane(idx);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), i), __builtin_amdgcn_readlane(__double2loint(v), i));
+}
+__device__ void alias_vose_wave(const double* __restrict__ w, int64_t k, double total, double* prob, int32_t* alias, int32_t* scratch) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t below = (1ull << lane) - 1ull;
+    int64_t ns = 0, nl = 0;
+    for (int64_t c = 0; c < k; c += 64) {                     // the stacks in slot order: smalls up from scratch[0], larges down from scratch[k-1]
+        const int64_t i = c + lane;
+        double p = 2.0;
+        if (i < k) { p = (double)k * w[i] / total; alias[i] = -1; prob[i] = p; }
+        const uint64_t ms = __ballot(i < k && p < 1.0), ml = __ballot(i < k && !(p < 1.0));
+        if (i < k) {
+            if (p < 1.0) scratch[ns + __popcll(ms & below)] = (int32_t)i;
+            else scratch[k - 1 - (nl + __popcll(ml & below))] = (int32_t)i;
+        }
+        ns += __popcll(ms); nl += __popcll(ml);
+    }
+    __threadfence_block();
+    // windows: lane j of the small window holds stack entry sw_top - j, lane j of the large window entry lw_top + j
+    int64_t sw_top = -1, lw_top = -1; int sw_n = 0, lw_n = 0, sw_i = 0, lw_i = 0;
+    int32_t sw_id = 0, lw_id = 0; double sw_p = 0.0, lw_p = 0.0;
+    bool has_pend = false; int32_t pend_id = 0; double pend_p = 0.0;
+    while (ns > 0 && nl > 0) {
+        // pop a large
+        if (!(lw_i < lw_n && lw_top + lw_i == k - nl)) {
+            lw_top = k - nl; lw_n = (int)min((int64_t)64, nl); lw_i = 0;
+            if (lane < lw_n) { lw_id = scratch[lw_top + lane]; lw_p = prob[lw_id]; }
+        }
+        const int32_t l = wave_pick(lw_id, lw_i); double pl = wave_pick(lw_p, lw_i);
+        lw_i++; nl--;
+        for (;;) {
+            // pop a small
+            int32_t sid; double sp;
+            if (has_pend) { sid = pend_id; sp = pend_p; has_pend = false; }
+            else {
+                if (!(sw_i < sw_n && sw_top - sw_i == ns - 1)) {
+                    sw_top = ns - 1; sw_n = (int)min((int64_t)64, ns); sw_i = 0;
+                    if (lane < sw_n) { sw_id = scratch[sw_top - lane]; sw_p = prob[sw_id]; }
+                }
+                sid = wave_pick(sw_id, sw_i); sp = wave_pick(sw_p, sw_i);
+                sw_i++;
+            }
+            ns--;
+            if (lane == 0) alias[sid] = l;
+            pl = (pl + sp) - 1.0;
+            if (pl < 1.0) {                                  // the large has become a small: on top of the small stack, taken next
+                if (lane == 0) { prob[l] = pl; scratch[ns] = l; }
+                ns++; has_pend = true; pend_id = l; pend_p = pl;
+                break;
+            }
+            if (ns == 0) {                                   // no small left: back on its stack
+                if (lane == 0) { prob[l] = pl; scratch[k - 1 - nl] = l; }
+                nl++;
+                break;
+            }
+        }
+    }
+    __threadfence_block();
+    for (int64_t j = lane; j < ns; j += 64) prob[scratch[j]] = 1.0;            // left-overs: full slots
+    for (int64_t j = lane; j < nl; j += 64) prob[scratch[k - nl + j]] = 1.0;
+}
+
+// Vertex.initiateAliasTable for every vertex: one lane per table (J/LayeredGraph.java:197); hub_min > 0: tables of hub_min slots and more
+// are left to k_alias_hubs
+__global__ void k_alias_vertices(int32_t V, const int64_t* row_ptr, const double* w, const double* outdeg,
+                                 double* prob, int32_t* alias, int exact, uint64_t* bs_scratch, int32_t* vose_scratch, int64_t hub_min) {
     int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     int64_t b = row_ptr[v], k = row_ptr[v + 1] - b;
-    if (k == 0) return;
+    if (k == 0 || (hub_min > 0 && k >= hub_min)) return;
     if (exact) dge_alias_reference(w + b, k, outdeg[v], prob + b, alias + b, bs_scratch + 2 * (b / 32 + 6 * v));
     else       dge_alias_vose(w + b, k, outdeg[v], prob + b, alias + b, vose_scratch + b);
-    for (int64_t i = 0; i < k; i++) {
-        int32_t a = alias[b + i];
-        dge_slot s;
-        s.prob = prob[b + i];
-        s.nbr = nbr[b + i];
-        s.nbr_alias = a >= 0 ? nbr[b + a] : nbr[b + i];   // "no alias" -> stay in slot i
-        s.base = (uint32_t)row_ptr[s.nbr]; s.k = (uint32_t)(row_ptr[s.nbr + 1] - row_ptr[s.nbr]);
-        s.base_alias = (uint32_t)row_ptr[s.nbr_alias]; s.k_alias = (uint32_t)(row_ptr[s.nbr_alias + 1] - row_ptr[s.nbr_alias]);
-        slots[b + i] = s;
-    }
+}
+__global__ void k_hub_list(int32_t V, const int64_t* row_ptr, int64_t hub_min, int32_t* hubs, int32_t* n_hubs) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < V && row_ptr[v + 1] - row_ptr[v] >= hub_min) hubs[atomicAdd(n_hubs, 1)] = (int32_t)v;
+}
+__global__ void __launch_bounds__(64) k_alias_hubs(const int32_t* hubs, const int64_t* row_ptr, const double* w, const double* outdeg, double* prob,
+                                                   int32_t* alias, int32_t* vose_scratch) {
+    const int32_t v = hubs[blockIdx.x];
+    const int64_t b = row_ptr[v];
+    alias_vose_wave(w + b, row_ptr[v + 1] - b, outdeg[v], prob + b, alias + b, vose_scratch + b);
 }
 
 // the same pairing over the source vertices, weight = outDegree (J/LayeredGraph.java:199-225)
-__global__ void k_alias_sources(int64_t S, const double* src_w, double total, const int32_t* srcv, const int64_t* row_ptr, double* prob, int32_t* alias,
-                                dge_slot* slots, int exact, uint64_t* bs_scratch, int32_t* vose_scratch) {
-    if (blockIdx.x != 0 || threadIdx.x != 0 || S == 0) return;
+__global__ void __launch_bounds__(64) k_alias_sources(int64_t S, const double* src_w, double total, double* prob, int32_t* alias, int exact,
+                                                      uint64_t* bs_scratch, int32_t* vose_scratch) {
+    if (blockIdx.x != 0 || S == 0) return;
+    if (!exact && S >= ALIAS_WAVE_MIN) { alias_vose_wave(src_w, S, total, prob, alias, vose_scratch); return; }
+    if (threadIdx.x != 0) return;
     if (exact) dge_alias_reference(src_w, S, total, prob, alias, bs_scratch);
     else       dge_alias_vose(src_w, S, total, prob, alias, vose_scratch);
-    for (int64_t i = 0; i < S; i++) {
-        int32_t a = alias[i];
-        dge_slot s;
-        s.prob = prob[i];
-        s.nbr = srcv[i];
-        s.nbr_alias = a >= 0 ? srcv[a] : srcv[i];
-        s.base = (uint32_t)row_ptr[s.nbr]; s.k = (uint32_t)(row_ptr[s.nbr + 1] - row_ptr[s.nbr]);
-        s.base_alias = (uint32_t)row_ptr[s.nbr_alias]; s.k_alias = (uint32_t)(row_ptr[s.nbr_alias + 1] - row_ptr[s.nbr_alias]);
-        slots[i] = s;
-    }
 }
+
+// The walk slots of a finished table, one thread per slot (the pairing above is serial per table; this is not): slot e of the table that
+// begins at row_ptr[owner[e]] (owner == nullptr: one table from 0, the sources) names its neighbour, its alias' neighbour ("no alias" ->
+// stay in slot e) and both neighbours' own row bounds.
+__global__ void k_owner_mark(int32_t V, const int64_t* row_ptr, int32_t* owner) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < V && row_ptr[v + 1] > row_ptr[v]) owner[row_ptr[v]] = (int32_t)v;
+}
+__global__ void k_fill_slots(int64_t n, const int32_t* __restrict__ owner, const int64_t* __restrict__ row_ptr, const double* __restrict__ prob,
+                             const int32_t* __restrict__ alias, const int32_t* __restrict__ ids, dge_slot* __restrict__ slots) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int64_t b = owner ? row_ptr[owner[e]] : 0;
+    const int32_t a = alias[e];
+    dge_slot s;
+    s.prob = prob[e];
+    s.nbr = ids[e];
+    s.nbr_alias = a >= 0 ? ids[b + a] : s.nbr;
+    s.base = (uint32_t)row_ptr[s.nbr]; s.k = (uint32_t)(row_ptr[s.nbr + 1] - row_ptr[s.nbr]);
+    s.base_alias = (uint32_t)row_ptr[s.nbr_alias]; s.k_alias = (uint32_t)(row_ptr[s.nbr_alias + 1] - row_ptr[s.nbr_alias]);
+    slots[e] = s;
+}
+struct MaxI32 { __host__ __device__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; } };
 
 // ------------------------------------------------------------------------------------------ walk sampler
 // One draw (J/LayeredGraph.java:104-116): x -> slot -> neighbour, and the neighbour's own row bounds (b, k) for the next draw.
@@ -621,13 +707,50 @@ extern "C" int dge_graph_build_alias(dge_graph* g, int exact) {
     } else {
         if ((rc = d_vs.alloc((size_t)std::max<int64_t>(E, S) + 1))) return rc;
     }
-    if (V > 0)
-        hipLaunchKernelGGL(k_alias_vertices, dim3(grid_for(V, 64)), dim3(64), 0, g->stream, V, g->d_row_ptr, g->d_w, g->d_nbr,
-                           g->d_outdeg, g->d_prob, g->d_alias, g->d_slots, exact, d_bs.p, d_vs.p);
-    DGE_HIP(hipStreamSynchronize(g->stream));
+    if (V > 0) {
+        const int64_t hub_min = exact ? 0 : ALIAS_WAVE_MIN;
+        hipLaunchKernelGGL(k_alias_vertices, dim3(grid_for(V, 64)), dim3(64), 0, g->stream, V, g->d_row_ptr, g->d_w,
+                           g->d_outdeg, g->d_prob, g->d_alias, exact, d_bs.p, d_vs.p, hub_min);
+        if (hub_min > 0 && E >= hub_min) {
+            const int64_t max_hubs = E / hub_min;
+            dge_tmp<int32_t> d_hubs;
+            if ((rc = d_hubs.alloc((size_t)max_hubs + 1))) return rc;
+            int32_t n_hubs = 0;
+            DGE_HIP(hipMemsetAsync(d_hubs.p + max_hubs, 0, sizeof(int32_t), g->stream));
+            hipLaunchKernelGGL(k_hub_list, dim3(grid_for(V, 256)), dim3(256), 0, g->stream, V, g->d_row_ptr, hub_min, d_hubs.p, d_hubs.p + max_hubs);
+            DGE_HIP(hipMemcpyAsync(&n_hubs, d_hubs.p + max_hubs, sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+            DGE_HIP(hipStreamSynchronize(g->stream));
+            if (n_hubs > 0)
+                hipLaunchKernelGGL(k_alias_hubs, dim3((unsigned)n_hubs), dim3(64), 0, g->stream, d_hubs.p, g->d_row_ptr, g->d_w, g->d_outdeg, g->d_prob,
+                                   g->d_alias, d_vs.p);
+            DGE_HIP(hipStreamSynchronize(g->stream));
+        }
+    }
     if (S > 0)
-        hipLaunchKernelGGL(k_alias_sources, dim3(1), dim3(64), 0, g->stream, S, g->d_src_w, g->src_weight_sum, g->d_srcv, g->d_row_ptr,
-                           g->d_src_prob, g->d_src_alias, g->d_src_slots, exact, d_bs.p, d_vs.p);
+        hipLaunchKernelGGL(k_alias_sources, dim3(1), dim3(64), 0, g->stream, S, g->d_src_w, g->src_weight_sum,
+                           g->d_src_prob, g->d_src_alias, exact, d_bs.p, d_vs.p);
+    if (E > 0) {
+        // the table an edge slot belongs to: the vertices mark their first slot, a running maximum carries the mark along the row
+        dge_tmp<int32_t> d_owner_own; dge_tmp<char> d_tmp;
+        int32_t* d_owner = d_vs.p;                                        // (Vose order: the stacks are done with once the stream gets here — E + 1 ints)
+        if (!d_owner) { if ((rc = d_owner_own.alloc((size_t)E))) return rc; d_owner = d_owner_own.p; }
+        DGE_HIP(hipMemsetAsync(d_owner, 0, (size_t)E * sizeof(int32_t), g->stream));
+        hipLaunchKernelGGL(k_owner_mark, dim3(grid_for(V, 256)), dim3(256), 0, g->stream, V, g->d_row_ptr, d_owner);
+        for (int64_t e0 = 0; e0 < E; e0 += (1ll << 30)) {                 // (the scan counts in 32 bits; a later piece starts from its predecessor's last mark)
+            const int64_t ne = std::min<int64_t>(E - e0, 1ll << 30);
+            const int64_t lo = e0 > 0 ? e0 - 1 : 0;
+            size_t tb = 0;
+            DGE_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb, d_owner + lo, d_owner + lo, MaxI32(), (int)(e0 + ne - lo), g->stream));
+            if (!d_tmp.p && (rc = d_tmp.alloc(tb + 256))) return rc;
+            DGE_HIP(hipcub::DeviceScan::InclusiveScan((void*)d_tmp.p, tb, d_owner + lo, d_owner + lo, MaxI32(), (int)(e0 + ne - lo), g->stream));
+        }
+        hipLaunchKernelGGL(k_fill_slots, dim3(grid_for(E, 256)), dim3(256), 0, g->stream, E, (const int32_t*)d_owner, g->d_row_ptr, g->d_prob, g->d_alias,
+                           g->d_nbr, g->d_slots);
+        DGE_HIP(hipStreamSynchronize(g->stream));
+    }
+    if (S > 0)
+        hipLaunchKernelGGL(k_fill_slots, dim3(grid_for(S, 256)), dim3(256), 0, g->stream, S, (const int32_t*)nullptr, g->d_row_ptr, g->d_src_prob,
+                           g->d_src_alias, g->d_srcv, g->d_src_slots);
     DGE_HIP(hipStreamSynchronize(g->stream));
     DGE_HIP(hipGetLastError());
     g->alias_built = true;

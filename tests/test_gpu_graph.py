@@ -56,6 +56,37 @@ def test_alias_hub_vertex_exact_order(dge, oracle):
     assert np.array_equal(a["alias"], b["alias"]) and np.array_equal(bits(a["prob"]), bits(b["prob"]))
 
 
+@pytest.mark.parametrize("shape", ["pareto", "near_uniform", "two_values", "one_giant"])
+def test_alias_vose_tables_of_thousands_of_slots(dge, oracle, shape):
+    """Vose order on big tables (hub vertices, the source table) is built by a whole wave with register windows over the two stacks
+    (alias_vose_wave): the same arrays as the serial loop, bit for bit — hubs of 1023 / 1024 / 1025 / 5000 / 40 000 slots, 3000 sources."""
+    rng = np.random.default_rng(len(shape))
+    ks = [1023, 1024, 1025, 5000, 40_000]
+    src, dst, w = [], [], []
+    nxt = len(ks)
+    for h, k in enumerate(ks):
+        if shape == "pareto": wk = np.floor(rng.pareto(1.1, k) * 3) + 1
+        elif shape == "near_uniform": wk = 1000.0 + rng.integers(-1, 2, k)            # slots a hair under, at and over 1: long alternations
+        elif shape == "two_values": wk = np.where(rng.random(k) < 0.9, 1.0, 37.0)
+        else: wk = np.ones(k); wk[k // 3] = 50.0 * k                               # one large serves nearly every small
+        src.append(np.full(k, h, np.int32)); dst.append(np.arange(nxt, nxt + k, dtype=np.int32)); w.append(wk)
+    src = np.concatenate(src); dst = np.concatenate(dst); w = np.concatenate(w).astype(np.float64)
+    # give 3000 of the leaves an out-edge each so that the source table has 3000 slots of varied weight
+    leaves = np.arange(len(ks), len(ks) + 3000, dtype=np.int32)
+    src = np.concatenate([src, leaves]); dst = np.concatenate([dst, np.zeros(3000, np.int32)])
+    w = np.concatenate([w, np.floor(rng.pareto(1.3, 3000) * 5) + 1])
+    og, dg = build_both(oracle, dge, src, dst, w, leaves, exact=False)
+    for v in range(len(ks)):
+        a, b = og.get_alias(v), dg.get_alias(v)
+        assert np.array_equal(a["alias"], b["alias"]) and np.array_equal(bits(a["prob"]), bits(b["prob"])), (shape, v)
+    sa, sb = og.get_source_alias(), dg.get_source_alias()
+    assert np.array_equal(sa["alias"], sb["alias"]) and np.array_equal(bits(sa["prob"]), bits(sb["prob"])), shape
+    # and the walk slots built from them
+    n = 4000
+    wo = og.sample_walks(n, 3, seed=11, rng_mode=1); wd = dg.sample_walks(n, 3, seed=11, rng_mode=1)
+    assert np.array_equal(wo, wd)
+
+
 @pytest.mark.parametrize("exact", [True, False])
 def test_walks_strided_bit_exact(dge, oracle, exact):
     src, dst, w, sources = layered_graph(R=50, T=6, deg=7, seed=3)
