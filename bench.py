@@ -188,6 +188,9 @@ def main():
         delta = torch.empty(model.sync_size(), dtype=torch.float32, device=dev)
         model.snapshot()
     copy_rate = box_copy_rate(dev) if rank == 0 else None
+    row_rates = None
+    if rank == 0 and NV * (-(-D // 64) * 64) * 4 < 0xFFFFFFFF:      # (the probe addresses a table through one descriptor)
+        row_rates = model.row_rates()        # this model's own tables: random rows read / read + written back (GB/s), lock exchanges, table look-ups per s
     setup_s = time.time() - t0
 
     def step_blocks(i):
@@ -290,7 +293,8 @@ def main():
                          "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
                          "walk_kernel_ms_per_launch": st["walk_kernel_ms"] / launches,
                          "walk_steps_per_s": (B * L) / (st["walk_kernel_ms"] / launches * 1e-3) if st["walk_kernel_ms"] > 0 else None,
-                         "walk_bytes_per_step": 36, "box_copy_GBps": copy_rate},
+                         "walk_bytes_per_step": 36, "box_copy_GBps": copy_rate,
+                         "row_read_GBps": row_rates and round(row_rates[0], 1), "row_rewrite_GBps": row_rates and round(row_rates[1], 1)},
         }
         if "expect_policy" in wl and not (args.policy or args.workers or args.hs or NB > 1) and sched["update_policy"] != wl["expect_policy"]:
             print("warning: workload %s resolved to policy %d, the committed traffic profile is for policy %d" % (args.workload, sched["update_policy"], wl["expect_policy"]), file=sys.stderr)

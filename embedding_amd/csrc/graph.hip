@@ -126,12 +126,38 @@ __global__ void k_sources_gather(const int32_t* __restrict__ srcv, int64_t S, co
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < S) src_w[i] = outdeg[srcv[i]];
 }
-__global__ void k_sources_sum(const double* __restrict__ src_w, int64_t S, int stream_sum, double* sum_out) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    double s = 0.0;
-    if (stream_sum) s = dge_java8_stream_sum(src_w, S);
-    else for (int64_t i = 0; i < S; i++) s += src_w[i];
-    *sum_out = s;
+// lane idx's value of a wave-uniform idx, on every lane
+__device__ __forceinline__ int32_t wave_pick(int32_t v, int idx) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(idx)); }
+__device__ __forceinline__ double wave_pick(double v, int idx) {
+    const int i = __builtin_amdgcn_readfirstlane(idx);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), i), __builtin_amdgcn_readlane(__double2loint(v), i));
+}
+// sourceWeightSum: the additions are a chain (plain left to right, or DoubleStream.sum's compensated form, dge_java8_stream_sum) and stay
+// one; the wave loads 64 terms at a time and every lane runs the chain on registers.
+__global__ void __launch_bounds__(64) k_sources_sum(const double* __restrict__ src_w, int64_t S, int stream_sum, double* sum_out) {
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x & 63;
+    double sum = 0.0, comp = 0.0, simple = 0.0;
+    for (int64_t c = 0; c < S; c += 64) {
+        const double mine = c + lane < S ? src_w[c + lane] : 0.0;
+        const int cnt = (int)min((int64_t)64, S - c);
+        for (int j = 0; j < cnt; j++) {
+            const double x = wave_pick(mine, j);
+            if (stream_sum) {
+                const double tmp = x - comp;
+                const double velvel = sum + tmp;
+                comp = (velvel - sum) - tmp;
+                sum = velvel;
+            }
+            simple += x;
+        }
+    }
+    double r = simple;
+    if (stream_sum) {
+        const double tmp = sum + comp;
+        r = (tmp != tmp && (simple - simple) != 0.0 && simple == simple) ? simple : tmp;      // NaN result, infinite simple sum
+    }
+    if (lane == 0) *sum_out = r;
 }
 static void launch_sources(hipStream_t st, const int32_t* srcv, int64_t S, const double* outdeg, double* src_w, int stream_sum, double* sum_out) {
     if (S > 0) hipLaunchKernelGGL(k_sources_gather, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, srcv, S, outdeg, src_w);
@@ -144,11 +170,6 @@ static void launch_sources(hipStream_t st, const int32_t* srcv, int64_t S, const
 // What a pop can see that a window cannot hold — the large that has just dropped below 1 and lies on top of the small stack — stays in
 // registers (`pend`).  All 64 lanes must call it with the same arguments; control flow is wave-uniform.
 #define ALIAS_WAVE_MIN 1024         /* tables from this size on (Vose order) take the wave form */
-__device__ __forceinline__ int32_t wave_pick(int32_t v, int idx) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(idx)); }
-__device__ __forceinline__ double wave_pick(double v, int idx) {
-    const int i = __builtin_amdgcn_readfirstlane(idx);
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), i), __builtin_amdgcn_readlane(__double2loint(v), i));
-}
 __device__ void alias_vose_wave(const double* __restrict__ w, int64_t k, double total, double* prob, int32_t* alias, int32_t* scratch) {
     const int lane = threadIdx.x & 63;
     const uint64_t below = (1ull << lane) - 1ull;

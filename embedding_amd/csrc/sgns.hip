@@ -28,7 +28,7 @@
 #include "sgns_model.h"
 
 
-int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1};
+int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
@@ -452,8 +452,8 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     }
     MC(dge_dev_alloc(&m->d_locks, 2 * ((size_t)V + 1)));      // [0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows
     MH(hipMemsetAsync(m->d_locks, 0, 2 * ((size_t)V + 1) * sizeof(int), st));
-    MC(dge_dev_alloc(&m->d_counters, 2));
-    MH(hipMemsetAsync(m->d_counters, 0, 2 * sizeof(unsigned long long), st));
+    MC(dge_dev_alloc(&m->d_counters, 3));       // pairs, words, the lock kernels' walk counter
+    MH(hipMemsetAsync(m->d_counters, 0, 3 * sizeof(unsigned long long), st));
     MH(hipStreamSynchronize(st));
     MH(hipGetLastError());
 #undef MC
@@ -545,6 +545,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.words_scale = words_scale;
     p.alpha0 = m->cfg.alpha; p.min_alpha = m->cfg.min_alpha;
     p.counters = m->d_counters;
+    p.next_walk = nullptr;
     p.locks = m->d_locks;
     p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
     p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0;
@@ -590,6 +591,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
     } else workers = m->cfg.workers;
+    if (m->cfg.workers == 0 && g_dge_tuning[DGE_TUNE_WORKERS] > 0) workers = std::min<int64_t>(g_dge_tuning[DGE_TUNE_WORKERS], (n_rows + 15) / 16 * 16);     // ablation knob
     p.n_workers = workers;
     // update policy (see Policy<>, k_sgns_train_locked and dge_train_config.update_policy)
     int pol = m->cfg.update_policy;
@@ -655,6 +657,14 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     // per-segment descriptors (TableView) for tables of 4 GiB and more; DGE_TUNE_FORCE_SEGMENTS selects that code path on small
     // tables too so that the parity tests can cover it
     const bool big = (uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull || g_dge_tuning[DGE_TUNE_FORCE_SEGMENTS] > 0;
+    // Walks handed out by a launch-wide counter wherever several workers run, the order of the walks is free (not the in-order schedule) and
+    // a worker trains enough walks for the hand-out to even anything out.  Measured on one model in one process (scripts/ab_inproc.py): cfg3
+    // 415 against 426 ms per launch, cfg3_zipf 666 against 678, hierarchical softmax 3.24 against 3.28 s, atomics 914 against 925; cfg2 under
+    // atomics (6 walks per worker) 5.6 against 5.4 — there the workers keep their fixed walks.
+    if (workers > 1 && n_rows >= 32 * workers && pol != 0 && !(g_dge_tuning[DGE_TUNE_STATIC_WALKS] > 0)) {
+        p.next_walk = m->d_counters + 2;
+        DGE_HIP(hipMemsetAsync(p.next_walk, 0, sizeof(unsigned long long), st));
+    }
     EventPair ev;
     if ((rc = timing_begin(m, ev, 0))) return rc;
     switch (m->stride / 64) {
@@ -816,6 +826,96 @@ extern "C" int dge_model_stats(const dge_model* mc, dge_train_stats* out) {
     DGE_HIP(hipMemcpy(c, m->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     out->pairs = (int64_t)c[0]; out->words = (int64_t)c[1];
     out->kernel_ms = m->kernel_ms; out->walk_kernel_ms = m->walk_ms; out->launches = m->launches;
+    return DGE_OK;
+}
+
+// ---- dge_model_row_rates: how fast THIS model's memory answers the three things the lock kernel does to it — rows read at random, rows read and
+// written back (write-through stores, as a commit does), exchanges on random lock words.  Two models of one process can differ by 15 % in
+// training speed while the device's copy rate does not move (profiles/r02_box_drift.txt): the difference follows the allocation, and this
+// probe shows which access it is without training anything.  16 lanes per row, 8 rows in flight per group; tables below 4 GiB.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_probe_rows(float* t0, float* t1, int* locks, const int32_t* table, int64_t T, int64_t V, int32_t stride, int64_t reads_per_group,
+                                                    float* sink) {
+    const int lane = threadIdx.x & 15;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    uint64_t s = dge_mix64(0x9E3779B97F4A7C15ull * (uint64_t)(group + 1));
+    const TableView v0 = make_view(t0, V, stride), v1 = make_view(t1, V, stride);
+    float acc = 0.f;
+    if (MODE == 3) {
+        for (int64_t i = 0; i < reads_per_group; i += 4) {
+            int32_t t[4];
+#pragma unroll
+            for (int z = 0; z < 4; z++) { s = s * DGE_W2V_MULT + 11; t[z] = table[((s >> 16) + (uint64_t)lane * 0x9E3779B1ull) % (uint64_t)T]; }
+            acc += (float)(t[0] ^ t[1] ^ t[2] ^ t[3]);
+        }
+    } else if (MODE == 2) {
+        for (int64_t i = 0; i < reads_per_group; i++) {
+            s = s * DGE_W2V_MULT + 11;
+            const int64_t w = (int64_t)(((s >> 16) + (uint64_t)lane * 0x9E3779B1ull) % (uint64_t)(2 * V));
+            acc += (float)__hip_atomic_exchange(&locks[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        for (int64_t i = 0; i < reads_per_group; i += 8) {
+            v4u v[8]; uint32_t off[8]; uint32_t mix = 0;
+#pragma unroll
+            for (int z = 0; z < 8; z++) {
+                s = s * DGE_W2V_MULT + 11;
+                off[z] = (uint32_t)((s >> 16) % (uint64_t)V) * v0.row_bytes + (uint32_t)lane * 16u;
+                v[z] = __builtin_amdgcn_raw_buffer_load_b128((z & 1) ? v1.rsrc : v0.rsrc, (int)off[z], 0, 0);
+                for (uint32_t c = 256; c < v0.row_bytes; c += 256) {
+                    const v4u u = __builtin_amdgcn_raw_buffer_load_b128((z & 1) ? v1.rsrc : v0.rsrc, (int)(off[z] + c), 0, 0);
+                    mix ^= u.x;
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < 8; z++) {
+                acc += __uint_as_float(v[z].x ^ mix);
+                if (MODE == 1) {           // the same bytes back, write-through (aux 16 = sc1), every 256-byte piece of the row
+                    for (uint32_t c = 0; c < v0.row_bytes; c += 256) {
+                        const v4u u = c ? __builtin_amdgcn_raw_buffer_load_b128((z & 1) ? v1.rsrc : v0.rsrc, (int)(off[z] + c), 0, 0) : v[z];
+                        __builtin_amdgcn_raw_buffer_store_b128(u, (z & 1) ? v1.rsrc : v0.rsrc, (int)(off[z] + c), 0, 16);
+                    }
+                }
+            }
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;                 // keeps the loads alive
+}
+
+extern "C" int dge_model_row_rates(dge_model* m, double* read_gb_per_s, double* rewrite_gb_per_s, double* lock_exchanges_per_s, double* table_lookups_per_s) {
+    if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_row_rates: null model");
+    if ((uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull) DGE_FAIL(DGE_ERR_ARG, "dge_model_row_rates: tables of 4 GiB and more are not probed");
+    DGE_HIP(hipSetDevice(m->device));
+    int rc = drain_events(m);
+    if (rc) return rc;
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    const int64_t groups = 256 * 16 * 16, reads = 256;     // 65 536 groups x 256 rows
+    dge_tmp<float> sink;
+    if ((rc = sink.alloc(4))) return rc;
+    hipEvent_t e0, e1;
+    DGE_HIP(hipEventCreate(&e0)); DGE_HIP(hipEventCreate(&e1));
+    double best[4] = {0, 0, 0, 0};
+    for (int mode = 0; mode < 4; mode++) {
+        for (int r = 0; r < 3; r++) {
+            DGE_HIP(hipEventRecord(e0, m->stream));
+            const dim3 grid((unsigned)(groups * 16 / 256));
+#define PROBE(M) hipLaunchKernelGGL(k_probe_rows<M>, grid, dim3(256), 0, m->stream, m->d_syn0, m->d_syn1neg, m->d_locks, m->d_table, m->T, m->V, m->stride, reads, sink.p)
+            if (mode == 0) PROBE(0); else if (mode == 1) PROBE(1); else if (mode == 2) PROBE(2); else PROBE(3);
+#undef PROBE
+            DGE_HIP(hipEventRecord(e1, m->stream));
+            DGE_HIP(hipEventSynchronize(e1));
+            float ms = 0.f; DGE_HIP(hipEventElapsedTime(&ms, e0, e1));
+            const double n = (double)groups * reads;
+            const double rate = mode >= 2 ? n * 16.0 / (ms * 1e-3) : n * m->stride * 4.0 * (mode == 1 ? 2.0 : 1.0) / (ms * 1e-3) / 1e9;
+            if (rate > best[mode]) best[mode] = rate;
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    DGE_HIP(hipGetLastError());
+    if (read_gb_per_s) *read_gb_per_s = best[0];
+    if (rewrite_gb_per_s) *rewrite_gb_per_s = best[1];
+    if (lock_exchanges_per_s) *lock_exchanges_per_s = best[2];
+    if (table_lookups_per_s) *table_lookups_per_s = best[3];
     return DGE_OK;
 }
 

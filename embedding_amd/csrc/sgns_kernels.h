@@ -35,6 +35,8 @@ struct TrainParams {
     float alpha0, min_alpha;
     int64_t n_workers;
     unsigned long long* counters;
+    unsigned long long* next_walk;   // lock kernels: walks are handed out in order, one at a time (zero before every launch): worker w starts on walk w, the
+                                     // k-th request gets walk n_workers + k.  nullptr: worker w takes walks w, w + n_workers, ...
     int* locks;               // one commit-lock word per syn1neg row (all zero between launches)
     float* syn1;              // hierarchical softmax: inner-node rows, Huffman paths (null when off)
     const int64_t* hs_off; const int32_t* hs_points; const uint64_t* hs_codes;
@@ -384,8 +386,9 @@ k_sgns_train(TrainParams p) {
     int nx_len = 0; int64_t nx_wb = 0; int32_t nx0 = -1, nx1 = -1, nx2 = -1, nx3 = -1;
 
     // ---- per-worker state: walk w, centre i, next context c (contexts are c..c_hi without i)
-    int64_t w = (HOT && worker >= p.n_workers) ? p.n_rows - p.n_workers : worker - p.n_workers;   // surplus workers find no walk
-    if (PART) walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
+    // (the next walk: the worker's own number first, then — p.next_walk set — whatever the launch-wide counter hands out, see k_sgns_train_locked)
+    int64_t w = -1, w_next = (HOT && worker >= p.n_workers) ? p.n_rows : worker;                  // surplus workers find no walk
+    if (PART) walk_fetch(p, w_next, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
     int len = 0, i = 0, c = 1, c_hi = 0;
     int32_t tk0 = -1, tk1 = -1, tk2 = -1, tk3 = -1;       // the walk's tokens: lane j holds tokens j, j+16, j+32, j+48
     const int32_t* sen = p.sen;
@@ -414,12 +417,17 @@ k_sgns_train(TrainParams p) {
             DGE_CLOSE_CENTRE();
             if (PART) i = first_bit_from(tgt_mask, i + 1, len); else i++;
             while (i >= len) {                             // next walk of this worker (empty walks are skipped)
-                w += p.n_workers;
+                w = w_next;
                 if (w >= p.n_rows) { alive = false; break; }
+                if (p.next_walk) {
+                    unsigned long long t = 0;
+                    if (lane == 0) t = atomicAdd(p.next_walk, 1ull);
+                    w_next = (int64_t)shfl16_u64(t, 0) + p.n_workers;
+                } else w_next = w + p.n_workers;
                 int64_t wb_next = 0;
                 if (PART) {                                // prefetched while the previous walk was trained
                     len = nx_len; wb_next = nx_wb; tk0 = nx0; tk1 = nx1; tk2 = nx2; tk3 = nx3;
-                    walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
+                    walk_fetch(p, w_next, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
                 } else len = (int)p.len[w];
                 i = 0;
                 if (len > 0) {
@@ -752,7 +760,9 @@ k_sgns_train_locked(TrainParams p) {
     const bool toks_in_regs = L <= 64;
     unsigned long long my_pairs = 0, my_words = 0;
 
-    int64_t w = worker - p.n_workers;
+    // A worker's next walk: its own number first, then whatever the launch-wide counter hands out — the workers of a slower compute unit
+    // (consecutive processes, and two models of one process, differ: profiles/r02_box_drift.txt) take fewer walks instead of finishing late.
+    int64_t w = -1, w_next = worker;
     int len = 0, i = 0, c = 1, c_hi = 0;
     int32_t tk0 = -1, tk1 = -1, tk2 = -1, tk3 = -1;
     const int32_t* sen = p.sen;
@@ -770,7 +780,7 @@ k_sgns_train_locked(TrainParams p) {
     int32_t last = 0;
     uint64_t ctx_mask = 0, tgt_mask = 0, pair_mask = 0, s_centre = 0;     // PART: see k_sgns_train
     int nx_len = 0; int64_t nx_wb = 0; int32_t nx0 = -1, nx1 = -1, nx2 = -1, nx3 = -1;
-    if (PART) walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
+    if (PART) walk_fetch(p, w_next, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
 
 #define LK_TOK(idx) walk_tok(toks_in_regs, sen, (idx), tk0, tk1, tk2, tk3)
     // positive target (label 1): the centre's row lives in registers for all its contexts, its accumulated delta in LDS
@@ -803,12 +813,17 @@ k_sgns_train_locked(TrainParams p) {
             LK_CLOSE_CENTRE();
             if (PART) i = first_bit_from(tgt_mask, i + 1, len); else i++;
             while (i >= len) {
-                w += p.n_workers;
+                w = w_next;
                 if (w >= p.n_rows) { alive = false; break; }
+                if (p.next_walk) {
+                    unsigned long long t = 0;
+                    if (lane == 0) t = atomicAdd(p.next_walk, 1ull);
+                    w_next = (int64_t)shfl16_u64(t, 0) + p.n_workers;
+                } else w_next = w + p.n_workers;
                 int64_t wb_next = 0;
                 if (PART) {                                // prefetched while the previous walk was trained
                     len = nx_len; wb_next = nx_wb; tk0 = nx0; tk1 = nx1; tk2 = nx2; tk3 = nx3;
-                    walk_fetch(p, w + p.n_workers, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
+                    walk_fetch(p, w_next, L, lane, nx_len, nx_wb, nx0, nx1, nx2, nx3);
                 } else len = (int)p.len[w];
                 i = 0;
                 if (len > 0) {

@@ -297,6 +297,12 @@ class SgnsModel:
         check(lib.dge_model_table(self._h, C.byref(p), C.byref(T)))
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(T.value,)).copy()
 
+    def row_rates(self):
+        """(GB/s of random row reads, GB/s of random row read + write-back, lock-word exchanges per second, unigram-table look-ups per
+        second) on this model's own memory (diagnostic: include/dge.h, dge_model_row_rates)."""
+        v = [C.c_double(0) for _ in range(4)]
+        check(lib.dge_model_row_rates(self._h, *[C.byref(x) for x in v])); return tuple(x.value for x in v)
+
     def stats(self):
         s = TrainStats()
         check(lib.dge_model_stats(self._h, C.byref(s)))
@@ -344,7 +350,7 @@ class SgnsModel:
         check(lib.dge_model_import_delta(self._h, _dev_ptr(d_buf), float(scale)))
 
 
-TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5}      # include/dge.h: DGE_TUNE_*
+TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7}      # include/dge.h: DGE_TUNE_*
 
 
 class tuning:

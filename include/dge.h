@@ -222,6 +222,12 @@ int  dge_model_huffman(dge_model* m, const int64_t** offsets, const int32_t** po
 int  dge_model_counts(dge_model* m, const int64_t** counts);
 int  dge_model_table(dge_model* m, const int32_t** table, int64_t* table_size);
 int  dge_model_stats(const dge_model* m, dge_train_stats* out);
+/* Diagnostic: how fast this model's memory answers the four things the lock kernels do to it, measured on the model's stream (tables below
+   4 GiB; the rewrite leaves every value as it was; any output may be NULL): GB/s of rows read at random, GB/s (read + written) of rows read and
+   stored back write-through, exchanges per second on random lock words, look-ups per second in the unigram table.  Consecutive processes on one box — and two models of one process —
+   differ by up to 15 % in training speed with the device's copy rate unchanged (profiles/r02_box_drift.txt); the difference follows the
+   allocation and shows here without training anything. */
+int  dge_model_row_rates(dge_model* m, double* read_gb_per_s, double* rewrite_gb_per_s, double* lock_exchanges_per_s, double* table_lookups_per_s);
 int  dge_model_reset_stats(dge_model* m);
 /* what the latest training launch resolved `update_policy` 0 / `workers` 0 to: the policy that ran (0 = in-order plain),
  * the concurrent workers, and for policy 7 the head rows kept out of the lock protocol */
@@ -301,7 +307,9 @@ enum {
     DGE_TUNE_SEGMENT_SHIFT = 3,   /* rows per descriptor segment = 2^value (with FORCE_SEGMENTS: many segments on a small table) */
     DGE_TUNE_SORTED_CHUNK = 4,    /* update_policy 8: items per work unit (default 128); a row's item list longer than what is left of a unit is split */
     DGE_TUNE_SORTED_WALKS = 5,    /* update_policy 8: walks per synchronous mini-batch (default: as many as the item buffers hold) */
-    DGE_TUNE_COUNT = 6
+    DGE_TUNE_WORKERS = 6,         /* workers = 0 (fill the device): this many concurrent walks instead of the count the library derives */
+    DGE_TUNE_STATIC_WALKS = 7,    /* > 0: the lock kernels' worker w trains walks w, w + workers, ... instead of taking them from a launch-wide counter */
+    DGE_TUNE_COUNT = 8
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
 

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Collect the evidence behind one bench line on the GPU box:  scripts/collect_profiles.sh <tag> <kernel-substring> [bench.py args...]
-#   gpurun_out/prof_<tag>/bench.json            the bench line (HIP-event timing, cpu baseline skipped)
+#   gpurun_out/prof_<tag>/bench.json            the bench line printed BY THE PROFILED RUN (HIP-event timing, cpu baseline skipped): the same
+#                                               process as kernel_stats.csv, so the two must agree
+#   gpurun_out/prof_<tag>/bench_unprofiled.json the same command without the profiler, run second (consecutive processes on a box differ: profiles/r02_box_drift.txt)
 #   gpurun_out/prof_<tag>/kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command
 #   gpurun_out/prof_<tag>/pmc.csv               FETCH_SIZE / WRITE_SIZE+TCC_EA0_ATOMIC / TCC_EA0_RDREQ+WRREQ, one pass each, digested per dispatch
 # Counters are collected in their own runs with --kernel-trace only (MI355X_MICROARCH.md, HBM section).
@@ -8,10 +10,11 @@ set -e
 tag=$1; needle=$2; shift 2
 root=$(pwd); out=$root/gpurun_out/prof_$tag; mkdir -p $out
 export TMPDIR=/tmp
-python3 bench.py --no-cpu-baseline --steps 4 --warmup 1 "$@" > $out/bench.json 2> $out/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 $root/bench.py --no-cpu-baseline --steps 4 --warmup 1 "$@" > $out/stats.log 2>&1
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+grep '^{"metric"' $out/stats.log | tail -1 > $out/bench.json
+python3 $root/bench.py --no-cpu-baseline --steps 4 --warmup 1 "$@" > $out/bench_unprofiled.json 2> $out/bench.err
 i=0
 for ctr in "FETCH_SIZE" "WRITE_SIZE TCC_EA0_ATOMIC_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   name=$(echo $ctr | cut -d' ' -f1)

@@ -609,3 +609,13 @@ def test_block_schedule_hogwild_policies(dge, oracle):
         m.train(corpus)
     with pytest.raises(dge.DgeError):
         m.set_partition(2, 2, 0)
+
+
+def test_row_rate_probe_leaves_the_model_as_it_was(dge, oracle):
+    """dge_model_row_rates (diagnostic): four positive rates, and the rewrite pass stores every row back unchanged."""
+    walks, NV = _walks(oracle, dge, n=600)
+    m = dge.SgnsModel.fit(walks, dge.make_config(128, 5, NV, negative=5, min_count=1, epochs=1, seed=3, workers=0), 0)
+    s0, s1 = m.vectors()[0].copy(), m.syn1neg().copy()
+    rates = m.row_rates()
+    assert len(rates) == 4 and all(r > 0 for r in rates)
+    assert np.array_equal(s0.view(np.uint32), m.vectors()[0].view(np.uint32)) and np.array_equal(s1.view(np.uint32), m.syn1neg().view(np.uint32))
