@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--force-exchange", action="store_true", help="run the delta exchange even with one rank (plumbing check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (debugging the multi-rank plumbing)")
+    ap.add_argument("--placement-trials", type=int, default=3,
+                    help="models created side by side before the timed region, one launch timed on each, the fastest kept (where the driver "
+                         "puts the tables is worth up to 15 %%: profiles/r02_box_drift.txt); 1 = the first model, whatever it got")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="dge_set_tuning knob for experiments (hot_rows, hs_drain, sorted_chunk, sorted_walks, ...)")
     ap.add_argument("--rendezvous-check", action="store_true",
@@ -180,6 +183,23 @@ def main():
         part_buf = torch.empty(pf, dtype=torch.float32, device=dev)
         recv_buf = torch.empty(pf, dtype=torch.float32, device=dev)
         stage("block schedule: %d ranks, global batch %d walks, partition buffers %.0f MB" % (NB, BG, pf * 4 / 1e6))
+    # start-up placement trials (SgnsModel.create_placed): the same launch the steps will run, on models created side by side; the fastest stays
+    trial_ms = None
+    if args.placement_trials > 1:
+        def probe(m):
+            if blocks:
+                m.set_partition(NB, rank if N > 1 else 0, rank if N > 1 else 0)
+            ms = float("inf")
+            for _ in range(2):                                 # (the first launch of a model also allocates its work buffers)
+                m.reset_stats()
+                m.train(corpus, 0, BG if blocks else B, walk_index_base=0, epoch=0, words_before=0, words_scale=1.0, total_walks=epoch_walks)
+                ms = min(ms, m.stats()["kernel_ms"])
+            if blocks:
+                m.set_partition(1)
+            m.reset_stats()
+            return ms
+        model, trial_ms = E.SgnsModel.create_placed(cfg, counts, local_rank, probe, trials=args.placement_trials, first=model)
+        stage("placement trials: %s ms per launch, kept the fastest" % ", ".join("%.1f" % x for x in trial_ms))
     exchange = (N > 1 and not blocks) or args.force_exchange
     if exchange and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
@@ -282,7 +302,7 @@ def main():
             "config": {"workload": wl["name"], "vertices": NV, "edges": int(n_edges), "timeslices": T, "dim": D,
                        "negatives": K, "walk_len": L, "window": L, "walks_per_step_per_gpu": B,
                        "pairs_per_step_per_gpu": st["pairs"] / args.steps, "vocabulary": int((counts >= 2).sum().item()),
-                       "sgns_workers": args.workers, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, syn1neg partitions passed round a ring" % N if blocks and N > 1
+                       "sgns_workers": args.workers, "placement_trial_ms": trial_ms and [round(x, 1) for x in trial_ms], "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, syn1neg partitions passed round a ring" % N if blocks and N > 1
                                        else "SIMULATED rank 0 of a %d-rank block schedule on one GPU (value = this rank's share only)" % NB if blocks
                                        else "walk-shard x%d, RCCL all-reduce of deltas per step (comparison mode)" % N if N > 1 else "1 GPU"),
                        "setup_s": round(setup_s, 1)},

@@ -209,6 +209,23 @@ class SgnsModel:
         return cls(h, int(device), cfg)
 
     @classmethod
+    def create_placed(cls, cfg, d_counts, device, probe, trials=3, first=None):
+        """Start-up placement trials.  Where the driver puts a model's tables decides its training speed by up to 15 % (two models of one
+        process differ reproducibly, a model freed and re-created in the same memory does not: profiles/r02_box_drift.txt), and no cheap probe
+        of the memory predicts it — so: create `trials` models side by side (the earlier ones kept, or the next would get their memory
+        back), time `probe(model) -> milliseconds` on each (one launch of the caller's own workload), keep the fastest, free the others.
+        -> (model, [milliseconds of every trial])."""
+        models = [first if first is not None else cls.create(cfg, d_counts, device)]
+        ms = [float(probe(models[0]))]
+        for _ in range(max(int(trials), 1) - 1):
+            models.append(cls.create(cfg, d_counts, device)); ms.append(float(probe(models[-1])))
+        best = min(range(len(ms)), key=ms.__getitem__)
+        for i, m in enumerate(models):
+            if i != best:
+                m.close()
+        return models[best], ms
+
+    @classmethod
     def fit(cls, walks, cfg, device=0):
         """w2v.fit() one-shot: walks is a host int32 [n x L] array or a WalkCorpus."""
         h = C.c_void_p(0)
