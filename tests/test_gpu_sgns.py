@@ -619,3 +619,38 @@ def test_row_rate_probe_leaves_the_model_as_it_was(dge, oracle):
     rates = m.row_rates()
     assert len(rates) == 4 and all(r > 0 for r in rates)
     assert np.array_equal(s0.view(np.uint32), m.vectors()[0].view(np.uint32)) and np.array_equal(s1.view(np.uint32), m.syn1neg().view(np.uint32))
+
+
+def test_counter_hand_out_and_fixed_walks_train_the_same_pairs(dge, oracle):
+    """Lock and atomics kernels take their walks from a launch-wide counter when a worker has many walks to train (>= 32 per worker), or
+    walks w, w + workers, ... (dge_set_tuning STATIC_WALKS): the same pairs and words either way, finite tables, and the same quality."""
+    from helpers import link_auc
+    walks, NV = _walks(oracle, dge, R=60, T=6, n=40_000, seed=4)
+    for pol in (5, 2):
+        res = []
+        for static in (0, 1):
+            cfg = dge.make_config(64, 5, NV, negative=5, min_count=1, epochs=1, seed=7, workers=256, update_policy=pol)
+            with dge.tuning(static_walks=static):
+                m = dge.SgnsModel.fit(walks, cfg, 0)
+            st = m.stats(); s0, vid = m.vectors()
+            assert np.isfinite(s0).all() and np.isfinite(m.syn1neg()).all()
+            res.append((st["pairs"], st["words"], link_auc(s0, m.syn1neg(), vid, walks[:4000], 60)))
+        assert res[0][:2] == res[1][:2], (pol, res)
+        assert abs(res[0][2] - res[1][2]) < 0.02, (pol, res)
+
+
+def test_placement_trials_keep_the_fastest_model(dge, oracle):
+    """SgnsModel.create_placed: `trials` models side by side, the caller's probe on each, the fastest kept and the others closed."""
+    import torch
+    walks, NV = _walks(oracle, dge, n=2000)
+    corpus = dge.WalkCorpus.from_host(walks, 0)
+    counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0"); corpus.count_tokens(NV, counts)
+    cfg = dge.make_config(64, 5, NV, negative=5, min_count=1, epochs=1, seed=7, workers=0)
+    seen = []
+    fake = iter([5.0, 3.0, 4.0])
+    def probe(m):
+        m.train(corpus); seen.append(m); return next(fake)
+    best, ms = dge.SgnsModel.create_placed(cfg, counts, 0, probe, trials=3)
+    assert ms == [5.0, 3.0, 4.0] and best is seen[1] and len(seen) == 3
+    assert best.stats()["pairs"] > 0                       # alive; the other two are closed
+    assert all(m._h is None or not m._h for m in (seen[0], seen[2]))
