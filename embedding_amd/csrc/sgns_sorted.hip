@@ -432,7 +432,8 @@ static void launch_commit_any(int dch, const SortedParams& q, const int64_t* seg
 
 // Items of one synchronous mini-batch.  Within a mini-batch the context rows are frozen and every row takes its terms without feedback
 // from the other side, so the size is set by TERMS PER LIVE ROW: measured (scripts/quality_sorted.py, profiles/r02_quality_sorted.txt)
-// the link-prediction AUC equals the atomics schedule's up to ~120 items per row and mini-batch, slips at ~460 and collapses at ~2300 —
+// the link-prediction AUC equals the atomics schedule's up to ~120 items per row and mini-batch, slips by 0.001 per ~70 items beyond and
+// collapses between 320 and 390 (8 ranks: 73 ms per episode at 128 items per row, 69 at 256 — not worth the margin) —
 // and the HOTTEST row counts, not the average one: on a Zipf-popular graph a head row took > 1e5 terms of a 96-per-row mini-batch and
 // the tables went to NaN within an epoch.  Hence: 128 items per live row, at most 2048 for the hottest row, and no mini-batch below 1e6
 // items (the two sorts and ~16 launches per mini-batch need that much to pay): 0 = this vocabulary is too skewed or too small.

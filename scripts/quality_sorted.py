@@ -25,7 +25,7 @@ n = 10 * NV
 corpus = g.sample_walks_device(n, L, seed=5)
 test = g.sample_walks(100_000, L, seed=99)
 counts = torch.zeros(NV, dtype=torch.int64, device=dev); corpus.count_tokens(NV, counts)
-runs = [(2, None), (8, 100_000), (8, 20_000), (8, 5_000), (8, 1_000)]
+runs = [(2, None)] + [(8, int(x)) for x in (sys.argv[1:] or [100_000, 20_000, 5_000, 1_000])]
 for pol, per in runs:
     cfg = E.make_config(D, L, NV, negative=K, workers=0, update_policy=pol)
     with E.tuning(**({"sorted_walks": per} if per else {})):
