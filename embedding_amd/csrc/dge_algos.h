@@ -261,7 +261,7 @@ DGE_HD void dge_alias_vose(const double* w, int64_t k, double total, double* pro
 #include <stddef.h>
 #include <vector>
 inline int dge_huffman_paths(const int64_t* counts, int64_t V, std::vector<int64_t>& off, std::vector<int32_t>& points,
-                             std::vector<uint64_t>& codes) {
+                             std::vector<uint64_t>& codes, std::vector<int64_t>* node_weight = nullptr) {
     off.assign((size_t)V + 1, 0); points.clear(); codes.assign((size_t)V, 0);
     if (V < 2) return 0;
     const int64_t n_inner = V - 1;
@@ -279,6 +279,7 @@ inline int dge_huffman_paths(const int64_t* counts, int64_t V, std::vector<int64
                                           : weight[(size_t)a] + (node < V ? counts[node] : weight[(size_t)(node - V)]);
         }
     }
+    if (node_weight) *node_weight = weight;                // tokens below inner node a: non-decreasing in a (the merge takes the two lightest)
     // depth of every inner node from the root (row V-2), parents are created after their children
     std::vector<int32_t> depth((size_t)n_inner, 0);
     for (int64_t a = n_inner - 2; a >= 0; a--) depth[(size_t)a] = depth[(size_t)up[(size_t)(V + a)]] + 1;

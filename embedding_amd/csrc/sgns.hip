@@ -28,7 +28,7 @@
 #include "sgns_model.h"
 
 
-int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
+int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
@@ -441,7 +441,12 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     if (V) hipLaunchKernelGGL(k_init_syn0, dim3(grid_for(V, 256)), dim3(256), 0, st, m->d_syn0, V, m->D, m->stride, cfg->seed);
     if (cfg->use_hs) {
         // inner-node table (V rows allocated, V-1 used: the tables stay the same size for the delta exchange) and paths
-        const int longest = dge_huffman_paths(m->h_counts.data(), V, m->h_hs_off, m->h_hs_points, m->h_hs_codes);
+        std::vector<int64_t> node_w;
+        const int longest = dge_huffman_paths(m->h_counts.data(), V, m->h_hs_off, m->h_hs_points, m->h_hs_codes, &node_w);
+        // cold inner nodes: on fewer than 2e-5 of all paths (their weights ascend with the node number: a prefix)
+        { int64_t tot = 0; for (int64_t c : m->h_counts) tot += c;
+          const int64_t limit = (int64_t)((double)tot * 2e-5);
+          m->hs_cold_auto = (int32_t)(std::upper_bound(node_w.begin(), node_w.end(), limit) - node_w.begin()); }
         MC(dge_dev_alloc(&m->d_syn1, tab + 64));
         MH(hipMemsetAsync(m->d_syn1, 0, (tab + 64) * sizeof(float), st));
         if (longest > 40) { model_release(m); delete m; DGE_FAIL(DGE_ERR_ARG, "dge_model_create: a Huffman code of %d bits exceeds word2vec's MAX_CODE_LENGTH 40", longest); }
@@ -548,7 +553,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.next_walk = nullptr;
     p.locks = m->d_locks;
     p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
-    p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0;
+    p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0; p.hs_cold = 0;
     p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt; p.syn0_free = 0;
     p.big_seg_shift = 0;
     p.filler_row = (int32_t)(0xFFFFFFF0u / ((uint32_t)m->stride * 4u)) - 1;      // offset + the largest in-row displacement stays below 2^32
@@ -648,6 +653,9 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
             p.hs_hot0 = (int32_t)(std::max<int64_t>(m->V - 1, 0) - p.hs_n_hot);
             p.hs_drain = 64;
             if (g_dge_tuning[DGE_TUNE_HS_DRAIN] >= 1) p.hs_drain = (int32_t)g_dge_tuning[DGE_TUNE_HS_DRAIN];      // ablation knob
+            // the cold end of the tree: plain read-modify-write instead of atomics (see k_sgns_train)
+            p.hs_cold = (int32_t)std::min<int64_t>(m->hs_cold_auto, p.hs_hot0);
+            if (g_dge_tuning[DGE_TUNE_HS_COLD] >= 0) p.hs_cold = (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_HS_COLD], p.hs_hot0);
             shmem = (size_t)p.hs_n_hot * (size_t)row_b;
         }
     }

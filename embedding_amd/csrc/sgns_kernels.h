@@ -34,6 +34,7 @@ struct TrainParams {
     double words_scale;
     float alpha0, min_alpha;
     int64_t n_workers;
+    int32_t hs_cold;          // hierarchical softmax under atomics: inner nodes [0, hs_cold) are updated by plain read-modify-write
     unsigned long long* counters;
     unsigned long long* next_walk;   // lock kernels: walks are handed out in order, one at a time (zero before every launch): worker w starts on walk w, the
                                      // k-th request gets walk n_workers + k.  nullptr: worker w takes walks w, w + n_workers, ...
@@ -512,7 +513,13 @@ k_sgns_train(TrainParams p) {
                                 row_axpy(neu, g, rr[q]);
                                 if (P::ATOMIC) {
                                     if (tg[q] >= p.hs_hot0) hot_add<DCH>(s_hot, s_hot_cnt, tg[q] - p.hs_hot0, p.hs_drain, syn1, tg[q], lane, g, l1);
-                                    else row_atomic_axpy(syn1, tg[q], lane, g, l1);
+                                    else if (tg[q] < p.hs_cold) {
+                                        // a cold inner node (on < 2e-5 of the paths: two workers meet on it within a read-modify-write
+                                        // less than once in 200 updates): the row is already here for the dot product, its update goes
+                                        // back as a write-through store — 512 B at the plain rate instead of 512 B at the atomic rate
+                                        row_axpy(rr[q], g, l1);
+                                        row_store<DCH, 16, BIG>(rr[q], syn1, tg[q], lane);
+                                    } else row_atomic_axpy(syn1, tg[q], lane, g, l1);
                                 } else {
                                     row_axpy(rr[q], g, l1);
                                     row_store<DCH, P::STORE_AUX, BIG>(rr[q], syn1, tg[q], lane);

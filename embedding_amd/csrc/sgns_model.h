@@ -37,6 +37,7 @@ struct dge_model {
     int64_t* d_counts = nullptr;
     int32_t* d_remap = nullptr;
     int32_t* d_table = nullptr;
+    int32_t hs_cold_auto = 0;                   // hierarchical softmax: inner nodes [0, hs_cold_auto) are each on fewer than 2e-5 of the paths
     float* d_exp = nullptr;
     // per-call work buffers
     int64_t cap_rows = 0; int32_t cap_L = 0;

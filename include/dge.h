@@ -309,7 +309,8 @@ enum {
     DGE_TUNE_SORTED_WALKS = 5,    /* update_policy 8: walks per synchronous mini-batch (default: as many as the item buffers hold) */
     DGE_TUNE_WORKERS = 6,         /* workers = 0 (fill the device): this many concurrent walks instead of the count the library derives */
     DGE_TUNE_STATIC_WALKS = 7,    /* > 0: the lock kernels' worker w trains walks w, w + workers, ... instead of taking them from a launch-wide counter */
-    DGE_TUNE_COUNT = 8
+    DGE_TUNE_HS_COLD = 8,         /* hierarchical softmax under atomics: inner nodes [0, value) take plain read-modify-write (default: those on < 2e-5 of the paths) */
+    DGE_TUNE_COUNT = 9
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
 

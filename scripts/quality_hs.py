@@ -43,9 +43,11 @@ o8 = O.train_sgns(walks, NV, D, L, negative=K, threads=8, table_size=10_000_000,
 print("oracle HS 8thr:", metrics(o8.syn0, o8.syn1neg, o8.vocab_ids), "median cos vs seq %.3f" % float(np.median(cosine_rows(o8.syn0, om.syn0))), flush=True)
 ons = O.train_sgns(walks, NV, D, L, negative=K, threads=8, table_size=10_000_000, arith=0)
 print("oracle NS-only 8thr:", metrics(ons.syn0, ons.syn1neg, ons.vocab_ids), flush=True)
-for workers, load in ((0, "1"), (0, "16"), (0, "64"), (0, "256"), (0, "1024"), (1024, "64"), (64, "64")):
-    E.lib.dge_set_tuning(1, int(load))            # DGE_TUNE_HS_DRAIN
-    cfg = E.make_config(D, L, NV, negative=K, workers=workers, table_size=10_000_000, use_hs=True)
-    dm = E.SgnsModel.fit(walks, cfg, 0); syn0, vid = dm.vectors(); st = dm.stats()
-    print("gpu HS workers", workers, "drain", load, "pairs", st["pairs"], "kernel_ms %.1f" % st["kernel_ms"], metrics(syn0, dm.syn1neg(), vid),
+# (drain period of the LDS accumulators near the root, cold = inner nodes updated by plain read-modify-write instead of atomics: -1 = the
+#  library's rule (nodes on < 2e-5 of the paths), 0 = none, large = every node outside the LDS accumulators)
+for workers, load, cold in ((0, "64", -1), (0, "64", 0), (0, "64", 1 << 30), (0, "1", -1), (0, "16", -1), (0, "256", -1), (0, "1024", -1), (1024, "64", -1), (64, "64", -1)):
+    with E.tuning(hs_drain=int(load), **({"hs_cold": cold} if cold >= 0 else {})):
+        cfg = E.make_config(D, L, NV, negative=K, workers=workers, table_size=10_000_000, use_hs=True)
+        dm = E.SgnsModel.fit(walks, cfg, 0); syn0, vid = dm.vectors(); st = dm.stats()
+    print("gpu HS workers", workers, "drain", load, "cold", cold, "pairs", st["pairs"], "kernel_ms %.1f" % st["kernel_ms"], metrics(syn0, dm.syn1neg(), vid),
           "median cos vs seq %.3f" % float(np.median(cosine_rows(syn0, om.syn0))), flush=True)
