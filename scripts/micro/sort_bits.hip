@@ -48,16 +48,25 @@ int main() {
     typedef radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<1024, 8>, kernel_config<1024, 8>, 9, block_radix_rank_algorithm::match>> C9;
     typedef radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<1024, 8>, kernel_config<1024, 8>, 10, block_radix_rank_algorithm::match>> C10;
     typedef radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<1024, 8>, kernel_config<512, 12>, 9, block_radix_rank_algorithm::match>> C9b;
+    // bigger tiles (gfx950 has 160 KB of LDS a workgroup may use): more items per digit and block, longer runs in the scatter
+    typedef radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<1024, 8>, kernel_config<512, 16>, 9, block_radix_rank_algorithm::match>> C9_512x16;
+    typedef radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<1024, 8>, kernel_config<512, 20>, 9, block_radix_rank_algorithm::match>> C9_512x20;
+    typedef radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<1024, 8>, kernel_config<1024, 12>, 9, block_radix_rank_algorithm::match>> C9_1024x12;
+    typedef radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<1024, 8>, kernel_config<1024, 16>, 9, block_radix_rank_algorithm::match>> C9_1024x16;
+    typedef radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<1024, 8>, kernel_config<256, 24>, 9, block_radix_rank_algorithm::match>> C9_256x24;
     const int64_t sizes[] = {12800000, 48000000};
     for (int64_t n : sizes) {
         int32_t *k0, *k1; uint64_t *v0, *v1; int* d_bad;
         CK(hipMalloc(&k0, n * 4)); CK(hipMalloc(&k1, n * 4)); CK(hipMalloc(&v0, n * 8)); CK(hipMalloc(&v1, n * 8)); CK(hipMalloc(&d_bad, 4));
-        for (int bits : {17, 18, 20}) {
+        for (int bits : {17, 18}) {
             hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, k0, v0, n, bits);
             if (run<default_config>("default (8-bit digits)", n, bits, k0, k1, v0, v1, d_bad)) return 1;
-            if (run<C9>("9-bit, 1024x8, match", n, bits, k0, k1, v0, v1, d_bad)) return 1;
-            if (run<C9b>("9-bit, 512x12, match", n, bits, k0, k1, v0, v1, d_bad)) return 1;
-            if (run<C10>("10-bit, 1024x8, match", n, bits, k0, k1, v0, v1, d_bad)) return 1;
+            if (run<C9b>("9-bit, 512x12", n, bits, k0, k1, v0, v1, d_bad)) return 1;
+            if (run<C9_512x16>("9-bit, 512x16", n, bits, k0, k1, v0, v1, d_bad)) return 1;
+            if (run<C9_512x20>("9-bit, 512x20", n, bits, k0, k1, v0, v1, d_bad)) return 1;
+            if (run<C9_1024x12>("9-bit, 1024x12", n, bits, k0, k1, v0, v1, d_bad)) return 1;
+            if (run<C9_1024x16>("9-bit, 1024x16", n, bits, k0, k1, v0, v1, d_bad)) return 1;
+            if (run<C9_256x24>("9-bit, 256x24", n, bits, k0, k1, v0, v1, d_bad)) return 1;
         }
         hipFree(k0); hipFree(k1); hipFree(v0); hipFree(v1); hipFree(d_bad);
     }
