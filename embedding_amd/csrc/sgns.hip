@@ -356,6 +356,10 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     MH(hipStreamSynchronize(st));
     const int64_t V = (int64_t)kept;
     m->V = V;
+    // the two tables and their lock words first: before the unigram table and the 0.8 GB of temporaries its construction takes
+    const size_t tab = (size_t)V * (size_t)m->stride;
+    MC(dge_dev_alloc(&m->d_syn0, tab + 64)); MC(dge_dev_alloc(&m->d_syn1neg, tab + 64));
+    MC(dge_dev_alloc(&m->d_locks, 2 * ((size_t)V + 1)));      // [0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows
     MC(dge_dev_alloc(&m->d_vocab_ids, (size_t)V)); MC(dge_dev_alloc(&m->d_counts, (size_t)V)); MC(dge_dev_alloc(&m->d_remap, (size_t)NV));
     if (V) {
         MH(hipMemcpyAsync(m->d_vocab_ids, d_ids_sorted.p, V * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -435,8 +439,6 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         MH(hipMemcpyAsync(m->d_exp, e, sizeof(e), hipMemcpyHostToDevice, st));
         MH(hipStreamSynchronize(st));
     }
-    size_t tab = (size_t)V * (size_t)m->stride;
-    MC(dge_dev_alloc(&m->d_syn0, tab + 64)); MC(dge_dev_alloc(&m->d_syn1neg, tab + 64));
     MH(hipMemsetAsync(m->d_syn1neg, 0, (tab + 64) * sizeof(float), st));
     if (V) hipLaunchKernelGGL(k_init_syn0, dim3(grid_for(V, 256)), dim3(256), 0, st, m->d_syn0, V, m->D, m->stride, cfg->seed);
     if (cfg->use_hs) {
@@ -455,7 +457,6 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         if (!m->h_hs_points.empty()) MH(hipMemcpyAsync(m->d_hs_points, m->h_hs_points.data(), m->h_hs_points.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         if (V) MH(hipMemcpyAsync(m->d_hs_codes, m->h_hs_codes.data(), (size_t)V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     }
-    MC(dge_dev_alloc(&m->d_locks, 2 * ((size_t)V + 1)));      // [0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows
     MH(hipMemsetAsync(m->d_locks, 0, 2 * ((size_t)V + 1) * sizeof(int), st));
     MC(dge_dev_alloc(&m->d_counters, 3));       // pairs, words, the lock kernels' walk counter
     MH(hipMemsetAsync(m->d_counters, 0, 3 * sizeof(unsigned long long), st));
