@@ -550,6 +550,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.all_words = (int64_t)std::max(m->cfg.epochs, 1) * m->total_words;
     p.words_scale = words_scale;
     p.alpha0 = m->cfg.alpha; p.min_alpha = m->cfg.min_alpha;
+    p.D = m->D;
     p.counters = m->d_counters;
     p.next_walk = nullptr;
     p.locks = m->d_locks;

@@ -26,6 +26,7 @@ struct TrainParams {
     const int32_t* sen; const int64_t* len; const int64_t* wb;
     float* syn0; float* syn1neg; const int32_t* table; const float* exp_table;
     int64_t n_rows; int32_t L, W, K, stride;
+    int32_t D;                // the rows' meaningful floats (stride = D rounded up to 64: the rest is zero padding and stays zero)
     int64_t V, T;
     uint64_t seed;
     int64_t gidx_base;        // (epoch*total_walks + walk_index_base): RNG stream key of row 0
@@ -150,6 +151,7 @@ struct TableView {
     __amdgpu_buffer_rsrc_t rsrc;
     float* base;
     uint32_t row_bytes;
+    uint32_t valid;           // floats of a row that are not padding: atomics skip the rest (a D = 20 row is 2 requests of 64 B, not 4)
     uint32_t seg_shift;       // BIG: rows per segment = 1 << seg_shift (the largest power of two whose rows fit a 4 GiB window)
     bool big;
 };
@@ -157,6 +159,7 @@ __device__ __forceinline__ TableView make_view(float* base, int64_t rows, int st
     TableView t;
     t.base = base;
     t.row_bytes = (uint32_t)stride * 4u;
+    t.valid = (uint32_t)stride;
     t.big = (uint64_t)rows * (uint64_t)stride * 4ull >= 0xFFFFFFFFull;
     t.rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, t.big ? 0 : (int)(uint32_t)(rows * stride * 4), 0x00020000);   // unused when BIG
     t.seg_shift = 31u - (uint32_t)__builtin_clz(0xFFFFFFFFu / t.row_bytes);
@@ -235,10 +238,11 @@ __device__ __forceinline__ void row_atomic_axpy(const TableView& t, int32_t row,
     float* p = t.base + (size_t)row * (t.row_bytes / 4) + lane;
 #pragma unroll
     for (int c = 0; c < DCH; c++) {
-        atomicAdd(p + c * 64 + 0, g * x.v[c].x);
-        atomicAdd(p + c * 64 + 16, g * x.v[c].y);
-        atomicAdd(p + c * 64 + 32, g * x.v[c].z);
-        atomicAdd(p + c * 64 + 48, g * x.v[c].w);
+        const uint32_t e = (uint32_t)(c * 64 + lane);          // this lane's first element of the chunk; padding takes no atomics
+        if (e < t.valid) atomicAdd(p + c * 64 + 0, g * x.v[c].x);
+        if (e + 16 < t.valid) atomicAdd(p + c * 64 + 16, g * x.v[c].y);
+        if (e + 32 < t.valid) atomicAdd(p + c * 64 + 32, g * x.v[c].z);
+        if (e + 48 < t.valid) atomicAdd(p + c * 64 + 48, g * x.v[c].w);
     }
 }
 template <int DCH>
@@ -326,6 +330,7 @@ __device__ __forceinline__ void hot_add(float* s_hot, int* s_cnt, int slot, int 
         for (int c = 0; c < DCH; c++)
 #pragma unroll
             for (int m = 0; m < 4; m++) {
+                if ((uint32_t)(c * 64 + m * 16 + lane) >= t.valid) continue;
                 const float v = atomicExch(a + c * 64 + m * 16, 0.f);
                 if (v != 0.f) atomicAdd(gp + c * 64 + m * 16, v);
             }
@@ -367,9 +372,10 @@ k_sgns_train(TrainParams p) {
     }
     if (!HOT && worker >= p.n_workers) return;    // (the HOT kernel keeps every thread for its final block-wide drain)
 
-    const TableView syn0 = make_view(p.syn0, p.V, p.stride, p.big_seg_shift);
-    const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride, p.big_seg_shift);
-    const TableView syn1 = make_view(HS ? p.syn1 : p.syn1neg, p.V, p.stride, p.big_seg_shift);
+    TableView syn0 = make_view(p.syn0, p.V, p.stride, p.big_seg_shift);
+    TableView syn1neg = make_view(p.syn1neg, p.V, p.stride, p.big_seg_shift);
+    TableView syn1 = make_view(HS ? p.syn1 : p.syn1neg, p.V, p.stride, p.big_seg_shift);
+    syn0.valid = syn1neg.valid = syn1.valid = (uint32_t)p.D;
     int64_t hs_o = 0; int hs_n = 0; uint64_t hs_bits = 0;   // Huffman path of the open centre
 
     // lane j turns the pair's LCG state s into the state after j+1 draws: s*mA + cA
@@ -700,7 +706,7 @@ __device__ __forceinline__ void rowA_atomic_axpy(const TableView& t, int32_t row
             const int src = 4 * m + hi;
             const float x0 = __shfl(x.v[c].x, src, 16), x1 = __shfl(x.v[c].y, src, 16), x2 = __shfl(x.v[c].z, src, 16), x3 = __shfl(x.v[c].w, src, 16);
             const float v = comp == 0 ? x0 : (comp == 1 ? x1 : (comp == 2 ? x2 : x3));
-            atomicAdd(p + c * 64 + 16 * m, g * v);
+            if ((uint32_t)(c * 64 + 16 * m + lane) < t.valid) atomicAdd(p + c * 64 + 16 * m, g * v);
         }
 }
 // the centre's delta parked in LDS (index 64q + 16*component + lane holds element 64q + 4*lane + component)
@@ -711,7 +717,8 @@ __device__ __forceinline__ void ldsA_atomic_add(const TableView& t, int32_t row,
 #pragma unroll
     for (int c = 0; c < DCH; c++)
 #pragma unroll
-        for (int m = 0; m < 4; m++) atomicAdd(p + c * 64 + 16 * m, d_base[c * 64 + comp * 16 + 4 * m + hi]);
+        for (int m = 0; m < 4; m++)
+            if ((uint32_t)(c * 64 + 16 * m + lane) < t.valid) atomicAdd(p + c * 64 + 16 * m, d_base[c * 64 + comp * 16 + 4 * m + hi]);
 }
 
 template <int DCH, bool STRICT, bool BIG, bool HOTMIX = false>
@@ -754,8 +761,9 @@ k_sgns_train_locked(TrainParams p) {
     const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (worker >= p.n_workers) return;
 
-    const TableView syn0 = make_view(p.syn0, p.V, p.stride, p.big_seg_shift);
-    const TableView syn1neg = make_view(p.syn1neg, p.V, p.stride, p.big_seg_shift);
+    TableView syn0 = make_view(p.syn0, p.V, p.stride, p.big_seg_shift);
+    TableView syn1neg = make_view(p.syn1neg, p.V, p.stride, p.big_seg_shift);
+    syn0.valid = syn1neg.valid = (uint32_t)p.D;
     int* const locks1 = p.locks;
     int* const locks0 = p.locks + p.V + 1;
     const int32_t hot_rows = HOTMIX ? p.hot_rows : 0;
