@@ -663,6 +663,11 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     }
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
+    if ((pol == 7 || pol == 27) && workers > 1) {
+        // the mixed kernels keep every workgroup's fourth wave for the head rows' atomics (k_sgns_train_locked): 12 workers a workgroup
+        if (m->cfg.workers == 0 && !(g_dge_tuning[DGE_TUNE_WORKERS] > 0)) { workers = std::max<int64_t>(workers / 16 * 12, 2); p.n_workers = workers; }
+        blocks = (unsigned)((workers + 11) / 12);
+    }
 
     // per-segment descriptors (TableView) for tables of 4 GiB and more; DGE_TUNE_FORCE_SEGMENTS selects that code path on small
     // tables too so that the parity tests can cover it

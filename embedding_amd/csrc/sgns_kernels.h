@@ -743,6 +743,88 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
     }
 }
 
+// ---- HOTMIX: the head rows' atomics leave through an ATOMICS WAVE.
+// A wave waits for ITS OWN outstanding memory operations whenever it waits for anything (vmcnt counts loads, stores and atomics alike on
+// gfx9), so a worker that issues head-row atomics sits on their completion at its next try-lock — and the memory-side atomic unit, saturated
+// by the head, answers slowly: on cfg5 the atomic bytes (2.3 s at 1.24 TB/s) and the plain bytes (2.5 s) ADDED UP to the launch's 4.7 s,
+// although the memory system serves both at once (scripts/micro/atomic_overlap.hip: 3.64 ms together, 3.36 + 1.02 alone).  So the last wave
+// of every workgroup trains nothing: the 12 workers of the other three waves post (vector, rows, steps) messages into LDS boxes, the atomics
+// wave turns them into float atomics and never waits for their completion.  A message: LK_MB_HDR floats of header (count, then 16 rows as
+// int bits, then 16 steps) followed by the vector in element order; two boxes per worker.  Box states: 0 = free, 1 = rows of syn1neg, 2 = of syn0.
+#define LK_MB_WORKERS 12
+#define LK_MB_HDR 36
+template <int DCH> struct LkBox { static constexpr int FLOATS = LK_MB_HDR + DCH * 64; };
+__device__ __forceinline__ int lk_flag_load(int* f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lk_flag_store(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// worker side: lane j contributes (row, step) when row >= 0; `vec` is the 16-byte register layout (lane j: elements 64c + 4j .. 4j + 3)
+template <int DCH>
+__device__ __forceinline__ void lk_post(float* boxes, int* flags, int wk, unsigned& n_posts, int kind, int32_t row, float step, const Row<DCH>& vec, int lane) {
+    const int b = wk * 2 + (int)(n_posts & 1u);
+    float* box = boxes + (size_t)b * LkBox<DCH>::FLOATS;
+    for (;;) {                                              // (both boxes of this worker are still being read: wait for the older one)
+        int f = 0;
+        if (lane == 0) f = lk_flag_load(&flags[b]);
+        if (__shfl(f, 0, 16) == 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    const unsigned have = (unsigned)(__ballot(row >= 0) >> (threadIdx.x & 48)) & 0xFFFFu;
+    if (lane == 0) box[0] = __int_as_float((int)have);
+    box[1 + lane] = __int_as_float(row);
+    box[17 + lane] = step;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) *(float4*)(box + LK_MB_HDR + c * 64 + 4 * lane) = vec.v[c];
+    if (lane == 0) lk_flag_store(&flags[b], kind);         // release: the box's contents are written before the flag turns
+    n_posts++;
+}
+// atomics wave: group g (16 lanes) serves workers g, g + 4, g + 8; returns when every worker of the workgroup has left and every box is free
+template <int DCH>
+__device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* done, int n_workers_here, const TableView& syn0, const TableView& syn1neg, int group, int lane) {
+    for (;;) {
+        bool any = false;
+        for (int w = group; w < LK_MB_WORKERS; w += 4)
+            for (int h = 0; h < 2; h++) {
+                const int b = w * 2 + h;
+                int f = 0;
+                if (lane == 0) f = lk_flag_load(&flags[b]);
+                f = __shfl(f, 0, 16);
+                if (f == 0) continue;
+                any = true;
+                const float* box = boxes + (size_t)b * LkBox<DCH>::FLOATS;
+                const unsigned have = (unsigned)__float_as_int(box[0]);
+                const int32_t my_row = __float_as_int(box[1 + lane]);
+                const float my_step = box[17 + lane];
+                float v[DCH * 4];
+#pragma unroll
+                for (int c = 0; c < DCH; c++)
+#pragma unroll
+                    for (int m = 0; m < 4; m++) v[c * 4 + m] = box[LK_MB_HDR + c * 64 + 16 * m + lane];
+                if (lane == 0) lk_flag_store(&flags[b], 0);                       // (everything of the box is in registers)
+                const TableView& t = f == 2 ? syn0 : syn1neg;
+                for (unsigned left = have; left; left &= left - 1u) {
+                    const int j = __builtin_ctz(left);
+                    const int32_t row = __shfl(my_row, j, 16);
+                    const float g = __shfl(my_step, j, 16);
+                    float* pr = t.base + (size_t)row * (t.row_bytes / 4) + lane;
+#pragma unroll
+                    for (int c = 0; c < DCH; c++)
+#pragma unroll
+                        for (int m = 0; m < 4; m++)
+                            if ((uint32_t)(c * 64 + 16 * m + lane) < t.valid) atomicAdd(pr + c * 64 + 16 * m, g * v[c * 4 + m]);
+                }
+            }
+        if (!any) {
+            int d = 0;
+            if (lane == 0) d = __hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__shfl(d, 0, 16) >= n_workers_here) {       // every worker has left: whatever it posted is visible now — one last look
+                bool left_over = false;
+                for (int w = group; w < LK_MB_WORKERS; w += 4)
+                    for (int h = 0; h < 2; h++) { int f = 0; if (lane == 0) f = lk_flag_load(&flags[w * 2 + h]); left_over |= __shfl(f, 0, 16) != 0; }
+                if (!left_over) return;
+            } else __builtin_amdgcn_s_sleep(2);
+        }
+    }
+}
+
 #define LK_NEG_LANES 13      /* lanes 0..12 draw negatives, lane 13 = pending centre flush, lane 14 = the pair's syn0 row */
 #ifndef LK_CHUNK
 #define LK_CHUNK 10          /* negatives per lock round: a multiple of NEG_BATCH, so no batch of a full chunk loads filler rows */
@@ -753,17 +835,31 @@ __global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HOTMIX ? (PART ? 2 
 k_sgns_train_locked(TrainParams p) {
     __shared__ float s_exp[EXP_TABLE_SIZE];
     __shared__ float s_dh[16 * 2 * DCH * 64];
+    __shared__ __attribute__((aligned(16))) float s_mb[HOTMIX ? LK_MB_WORKERS * 2 * LkBox<DCH>::FLOATS : 4];     // the atomics wave's message boxes
+    __shared__ int s_mb_flag[LK_MB_WORKERS * 2];
+    __shared__ int s_mb_done;
     for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
+    if (threadIdx.x < LK_MB_WORKERS * 2) s_mb_flag[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_mb_done = 0;
     __syncthreads();
 
     const int lane = threadIdx.x & 15;
     const int wk = threadIdx.x >> 4;
-    const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    if (worker >= p.n_workers) return;
+    // HOTMIX with more than one worker: 12 workers a workgroup, the fourth wave is the atomics wave (one worker alone issues its atomics itself:
+    // its next read of a head row must see them, as the sequential schedule does)
+    const bool use_mb = HOTMIX && p.n_workers > 1;
+    const int64_t worker = use_mb ? (int64_t)blockIdx.x * LK_MB_WORKERS + wk : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
 
     TableView syn0 = make_view(p.syn0, p.V, p.stride, p.big_seg_shift);
     TableView syn1neg = make_view(p.syn1neg, p.V, p.stride, p.big_seg_shift);
     syn0.valid = syn1neg.valid = (uint32_t)p.D;
+    if (use_mb && wk >= LK_MB_WORKERS) {
+        const int64_t here = min((int64_t)LK_MB_WORKERS, p.n_workers - (int64_t)blockIdx.x * LK_MB_WORKERS);
+        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(here, (int64_t)0), syn0, syn1neg, wk - LK_MB_WORKERS, lane);
+        return;
+    }
+    if (worker >= p.n_workers) return;
+    unsigned n_posts = 0;
     int* const locks1 = p.locks;
     int* const locks0 = p.locks + p.V + 1;
     const int32_t hot_rows = HOTMIX ? p.hot_rows : 0;
@@ -1007,12 +1103,24 @@ k_sgns_train_locked(TrainParams p) {
                 if (HOTMIX) {
                     // head rows: memory-side atomics, issued behind the commit so that the wait above (which drains every
                     // outstanding memory operation of the wave) never sits on them while row locks are held
+                    if (use_mb) {
+                        const bool mine = lane < kc && ((got13 >> lane) & 1u) && t < hot_rows;
+                        if ((unsigned)(__ballot(mine) >> (threadIdx.x & 48)) & 0xFFFFu) lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, mine ? t : -1, my_hot_g, l1, lane);
+                    } else
                     for (int j = 0; j < kc; j++) {
                         const int32_t tj = __shfl(t, j, 16);
                         const float gj = __shfl(my_hot_g, j, 16);
                         if (((got13 >> j) & 1u) && tj < hot_rows) rowA_atomic_axpy<DCH>(syn1neg, tj, lane, gj, l1);
                     }
-                    if (hot_flush) ldsA_atomic_add<DCH>(syn1neg, pend_row, lane, my_dh + (cur_buf ^ 1) * DCH * 64);
+                    if (hot_flush) {
+                        if (use_mb) {                       // the parked delta of a head centre: element 64q + 4*lane + component sits at 64q + 16*component + lane
+                            const float* d = my_dh + (cur_buf ^ 1) * DCH * 64 + lane;
+                            Row<DCH> dv;
+#pragma unroll
+                            for (int q = 0; q < DCH; q++) { dv.v[q].x = d[q * 64]; dv.v[q].y = d[q * 64 + 16]; dv.v[q].z = d[q * 64 + 32]; dv.v[q].w = d[q * 64 + 48]; }
+                            lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, lane == 0 ? pend_row : -1, 1.0f, dv, lane);
+                        } else ldsA_atomic_add<DCH>(syn1neg, pend_row, lane, my_dh + (cur_buf ^ 1) * DCH * 64);
+                    }
                 }
                 pend13 &= ~got13;
                 if (gotf) { flush_pending = false; pend_row = -1; if (lane == 13) t = -1; }
@@ -1028,7 +1136,8 @@ k_sgns_train_locked(TrainParams p) {
             l1.v[q].x += neu.v[q].x; l1.v[q].y += neu.v[q].y; l1.v[q].z += neu.v[q].z; l1.v[q].w += neu.v[q].w;
         }
         if (HOTMIX && (last < hot_rows || p.syn0_free)) {
-            rowA_atomic_axpy<DCH>(syn0, last, lane, 1.0f, neu);
+            if (use_mb) lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 2, lane == 0 ? last : -1, 1.0f, neu, lane);
+            else rowA_atomic_axpy<DCH>(syn0, last, lane, 1.0f, neu);
         } else {
             rowA_store<DCH, 16, BIG>(l1, syn0, last, lane);
             row_commit_wait(STRICT ? row_probe_lines(syn0, last, lane, DCH * 2) : 0.f);
@@ -1051,6 +1160,7 @@ k_sgns_train_locked(TrainParams p) {
     if (lane == 0) {
         if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
         if (my_words) atomicAdd(&p.counters[1], my_words);
+        if (use_mb) __hip_atomic_fetch_add(&s_mb_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // (behind this worker's last post)
     }
 }
 
