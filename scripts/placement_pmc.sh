@@ -4,7 +4,9 @@
 root=$(pwd); out=$root/gpurun_out/placement_pmc; rm -rf $out; mkdir -p $out/flat
 export TMPDIR=/tmp; cd /tmp
 i=0
-for ctr in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum" "GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum" "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum" "TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum"; do
+sets=("$@")      # counter sets, one argument each ("A B"); none: the sets behind profiles/r02_box_drift.txt
+if [ ${#sets[@]} -eq 0 ]; then sets=("TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum" "GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum" "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum" "TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum"); fi
+for ctr in "${sets[@]}"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/p$i -o set$i -- python3 $root/scripts/slow_state_probe.py > $out/log$i.txt 2>&1
   find $out/p$i -name "*.csv" -exec cp {} $out/flat/ \;
