@@ -521,7 +521,7 @@ k_sgns_train(TrainParams p) {
                                     if (tg[q] >= p.hs_hot0) hot_add<DCH>(s_hot, s_hot_cnt, tg[q] - p.hs_hot0, p.hs_drain, syn1, tg[q], lane, g, l1);
                                     else if (tg[q] < p.hs_cold) {
                                         // a cold inner node (on < 2e-5 of the paths: two workers meet on it within a read-modify-write
-                                        // less than once in 200 updates): the row is already here for the dot product, its update goes
+                                        // about once in 100-200 updates at the warm end of the class, far less below): the row is already here for the dot product, its update goes
                                         // back as a write-through store — 512 B at the plain rate instead of 512 B at the atomic rate
                                         row_axpy(rr[q], g, l1);
                                         row_store<DCH, 16, BIG>(rr[q], syn1, tg[q], lane);
