@@ -13,6 +13,9 @@ ZIPF = len(sys.argv) > 1 and sys.argv[1] == "zipf"
 # "blocks N": the multi-GPU block schedule with N ranks simulated on this GPU (N models), 10 global batches per epoch,
 # against the one-GPU run of the same epoch.
 BLOCKS = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] == "blocks" else 0
+# "hs": hierarchical softmax + 5 negatives (what DL4J's builder default trains): every inner node under atomics, and with the cold end of
+# the tree updated by plain read-modify-write (the library's rule), one epoch each
+HS = len(sys.argv) > 1 and sys.argv[1] == "hs"
 
 R, T, L, D, K = 41667, 24, 24, 128, 5
 NV = R * T
@@ -73,6 +76,16 @@ if BLOCKS:
         wb += ms[0].stats()["words"]
     simulate_gather_syn0(ms)
     print("%d ranks, block schedule      | AUC %.4f pos %.3f neg %.3f" % ((BLOCKS,) + auc(ms[0])), "| ran as", ms[0].schedule(), "| %.0f s for all ranks on one GPU" % (time.time() - t), flush=True)
+    sys.exit(0)
+
+if HS:
+    for name, knobs in (("every inner node under atomics", {"hs_cold": 0}), ("cold end of the tree by plain read-modify-write (default)", {})):
+        with E.tuning(**knobs):
+            m = E.SgnsModel.create(E.make_config(D, L, NV, negative=K, workers=0, use_hs=True), counts, 0)
+            m.train(corpus); st = m.stats()
+        print("HS, %s | pairs %.3e kernel %.1f s -> %.3e edges/s" % (name, st["pairs"], st["kernel_ms"] / 1e3, st["pairs"] / (st["kernel_ms"] / 1e3)),
+              "| AUC %.4f pos %.3f neg %.3f" % auc(m), flush=True)
+        m.close()
     sys.exit(0)
 
 for pol in ((2, 7, 0) if ZIPF else (0, 2, 5, 6, 1, 3)):
