@@ -776,49 +776,43 @@ __device__ __forceinline__ void lk_post(float* boxes, int* flags, int wk, unsign
     if (lane == 0) lk_flag_store(&flags[b], kind);         // release: the box's contents are written before the flag turns
     n_posts++;
 }
-// atomics wave: group g (16 lanes) serves workers g, g + 4, g + 8; returns when every worker of the workgroup has left and every box is free
+// atomics wave: all 64 lanes on ONE message at a time — an atomic instruction then covers 256 contiguous bytes of a row (a wave can have ~63
+// memory instructions outstanding, and atomics on a saturated unit complete slowly: with one 16-lane group per message, 64 bytes an instruction,
+// the wave itself would cap the workgroup's atomic rate).  Returns when every worker of the workgroup has left and every box is free.
 template <int DCH>
-__device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* done, int n_workers_here, const TableView& syn0, const TableView& syn1neg, int group, int lane) {
+__device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* done, int n_workers_here, const TableView& syn0, const TableView& syn1neg) {
+    const int wl = threadIdx.x & 63;
     for (;;) {
         bool any = false;
-        for (int w = group; w < LK_MB_WORKERS; w += 4)
-            for (int h = 0; h < 2; h++) {
-                const int b = w * 2 + h;
-                int f = 0;
-                if (lane == 0) f = lk_flag_load(&flags[b]);
-                f = __shfl(f, 0, 16);
-                if (f == 0) continue;
-                any = true;
-                const float* box = boxes + (size_t)b * LkBox<DCH>::FLOATS;
-                const unsigned have = (unsigned)__float_as_int(box[0]);
-                const int32_t my_row = __float_as_int(box[1 + lane]);
-                const float my_step = box[17 + lane];
-                float v[DCH * 4];
+        for (int b = 0; b < LK_MB_WORKERS * 2; b++) {
+            const int f = __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b]));       // (every lane reads the same word)
+            if (f == 0) continue;
+            any = true;
+            const float* box = boxes + (size_t)b * LkBox<DCH>::FLOATS;
+            const unsigned have = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(box[0]));
+            const int32_t my_row = __float_as_int(box[1 + (wl & 15)]);
+            const float my_step = box[17 + (wl & 15)];
+            float v[DCH];
+#pragma unroll
+            for (int c = 0; c < DCH; c++) v[c] = box[LK_MB_HDR + c * 64 + wl];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                        // the box is in registers
+            if (wl == 0) lk_flag_store(&flags[b], 0);
+            const TableView& t = f == 2 ? syn0 : syn1neg;
+            for (unsigned left = have; left; left &= left - 1u) {
+                const int j = __builtin_ctz(left);
+                const int32_t row = __builtin_amdgcn_readlane(my_row, j);
+                const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_step), j));
+                float* pr = t.base + (size_t)row * (t.row_bytes / 4) + wl;
 #pragma unroll
                 for (int c = 0; c < DCH; c++)
-#pragma unroll
-                    for (int m = 0; m < 4; m++) v[c * 4 + m] = box[LK_MB_HDR + c * 64 + 16 * m + lane];
-                if (lane == 0) lk_flag_store(&flags[b], 0);                       // (everything of the box is in registers)
-                const TableView& t = f == 2 ? syn0 : syn1neg;
-                for (unsigned left = have; left; left &= left - 1u) {
-                    const int j = __builtin_ctz(left);
-                    const int32_t row = __shfl(my_row, j, 16);
-                    const float g = __shfl(my_step, j, 16);
-                    float* pr = t.base + (size_t)row * (t.row_bytes / 4) + lane;
-#pragma unroll
-                    for (int c = 0; c < DCH; c++)
-#pragma unroll
-                        for (int m = 0; m < 4; m++)
-                            if ((uint32_t)(c * 64 + 16 * m + lane) < t.valid) atomicAdd(pr + c * 64 + 16 * m, g * v[c * 4 + m]);
-                }
+                    if ((uint32_t)(c * 64 + wl) < t.valid) atomicAdd(pr + c * 64, g * v[c]);
             }
+        }
         if (!any) {
-            int d = 0;
-            if (lane == 0) d = __hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__shfl(d, 0, 16) >= n_workers_here) {       // every worker has left: whatever it posted is visible now — one last look
+            const int d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (d >= n_workers_here) {                      // every worker has left: whatever it posted is visible now — one last look
                 bool left_over = false;
-                for (int w = group; w < LK_MB_WORKERS; w += 4)
-                    for (int h = 0; h < 2; h++) { int f = 0; if (lane == 0) f = lk_flag_load(&flags[w * 2 + h]); left_over |= __shfl(f, 0, 16) != 0; }
+                for (int b = 0; b < LK_MB_WORKERS * 2; b++) left_over |= __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b])) != 0;
                 if (!left_over) return;
             } else __builtin_amdgcn_s_sleep(2);
         }
@@ -855,7 +849,7 @@ k_sgns_train_locked(TrainParams p) {
     syn0.valid = syn1neg.valid = (uint32_t)p.D;
     if (use_mb && wk >= LK_MB_WORKERS) {
         const int64_t here = min((int64_t)LK_MB_WORKERS, p.n_workers - (int64_t)blockIdx.x * LK_MB_WORKERS);
-        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(here, (int64_t)0), syn0, syn1neg, wk - LK_MB_WORKERS, lane);
+        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(here, (int64_t)0), syn0, syn1neg);
         return;
     }
     if (worker >= p.n_workers) return;
