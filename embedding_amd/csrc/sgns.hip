@@ -28,7 +28,7 @@
 #include "sgns_model.h"
 
 
-int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
@@ -555,7 +555,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.next_walk = nullptr;
     p.locks = m->d_locks;
     p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
-    p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0; p.hs_cold = 0;
+    p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0; p.hs_cold = 0; p.hs_wave = 0;
     p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt; p.syn0_free = 0;
     p.big_seg_shift = 0;
     p.filler_row = (int32_t)(0xFFFFFFF0u / ((uint32_t)m->stride * 4u)) - 1;      // offset + the largest in-row displacement stays below 2^32
@@ -649,7 +649,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     if (hs) {
         pol = pol == 0 ? 10 : 12;               // dge_model_create admitted policies 0/2/3 only
         if (pol == 12) {
-            // LDS accumulators for the inner nodes nearest the root: 30 KB a block (4 blocks a CU stay resident)
+            // LDS accumulators for the inner nodes nearest the root: 30 KB a block (3 blocks a CU stay resident beside the atomics wave's boxes)
             const int64_t row_b = (int64_t)m->stride * 4 + 4;
             p.hs_n_hot = (int32_t)std::min<int64_t>(std::max<int64_t>(m->V - 1, 0), 30720 / row_b);
             p.hs_hot0 = (int32_t)(std::max<int64_t>(m->V - 1, 0) - p.hs_n_hot);
@@ -663,6 +663,13 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     }
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
+    if (pol == 12 && workers > 1 && g_dge_tuning[DGE_TUNE_HS_WAVE] != 0) {
+        // hierarchical softmax under atomics: every workgroup's fourth wave issues the atomics of its 12 workers (k_sgns_train, lk_atomics_wave)
+        p.hs_wave = 1;
+        // (three workgroups a compute unit stay resident next to their LDS accumulators and message boxes: DGE_HS_WAVES)
+        if (m->cfg.workers == 0 && !(g_dge_tuning[DGE_TUNE_WORKERS] > 0)) { workers = std::max<int64_t>(std::min<int64_t>(workers / 16 * 12, (int64_t)m->n_cus * DGE_HS_WAVES * 12), 2); p.n_workers = workers; }
+        blocks = (unsigned)((workers + 11) / 12);
+    }
     if ((pol == 7 || pol == 27) && workers > 1) {
         // the mixed kernels keep every workgroup's fourth wave for the head rows' atomics (k_sgns_train_locked): 12 workers a workgroup
         if (m->cfg.workers == 0 && !(g_dge_tuning[DGE_TUNE_WORKERS] > 0)) { workers = std::max<int64_t>(workers / 16 * 12, 2); p.n_workers = workers; }

@@ -18,7 +18,7 @@
 #define DGE_HOTMIX_WAVES 3
 #endif
 #ifndef DGE_HS_WAVES
-#define DGE_HS_WAVES 4
+#define DGE_HS_WAVES 3
 #endif
 
 // ------------------------------------------------------------------------------------------ trainer
@@ -35,6 +35,7 @@ struct TrainParams {
     double words_scale;
     float alpha0, min_alpha;
     int64_t n_workers;
+    int32_t hs_wave;          // hierarchical softmax under atomics: every atomic of a workgroup goes through its atomics wave (12 workers a workgroup)
     int32_t hs_cold;          // hierarchical softmax under atomics: inner nodes [0, hs_cold) are updated by plain read-modify-write
     unsigned long long* counters;
     unsigned long long* next_walk;   // lock kernels: walks are handed out in order, one at a time (zero before every launch): worker w starts on walk w, the
@@ -353,17 +354,129 @@ __device__ __forceinline__ int32_t walk_tok(bool in_regs, const int32_t* sen, in
     return __shfl(v, idx & 15, 16);
 }
 
+// ---- The atomics wave (mixed lock kernels: the head rows' atomics; k_sgns_train with hierarchical softmax: every atomic).
+// A wave waits for ITS OWN outstanding memory operations whenever it waits for anything (vmcnt counts loads, stores and atomics alike on
+// gfx9), so a worker that issues head-row atomics sits on their completion at its next try-lock — and the memory-side atomic unit, saturated
+// by the head, answers slowly: on cfg5 the atomic bytes (2.3 s at 1.24 TB/s) and the plain bytes (2.5 s) ADDED UP to the launch's 4.7 s,
+// although the memory system serves both at once (scripts/micro/atomic_overlap.hip: 3.64 ms together, 3.36 + 1.02 alone).  So the last wave
+// of every workgroup trains nothing: the 12 workers of the other three waves post (vector, rows, steps) messages into LDS boxes, the atomics
+// wave turns them into float atomics and never waits for their completion.  A message: LK_MB_HDR floats of header (count, then 16 rows as
+// int bits, then 16 steps) followed by the vector in element order; two boxes per worker.  Box states: 0 = free, 1 = rows of syn1neg, 2 = of syn0,
+// 3 = of syn1 (hierarchical softmax).
+#define LK_MB_WORKERS 12
+#define LK_MB_HDR 36
+template <int DCH> struct LkBox { static constexpr int FLOATS = LK_MB_HDR + DCH * 64; };
+__device__ __forceinline__ int lk_flag_load(int* f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lk_flag_store(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// worker side: lane j contributes (row, step) when row >= 0; `vec` is the 16-byte register layout (lane j: elements 64c + 4j .. 4j + 3)
+template <int DCH>
+__device__ __forceinline__ void lk_post(float* boxes, int* flags, int wk, unsigned& n_posts, int kind, int32_t row, float step, const Row<DCH>& vec, int lane) {
+    const int b = wk * 2 + (int)(n_posts & 1u);
+    float* box = boxes + (size_t)b * LkBox<DCH>::FLOATS;
+    for (;;) {                                              // (both boxes of this worker are still being read: wait for the older one)
+        int f = 0;
+        if (lane == 0) f = lk_flag_load(&flags[b]);
+        if (__shfl(f, 0, 16) == 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    const unsigned have = (unsigned)(__ballot(row >= 0) >> (threadIdx.x & 48)) & 0xFFFFu;
+    if (lane == 0) box[0] = __int_as_float((int)have);
+    box[1 + lane] = __int_as_float(row);
+    box[17 + lane] = step;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) *(float4*)(box + LK_MB_HDR + c * 64 + 4 * lane) = vec.v[c];
+    if (lane == 0) lk_flag_store(&flags[b], kind);         // release: the box's contents are written before the flag turns
+    n_posts++;
+}
+// the same for the 4-byte-per-lane register layout of k_sgns_train's atomic policy (lane j: elements 64c + 16m + j, m = x, y, z, w)
+template <int DCH>
+__device__ __forceinline__ void lk_post4(float* boxes, int* flags, int wk, unsigned& n_posts, int kind, int32_t row, float step, const Row<DCH>& vec, int lane) {
+    const int b = wk * 2 + (int)(n_posts & 1u);
+    float* box = boxes + (size_t)b * LkBox<DCH>::FLOATS;
+    for (;;) {
+        int f = 0;
+        if (lane == 0) f = lk_flag_load(&flags[b]);
+        if (__shfl(f, 0, 16) == 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    const unsigned have = (unsigned)(__ballot(row >= 0) >> (threadIdx.x & 48)) & 0xFFFFu;
+    if (lane == 0) box[0] = __int_as_float((int)have);
+    box[1 + lane] = __int_as_float(row);
+    box[17 + lane] = step;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        float* v = box + LK_MB_HDR + c * 64 + lane;
+        v[0] = vec.v[c].x; v[16] = vec.v[c].y; v[32] = vec.v[c].z; v[48] = vec.v[c].w;
+    }
+    if (lane == 0) lk_flag_store(&flags[b], kind);
+    n_posts++;
+}
+// atomics wave: all 64 lanes on ONE message at a time — an atomic instruction then covers 256 contiguous bytes of a row (a wave can have ~63
+// memory instructions outstanding, and atomics on a saturated unit complete slowly: with one 16-lane group per message, 64 bytes an instruction,
+// the wave itself would cap the workgroup's atomic rate).  Returns when every worker of the workgroup has left and every box is free.
+template <int DCH>
+__device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* done, int n_workers_here, const TableView& syn0, const TableView& syn1neg, const TableView& syn1) {
+    const int wl = threadIdx.x & 63;
+    for (;;) {
+        bool any = false;
+        for (int b = 0; b < LK_MB_WORKERS * 2; b++) {
+            const int f = __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b]));       // (every lane reads the same word)
+            if (f == 0) continue;
+            any = true;
+            const float* box = boxes + (size_t)b * LkBox<DCH>::FLOATS;
+            const unsigned have = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(box[0]));
+            const int32_t my_row = __float_as_int(box[1 + (wl & 15)]);
+            const float my_step = box[17 + (wl & 15)];
+            float v[DCH];
+#pragma unroll
+            for (int c = 0; c < DCH; c++) v[c] = box[LK_MB_HDR + c * 64 + wl];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                        // the box is in registers
+            if (wl == 0) lk_flag_store(&flags[b], 0);
+            const TableView& t = f == 2 ? syn0 : (f == 3 ? syn1 : syn1neg);
+            for (unsigned left = have; left; left &= left - 1u) {
+                const int j = __builtin_ctz(left);
+                const int32_t row = __builtin_amdgcn_readlane(my_row, j);
+                const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_step), j));
+                float* pr = t.base + (size_t)row * (t.row_bytes / 4) + wl;
+#pragma unroll
+                for (int c = 0; c < DCH; c++)
+                    if ((uint32_t)(c * 64 + wl) < t.valid) atomicAdd(pr + c * 64, g * v[c]);
+            }
+        }
+        if (!any) {
+            const int d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (d >= n_workers_here) {                      // every worker has left: whatever it posted is visible now — one last look
+                bool left_over = false;
+                for (int b = 0; b < LK_MB_WORKERS * 2; b++) left_over |= __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b])) != 0;
+                if (!left_over) return;
+            } else __builtin_amdgcn_s_sleep(2);
+        }
+    }
+}
+
 template <int DCH, int POL, bool BIG, bool HS, bool PART>
 __global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HS ? DGE_HS_WAVES : 4) : 1)
 k_sgns_train(TrainParams p) {
     using P = Policy<POL>;
+    constexpr bool HOT = HS && P::ATOMIC;         // inner nodes near the root combine their updates in LDS (hot_add)
     __shared__ float s_exp[EXP_TABLE_SIZE];
+    __shared__ __attribute__((aligned(16))) float s_mb[HOT ? LK_MB_WORKERS * 2 * LkBox<DCH>::FLOATS : 4];     // the atomics wave's message boxes
+    __shared__ int s_mb_flag[LK_MB_WORKERS * 2];
+    __shared__ int s_mb_done;
     for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
+    if (threadIdx.x < LK_MB_WORKERS * 2) s_mb_flag[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_mb_done = 0;
     __syncthreads();
 
     const int lane = threadIdx.x & 15;
-    const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    constexpr bool HOT = HS && P::ATOMIC;         // inner nodes near the root combine their updates in LDS (hot_add)
+    const int wk = threadIdx.x >> 4;
+    // Hierarchical softmax under atomics (p.hs_wave): a pair is ~27 rows of atomics in ~7 batches, and a worker that issues them itself waits
+    // for each batch's atomics to complete before the next batch's rows arrive (a wave waits for ALL its outstanding memory operations) — on
+    // cfg3 126 us a pair.  So the workgroup's fourth wave is the atomics wave (lk_atomics_wave), 12 workers post to it.
+    const bool use_mb = HOT && p.hs_wave != 0;
+    const bool atomics_wave = use_mb && wk >= LK_MB_WORKERS;
+    const int64_t worker = use_mb ? (wk < LK_MB_WORKERS ? (int64_t)blockIdx.x * LK_MB_WORKERS + wk : p.n_workers) : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    unsigned n_posts = 0;
     float* s_hot = HOT ? s_dyn : nullptr;
     int* s_hot_cnt = HOT ? (int*)(s_dyn + (size_t)p.hs_n_hot * DCH * 64) : nullptr;
     if (HOT) {
@@ -376,6 +489,10 @@ k_sgns_train(TrainParams p) {
     TableView syn1neg = make_view(p.syn1neg, p.V, p.stride, p.big_seg_shift);
     TableView syn1 = make_view(HS ? p.syn1 : p.syn1neg, p.V, p.stride, p.big_seg_shift);
     syn0.valid = syn1neg.valid = syn1.valid = (uint32_t)p.D;
+    if (atomics_wave) {       // (then on to the block-wide drain at the end, with worker = n_workers: no walk)
+        const int64_t here = min((int64_t)LK_MB_WORKERS, p.n_workers - (int64_t)blockIdx.x * LK_MB_WORKERS);
+        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(here, (int64_t)0), syn0, syn1neg, syn1);
+    }
     int64_t hs_o = 0; int hs_n = 0; uint64_t hs_bits = 0;   // Huffman path of the open centre
 
     // lane j turns the pair's LCG state s into the state after j+1 draws: s*mA + cA
@@ -412,7 +529,7 @@ k_sgns_train(TrainParams p) {
     do {                                                                                                           \
         if (h_dirty) {                                                                                             \
             h_dirty = false;                                                                                       \
-            if (P::ATOMIC) row_atomic_axpy(syn1neg, word, lane, 1.0f, dh);                                         \
+            if (P::ATOMIC) { if (use_mb) lk_post4<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, lane == 0 ? word : -1, 1.0f, dh, lane); else row_atomic_axpy(syn1neg, word, lane, 1.0f, dh); } \
             else row_store<DCH, P::STORE_AUX, BIG>(h, syn1neg, word, lane);                                           \
         }                                                                                                          \
     } while (0)
@@ -498,6 +615,7 @@ k_sgns_train(TrainParams p) {
             for (int kd = 0; kd < hs_n; kd += 16) {
                 const int kc = min(16, hs_n - kd);
                 const int32_t t = lane < kc ? p.hs_points[hs_o + kd + lane] : -1;
+                float mb_g = 0.f; bool mb_mine = false;      // atomics wave: this lane's node of the round takes atomics, with this step
                 for (int base = 0; base < kc; base += NEG_BATCH) {
                     int32_t tg[NEG_BATCH];
                     Row<DCH> rr[NEG_BATCH];
@@ -525,7 +643,8 @@ k_sgns_train(TrainParams p) {
                                         // back as a write-through store — 512 B at the plain rate instead of 512 B at the atomic rate
                                         row_axpy(rr[q], g, l1);
                                         row_store<DCH, 16, BIG>(rr[q], syn1, tg[q], lane);
-                                    } else row_atomic_axpy(syn1, tg[q], lane, g, l1);
+                                    } else if (use_mb) { if (lane == base + q) { mb_g = g; mb_mine = true; } }
+                                    else row_atomic_axpy(syn1, tg[q], lane, g, l1);
                                 } else {
                                     row_axpy(rr[q], g, l1);
                                     row_store<DCH, P::STORE_AUX, BIG>(rr[q], syn1, tg[q], lane);
@@ -533,6 +652,7 @@ k_sgns_train(TrainParams p) {
                             }
                         }
                 }
+                if (use_mb && ((unsigned)(__ballot(mb_mine) >> (threadIdx.x & 48)) & 0xFFFFu)) lk_post4<DCH>(s_mb, s_mb_flag, wk, n_posts, 3, mb_mine ? t : -1, mb_g, l1, lane);
             }
         }
         {   // d == 0: target = word, label 1 (word2vec order: positive first)
@@ -555,6 +675,7 @@ k_sgns_train(TrainParams p) {
                 if (t == word) t = -1;
             }
             s = shfl16_u64(sl, kc - 1);
+            float mb_g = 0.f; bool mb_mine = false;
             for (int base = 0; base < kc; base += NEG_BATCH) {
                 int32_t tg[NEG_BATCH];
 #pragma unroll
@@ -582,7 +703,8 @@ k_sgns_train(TrainParams p) {
                             float g = sgns_g(f, 0.0f, alpha, s_exp);
                             row_axpy(neu, g, rr[q]);
                             if (P::ATOMIC) {
-                                row_atomic_axpy(syn1neg, tg[q], lane, g, l1);
+                                if (use_mb) { if (lane == base + q) { mb_g = g; mb_mine = true; } }
+                                else row_atomic_axpy(syn1neg, tg[q], lane, g, l1);
                             } else {
                                 row_axpy(rr[q], g, l1);
                                 row_store<DCH, P::STORE_AUX, BIG>(rr[q], syn1neg, tg[q], lane);
@@ -594,9 +716,11 @@ k_sgns_train(TrainParams p) {
                         if (tg[q] >= 0) neg_update_serial<DCH, POL, BIG>(l1, neu, syn1neg, tg[q], lane, alpha, s_exp);
                 }
             }
+            if (use_mb && ((unsigned)(__ballot(mb_mine) >> (threadIdx.x & 48)) & 0xFFFFu)) lk_post4<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, mb_mine ? t : -1, mb_g, l1, lane);
         }
         if (P::ATOMIC) {
-            row_atomic_axpy(syn0, last, lane, 1.0f, neu);
+            if (use_mb) lk_post4<DCH>(s_mb, s_mb_flag, wk, n_posts, 2, lane == 0 ? last : -1, 1.0f, neu, lane);
+            else row_atomic_axpy(syn0, last, lane, 1.0f, neu);
         } else {
 #pragma unroll
             for (int q = 0; q < DCH; q++) {
@@ -616,9 +740,10 @@ k_sgns_train(TrainParams p) {
     DGE_CLOSE_CENTRE();
 #undef DGE_TOK
 #undef DGE_CLOSE_CENTRE
-    if (lane == 0) {
+    if (lane == 0 && !atomics_wave) {
         if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
         if (my_words) atomicAdd(&p.counters[1], my_words);
+        if (use_mb && worker < p.n_workers) __hip_atomic_fetch_add(&s_mb_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // (behind this worker's last post)
     }
     if (HOT) hot_drain_block(s_hot, p.hs_n_hot * DCH * 64, p.syn1 + (size_t)p.hs_hot0 * (DCH * 64));
 }
@@ -743,82 +868,6 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
     }
 }
 
-// ---- HOTMIX: the head rows' atomics leave through an ATOMICS WAVE.
-// A wave waits for ITS OWN outstanding memory operations whenever it waits for anything (vmcnt counts loads, stores and atomics alike on
-// gfx9), so a worker that issues head-row atomics sits on their completion at its next try-lock — and the memory-side atomic unit, saturated
-// by the head, answers slowly: on cfg5 the atomic bytes (2.3 s at 1.24 TB/s) and the plain bytes (2.5 s) ADDED UP to the launch's 4.7 s,
-// although the memory system serves both at once (scripts/micro/atomic_overlap.hip: 3.64 ms together, 3.36 + 1.02 alone).  So the last wave
-// of every workgroup trains nothing: the 12 workers of the other three waves post (vector, rows, steps) messages into LDS boxes, the atomics
-// wave turns them into float atomics and never waits for their completion.  A message: LK_MB_HDR floats of header (count, then 16 rows as
-// int bits, then 16 steps) followed by the vector in element order; two boxes per worker.  Box states: 0 = free, 1 = rows of syn1neg, 2 = of syn0.
-#define LK_MB_WORKERS 12
-#define LK_MB_HDR 36
-template <int DCH> struct LkBox { static constexpr int FLOATS = LK_MB_HDR + DCH * 64; };
-__device__ __forceinline__ int lk_flag_load(int* f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lk_flag_store(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// worker side: lane j contributes (row, step) when row >= 0; `vec` is the 16-byte register layout (lane j: elements 64c + 4j .. 4j + 3)
-template <int DCH>
-__device__ __forceinline__ void lk_post(float* boxes, int* flags, int wk, unsigned& n_posts, int kind, int32_t row, float step, const Row<DCH>& vec, int lane) {
-    const int b = wk * 2 + (int)(n_posts & 1u);
-    float* box = boxes + (size_t)b * LkBox<DCH>::FLOATS;
-    for (;;) {                                              // (both boxes of this worker are still being read: wait for the older one)
-        int f = 0;
-        if (lane == 0) f = lk_flag_load(&flags[b]);
-        if (__shfl(f, 0, 16) == 0) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    const unsigned have = (unsigned)(__ballot(row >= 0) >> (threadIdx.x & 48)) & 0xFFFFu;
-    if (lane == 0) box[0] = __int_as_float((int)have);
-    box[1 + lane] = __int_as_float(row);
-    box[17 + lane] = step;
-#pragma unroll
-    for (int c = 0; c < DCH; c++) *(float4*)(box + LK_MB_HDR + c * 64 + 4 * lane) = vec.v[c];
-    if (lane == 0) lk_flag_store(&flags[b], kind);         // release: the box's contents are written before the flag turns
-    n_posts++;
-}
-// atomics wave: all 64 lanes on ONE message at a time — an atomic instruction then covers 256 contiguous bytes of a row (a wave can have ~63
-// memory instructions outstanding, and atomics on a saturated unit complete slowly: with one 16-lane group per message, 64 bytes an instruction,
-// the wave itself would cap the workgroup's atomic rate).  Returns when every worker of the workgroup has left and every box is free.
-template <int DCH>
-__device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* done, int n_workers_here, const TableView& syn0, const TableView& syn1neg) {
-    const int wl = threadIdx.x & 63;
-    for (;;) {
-        bool any = false;
-        for (int b = 0; b < LK_MB_WORKERS * 2; b++) {
-            const int f = __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b]));       // (every lane reads the same word)
-            if (f == 0) continue;
-            any = true;
-            const float* box = boxes + (size_t)b * LkBox<DCH>::FLOATS;
-            const unsigned have = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(box[0]));
-            const int32_t my_row = __float_as_int(box[1 + (wl & 15)]);
-            const float my_step = box[17 + (wl & 15)];
-            float v[DCH];
-#pragma unroll
-            for (int c = 0; c < DCH; c++) v[c] = box[LK_MB_HDR + c * 64 + wl];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                        // the box is in registers
-            if (wl == 0) lk_flag_store(&flags[b], 0);
-            const TableView& t = f == 2 ? syn0 : syn1neg;
-            for (unsigned left = have; left; left &= left - 1u) {
-                const int j = __builtin_ctz(left);
-                const int32_t row = __builtin_amdgcn_readlane(my_row, j);
-                const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_step), j));
-                float* pr = t.base + (size_t)row * (t.row_bytes / 4) + wl;
-#pragma unroll
-                for (int c = 0; c < DCH; c++)
-                    if ((uint32_t)(c * 64 + wl) < t.valid) atomicAdd(pr + c * 64, g * v[c]);
-            }
-        }
-        if (!any) {
-            const int d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (d >= n_workers_here) {                      // every worker has left: whatever it posted is visible now — one last look
-                bool left_over = false;
-                for (int b = 0; b < LK_MB_WORKERS * 2; b++) left_over |= __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b])) != 0;
-                if (!left_over) return;
-            } else __builtin_amdgcn_s_sleep(2);
-        }
-    }
-}
-
 #define LK_NEG_LANES 13      /* lanes 0..12 draw negatives, lane 13 = pending centre flush, lane 14 = the pair's syn0 row */
 #ifndef LK_CHUNK
 #define LK_CHUNK 10          /* negatives per lock round: a multiple of NEG_BATCH, so no batch of a full chunk loads filler rows */
@@ -849,7 +898,7 @@ k_sgns_train_locked(TrainParams p) {
     syn0.valid = syn1neg.valid = (uint32_t)p.D;
     if (use_mb && wk >= LK_MB_WORKERS) {
         const int64_t here = min((int64_t)LK_MB_WORKERS, p.n_workers - (int64_t)blockIdx.x * LK_MB_WORKERS);
-        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(here, (int64_t)0), syn0, syn1neg);
+        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(here, (int64_t)0), syn0, syn1neg, syn1neg);
         return;
     }
     if (worker >= p.n_workers) return;
