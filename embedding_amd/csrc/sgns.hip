@@ -663,7 +663,9 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     }
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
-    if (pol == 12 && workers > 1 && g_dge_tuning[DGE_TUNE_HS_WAVE] != 0) {
+    // (not on small vocabularies, where the worker count is capped at half the rows and every pair is a latency chain: the reference's own
+    //  801 x 8 tract graph with hierarchical softmax runs 407 ms per 6.5e7 pairs on its 3 204 workers, 552 ms on 2 400 workers and a wave)
+    if (pol == 12 && workers > 1 && (g_dge_tuning[DGE_TUNE_HS_WAVE] > 0 || (g_dge_tuning[DGE_TUNE_HS_WAVE] < 0 && m->V >= 65536))) {
         // hierarchical softmax under atomics: every workgroup's fourth wave issues the atomics of its 12 workers (k_sgns_train, lk_atomics_wave)
         p.hs_wave = 1;
         // (three workgroups a compute unit stay resident next to their LDS accumulators and message boxes: DGE_HS_WAVES)
