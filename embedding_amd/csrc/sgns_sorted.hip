@@ -333,6 +333,7 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
         int32_t k_l = -1; uint64_t v_l = 0;
         if (mine < stop) { k_l = q.key_in[mine]; v_l = q.val_in[mine]; }
         const int nb = (int)min((int64_t)16, stop - base);
+        float out_g = 0.f;                          // phase A: the step of the item this lane holds
         for (int g0 = 0; g0 < nb; g0 += SORTED_PIPE) {
             Row<DCH> o[SORTED_PIPE];
             int32_t key[SORTED_PIPE]; uint32_t vhi[SORTED_PIPE], vlo[SORTED_PIPE];
@@ -362,9 +363,14 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
                     const float g = sgns_g(f, (vlo[z] >> 31) ? 0.0f : 1.0f, fabsf(a), s_exp);
                     row_axpy(h, g, o[z]);
                     row_axpy(d, g, o[z]);
-                    if (lane == 0) { q.key_out[idx] = (int32_t)vhi[z] / q.kdiv; q.val_out[idx] = ((uint64_t)(uint32_t)OWN_ROW(key[z]) << 32) | (uint64_t)__float_as_uint(g); }
+                    if (lane == g0 + z) out_g = g;               // (the item's record for the second sort leaves with the other 15 of its batch, below)
                 }
             }
+        }
+        // phase A: (context key, target row | step) of the 16 items, one coalesced store each instead of 32 single-lane ones
+        if (!PB && mine < stop) {
+            q.key_out[mine] = (int32_t)(uint32_t)(v_l >> 32) / q.kdiv;
+            q.val_out[mine] = ((uint64_t)(uint32_t)OWN_ROW(k_l) << 32) | (uint64_t)__float_as_uint(out_g);
         }
     }
     SORTED_CLOSE(stop);
