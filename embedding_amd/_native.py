@@ -95,6 +95,7 @@ SIGNATURES = {
     "dge_model_ring_pass": (_int, [_vp, _vp, _i32]),
     "dge_model_gather_table": (_int, [_vp, _vp, _int]),
     "dge_set_tuning": (_int, [_i32, _i64]),
+    "dge_get_tuning": (_int, [_i32, _vp]),
     "dge_ndcg_at_k": (_int, [_int, _vp, _i32, _vp, _i32, _i32, _i32, _P(_dbl), _P(_dbl)]),
     "dge_knn_cosine": (_int, [_int, _vp, _i32, _i32, _i32, _vp, _vp, _P(_dbl)]),
     "dge_selftest_locked_rows": (_int, [_int, _i32, _i64, _i32, C.c_uint64, _i32, _P(_i64), _P(_dbl)]),

@@ -21,6 +21,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include "dge_algos.h"
 #include "dge_internal.h"
@@ -28,11 +30,114 @@
 #include "sgns_model.h"
 
 
-int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
     return DGE_OK;
+}
+extern "C" int dge_get_tuning(int32_t knob, int64_t* value) {
+    if (knob < 0 || knob >= DGE_TUNE_COUNT || !value) DGE_FAIL(DGE_ERR_ARG, "dge_get_tuning: unknown knob %d", knob);
+    *value = g_dge_tuning[knob];
+    return DGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ the model's large arrays
+// syn0, syn1neg, the lock words and the negative-sampling table are what a training launch reads and writes at random; where they lie
+// decides the launch time by up to 15 % (profiles/r02_box_drift.txt, profiles/r03_placement.txt).  They are obtained here, in one place,
+// so that the rule can be changed (and probed: DGE_TUNE_ALLOC) without touching the callers.
+struct BigAlloc { int mode; size_t bytes; size_t chunk; std::vector<hipMemGenericAllocationHandle_t> h; };
+static std::map<void*, BigAlloc> g_big_allocs;
+static std::mutex g_big_mu;
+static int big_alloc_mode() { return g_dge_tuning[DGE_TUNE_ALLOC] < 0 ? 0 : (int)g_dge_tuning[DGE_TUNE_ALLOC]; }
+static void big_free(void* p) {
+    if (!p) return;
+    BigAlloc a{0, 0, 0, {}};
+    { std::lock_guard<std::mutex> g(g_big_mu); auto it = g_big_allocs.find(p); if (it != g_big_allocs.end()) { a = it->second; g_big_allocs.erase(it); } }
+    if (a.mode >= 2) {
+        (void)hipMemUnmap(p, a.bytes);
+        for (auto& h : a.h) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(p, a.bytes);
+        return;
+    }
+    (void)hipFree(p);
+}
+// the arrays of one model, obtained together (modes 5 and 6 draw the arrays' physical chunks from one shuffled pool)
+static int big_alloc_group(int device, int n, void*** out, const size_t* bytes_in) {
+    const int mode = big_alloc_mode();
+    for (int i = 0; i < n; i++) *out[i] = nullptr;
+    if (mode <= 1) {
+        for (int i = 0; i < n; i++) {
+            const size_t bytes = bytes_in[i] ? bytes_in[i] : 4;
+            if (mode == 1) {
+                hipError_t e = hipExtMallocWithFlags(out[i], bytes, hipDeviceMallocContiguous);
+                if (e != hipSuccess) { (void)hipGetLastError(); DGE_FAIL(DGE_ERR_DEVICE, "hipExtMallocWithFlags(contiguous, %zu bytes) failed: %s", bytes, hipGetErrorName(e)); }
+            } else DGE_HIP(hipMalloc(out[i], bytes));
+        }
+        return DGE_OK;
+    }
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+    size_t gran = 0;
+    DGE_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    gran = std::max<size_t>(gran, (size_t)2 << 20);       // (the runtime recommends 4 KiB: a handle per 2 MiB is what the page tables can map as one fragment)
+    // physical chunk per handle: the whole array (2), the granularity (3, 4, 5), 16 MiB (6)
+    const size_t chunk0 = mode == 6 ? std::max<size_t>(gran, (size_t)16 << 20) : gran;
+    std::vector<size_t> sz(n), nch(n);
+    std::vector<std::vector<hipMemGenericAllocationHandle_t>> hs(n);
+    size_t total_chunks = 0;
+    for (int i = 0; i < n; i++) {
+        const size_t bytes = bytes_in[i] ? bytes_in[i] : 4;
+        const size_t ck = mode == 2 ? (bytes + gran - 1) / gran * gran : chunk0;
+        sz[i] = (bytes + ck - 1) / ck * ck; nch[i] = sz[i] / ck; total_chunks += nch[i];
+    }
+    // create every chunk first (the order of creation is the order the driver hands out physical memory) ...
+    std::vector<hipMemGenericAllocationHandle_t> pool;
+    auto fail_pool = [&]() { for (auto& h : pool) (void)hipMemRelease(h); };
+    for (int i = 0; i < n; i++)
+        for (size_t c = 0; c < nch[i]; c++) {
+            hipMemGenericAllocationHandle_t h;
+            hipError_t e = hipMemCreate(&h, sz[i] / nch[i], &prop, 0);
+            if (e != hipSuccess) { fail_pool(); DGE_FAIL(DGE_ERR_DEVICE, "hipMemCreate failed: %s", hipGetErrorName(e)); }
+            pool.push_back(h);
+        }
+    // ... then deal them out: in order (2, 3), shuffled inside each array (4), shuffled across the arrays of the group (5, 6: equal chunk sizes)
+    uint64_t rs = 0x9E3779B97F4A7C15ull;
+    auto shuffle = [&](size_t lo, size_t hi) { for (size_t k = hi; k > lo + 1; k--) { rs = rs * 6364136223846793005ull + 1442695040888963407ull; std::swap(pool[k - 1], pool[lo + (size_t)((rs >> 33) % (k - lo))]); } };
+    if (mode == 4) { size_t o = 0; for (int i = 0; i < n; i++) { shuffle(o, o + nch[i]); o += nch[i]; } }
+    if (mode == 5 || mode == 6) shuffle(0, pool.size());
+    size_t o = 0;
+    int rc = DGE_OK;
+    for (int i = 0; i < n && rc == DGE_OK; i++) {
+        void* va = nullptr;
+        hipError_t e = hipMemAddressReserve(&va, sz[i], (size_t)1 << 30, nullptr, 0);
+        if (e != hipSuccess) { dge_set_error("hipMemAddressReserve failed: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; break; }
+        const size_t ck = sz[i] / nch[i];
+        BigAlloc rec{mode, sz[i], ck, {}};
+        for (size_t c = 0; c < nch[i]; c++) {
+            e = hipMemMap((char*)va + c * ck, ck, 0, pool[o + c], 0);
+            if (e != hipSuccess) { dge_set_error("hipMemMap failed: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; break; }
+            rec.h.push_back(pool[o + c]);
+        }
+        if (rc == DGE_OK) {
+            hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+            e = hipMemSetAccess(va, sz[i], &acc, 1);
+            if (e != hipSuccess) { dge_set_error("hipMemSetAccess failed: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; }
+        }
+        if (rc != DGE_OK) {            // this array: undo what was mapped; its handles and the later arrays' are still in the pool
+            if (!rec.h.empty()) (void)hipMemUnmap(va, rec.h.size() * ck);
+            (void)hipMemAddressFree(va, sz[i]);
+            break;
+        }
+        { std::lock_guard<std::mutex> g(g_big_mu); g_big_allocs[va] = rec; }
+        *out[i] = va;
+        o += nch[i];
+    }
+    if (rc != DGE_OK) {
+        for (size_t k = o; k < pool.size(); k++) (void)hipMemRelease(pool[k]);
+        for (int i = 0; i < n; i++) { big_free(*out[i]); *out[i] = nullptr; }
+    }
+    return rc;
 }
 
 
@@ -78,6 +183,30 @@ __global__ void k_table_fill(const int32_t* __restrict__ m, int64_t V, int64_t T
     if (a >= T) return;
     int64_t i = a + (int64_t)min(0, m[a]);
     table[a] = (int32_t)min(i, V - 1);
+}
+
+// the table in rank-block form (neg_table_row, sgns_kernels.h): thread (block b, word k) collects the step bits of slots 96b + 32k .. + 31
+__global__ void k_table_pack(const int32_t* __restrict__ table, int64_t T, int64_t n_blocks, uint32_t* __restrict__ ctab) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_blocks * 3) return;
+    const int64_t b = i / 3; const int k = (int)(i - b * 3);
+    const int64_t a0 = b * DGE_CTAB_SLOTS + 32 * k;
+    uint32_t bits = 0;
+    int32_t prev = a0 > 0 && a0 - 1 < T ? table[a0 - 1] : 0;
+    for (int j = 0; j < 32; j++) {
+        const int64_t a = a0 + j;
+        if (a >= T) break;
+        const int32_t cur = table[a];
+        if (a > b * DGE_CTAB_SLOTS && cur != prev) bits |= 1u << j;
+        prev = cur;
+    }
+    ctab[b * 4 + 1 + k] = bits;
+    if (k == 0) ctab[b * 4] = (uint32_t)(b * DGE_CTAB_SLOTS < T ? table[b * DGE_CTAB_SLOTS] : 0);
+}
+// and back (dge_model_table): one thread per slot
+__global__ void k_table_unpack(const uint4* __restrict__ ctab, int64_t T, int32_t* __restrict__ table) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < T) table[a] = neg_table_row(ctab, nullptr, (uint64_t)a);
 }
 
 // word2vec.c InitNet: syn0[a][b] = ((lcg & 0xFFFF)/65536 - 0.5)/dim, one LCG stream over the whole table
@@ -280,10 +409,11 @@ extern "C" int dge_count_tokens(const dge_walks* w, int64_t row0, int64_t n_rows
 }
 
 static void model_release(dge_model* m) {
-    dge_dev_free(m->d_syn0); dge_dev_free(m->d_syn1neg); dge_dev_free(m->d_snap); dge_dev_free(m->d_vocab_ids);
+    big_free(m->d_syn0); big_free(m->d_syn1neg); big_free(m->d_locks); big_free(m->d_table); big_free(m->d_ctab);
+    dge_dev_free(m->d_snap); dge_dev_free(m->d_vocab_ids);
     dge_dev_free(m->d_syn1); dge_dev_free(m->d_hs_off); dge_dev_free(m->d_hs_points); dge_dev_free(m->d_hs_codes);
-    dge_dev_free(m->d_counts); dge_dev_free(m->d_remap); dge_dev_free(m->d_table); dge_dev_free(m->d_exp);
-    dge_dev_free(m->d_sen); dge_dev_free(m->d_len); dge_dev_free(m->d_wb); dge_dev_free(m->d_scan_tmp); dge_dev_free(m->d_counters); dge_dev_free(m->d_locks);
+    dge_dev_free(m->d_counts); dge_dev_free(m->d_remap); dge_dev_free(m->d_exp);
+    dge_dev_free(m->d_sen); dge_dev_free(m->d_len); dge_dev_free(m->d_wb); dge_dev_free(m->d_scan_tmp); dge_dev_free(m->d_counters);
     dge_sorted_release(m);
     for (auto& e : m->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
@@ -358,8 +488,15 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     m->V = V;
     // the two tables and their lock words first: before the unigram table and the 0.8 GB of temporaries its construction takes
     const size_t tab = (size_t)V * (size_t)m->stride;
-    MC(dge_dev_alloc(&m->d_syn0, tab + 64)); MC(dge_dev_alloc(&m->d_syn1neg, tab + 64));
-    MC(dge_dev_alloc(&m->d_locks, 2 * ((size_t)V + 1)));      // [0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows
+    m->ctab_blocks = (m->T + DGE_CTAB_SLOTS - 1) / DGE_CTAB_SLOTS;
+    // (the flat table only stays under DGE_TUNE_FULL_TABLE: the trainers read its rank-block form, built below)
+    const bool keep_flat = g_dge_tuning[DGE_TUNE_FULL_TABLE] > 0;
+    {
+        void** ptrs[5] = {(void**)&m->d_syn0, (void**)&m->d_syn1neg, (void**)&m->d_locks, (void**)&m->d_ctab, (void**)&m->d_table};
+        const size_t bytes[5] = {(tab + 64) * sizeof(float), (tab + 64) * sizeof(float), 2 * ((size_t)V + 1) * sizeof(int),     // locks [0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows
+                                 ((size_t)m->ctab_blocks + 1) * sizeof(uint4), (size_t)m->T * sizeof(int32_t)};
+        MC(big_alloc_group(device, keep_flat ? 5 : 4, ptrs, bytes));
+    }
     MC(dge_dev_alloc(&m->d_vocab_ids, (size_t)V)); MC(dge_dev_alloc(&m->d_counts, (size_t)V)); MC(dge_dev_alloc(&m->d_remap, (size_t)NV));
     if (V) {
         MH(hipMemcpyAsync(m->d_vocab_ids, d_ids_sorted.p, V * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -378,7 +515,7 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     m->total_words = tw;
 
     // --- unigram^0.75 cumulative (word2vec.c InitUnigramTable's running d1; a serial double sum by definition)
-    MC(dge_dev_alloc(&m->d_table, (size_t)m->T));
+    if (!keep_flat) MC(dge_dev_alloc(&m->d_table, (size_t)m->T));          // a temporary of this function
     if (V > 0) {
         std::vector<double> cum((size_t)V);
         double twp = 0.0; const double power = 0.75;
@@ -426,6 +563,9 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     } else {
         MH(hipMemsetAsync(m->d_table, 0, (size_t)m->T * sizeof(int32_t), st));
     }
+    hipLaunchKernelGGL(k_table_pack, dim3(grid_for(m->ctab_blocks * 3, 256)), dim3(256), 0, st, m->d_table, m->T, m->ctab_blocks, (uint32_t*)m->d_ctab);
+    MH(hipStreamSynchronize(st));
+    if (!keep_flat) { dge_dev_free(m->d_table); m->d_table = nullptr; }
 
     // --- sigmoid LUT (word2vec.c expTable) and weights
     {
@@ -542,7 +682,8 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
 
     TrainParams p;
     p.sen = m->d_sen; p.len = m->d_len; p.wb = m->d_wb;
-    p.syn0 = m->d_syn0; p.syn1neg = m->d_syn1neg; p.table = m->d_table; p.exp_table = m->d_exp;
+    p.syn0 = m->d_syn0; p.syn1neg = m->d_syn1neg; p.exp_table = m->d_exp;
+    p.ctab = m->d_ctab; p.table = (g_dge_tuning[DGE_TUNE_FULL_TABLE] > 0) ? m->d_table : nullptr;     // (null unless the model was created under that knob too)
     p.n_rows = n_rows; p.L = L; p.W = m->cfg.window; p.K = m->cfg.negative; p.stride = m->stride;
     p.V = m->V; p.T = m->T; p.seed = m->cfg.seed;
     p.gidx_base = (int64_t)epoch * total_walks + walk_index_base;
@@ -822,7 +963,13 @@ extern "C" int dge_model_table(dge_model* m, const int32_t** table, int64_t* tab
     if (!m || !table) DGE_FAIL(DGE_ERR_ARG, "dge_model_table: null argument");
     DGE_HIP(hipSetDevice(m->device));
     m->h_table.resize((size_t)m->T);
-    DGE_HIP(hipMemcpy(m->h_table.data(), m->d_table, (size_t)m->T * sizeof(int32_t), hipMemcpyDeviceToHost));
+    dge_tmp<int32_t> flat;                                   // word2vec's one-row-per-slot form, expanded from the rank blocks
+    int rc = flat.alloc((size_t)m->T);
+    if (rc) return rc;
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    hipLaunchKernelGGL(k_table_unpack, dim3(grid_for(m->T, 256)), dim3(256), 0, m->stream, m->d_ctab, m->T, flat.p);
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    DGE_HIP(hipMemcpy(m->h_table.data(), flat.p, (size_t)m->T * sizeof(int32_t), hipMemcpyDeviceToHost));
     *table = m->h_table.data();
     if (table_size) *table_size = m->T;
     return DGE_OK;
@@ -858,7 +1005,7 @@ extern "C" int dge_model_stats(const dge_model* mc, dge_train_stats* out) {
 // training speed while the device's copy rate does not move (profiles/r02_box_drift.txt): the difference follows the allocation, and this
 // probe shows which access it is without training anything.  16 lanes per row, 8 rows in flight per group; tables below 4 GiB.
 template <int MODE>
-__global__ void __launch_bounds__(256) k_probe_rows(float* t0, float* t1, int* locks, const int32_t* table, int64_t T, int64_t V, int32_t stride, int64_t reads_per_group,
+__global__ void __launch_bounds__(256) k_probe_rows(float* t0, float* t1, int* locks, const uint4* ctab, const int32_t* table, int64_t T, int64_t V, int32_t stride, int64_t reads_per_group,
                                                     float* sink) {
     const int lane = threadIdx.x & 15;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -869,7 +1016,7 @@ __global__ void __launch_bounds__(256) k_probe_rows(float* t0, float* t1, int* l
         for (int64_t i = 0; i < reads_per_group; i += 4) {
             int32_t t[4];
 #pragma unroll
-            for (int z = 0; z < 4; z++) { s = s * DGE_W2V_MULT + 11; t[z] = table[((s >> 16) + (uint64_t)lane * 0x9E3779B1ull) % (uint64_t)T]; }
+            for (int z = 0; z < 4; z++) { s = s * DGE_W2V_MULT + 11; t[z] = neg_table_row(ctab, table, ((s >> 16) + (uint64_t)lane * 0x9E3779B1ull) % (uint64_t)T); }
             acc += (float)(t[0] ^ t[1] ^ t[2] ^ t[3]);
         }
     } else if (MODE == 2) {
@@ -923,7 +1070,7 @@ extern "C" int dge_model_row_rates(dge_model* m, double* read_gb_per_s, double* 
         for (int r = 0; r < 3; r++) {
             DGE_HIP(hipEventRecord(e0, m->stream));
             const dim3 grid((unsigned)(groups * 16 / 256));
-#define PROBE(M) hipLaunchKernelGGL(k_probe_rows<M>, grid, dim3(256), 0, m->stream, m->d_syn0, m->d_syn1neg, m->d_locks, m->d_table, m->T, m->V, m->stride, reads, sink.p)
+#define PROBE(M) hipLaunchKernelGGL(k_probe_rows<M>, grid, dim3(256), 0, m->stream, m->d_syn0, m->d_syn1neg, m->d_locks, m->d_ctab, (g_dge_tuning[DGE_TUNE_FULL_TABLE] > 0) ? m->d_table : nullptr, m->T, m->V, m->stride, reads, sink.p)
             if (mode == 0) PROBE(0); else if (mode == 1) PROBE(1); else if (mode == 2) PROBE(2); else PROBE(3);
 #undef PROBE
             DGE_HIP(hipEventRecord(e1, m->stream));

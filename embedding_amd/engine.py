@@ -367,22 +367,27 @@ class SgnsModel:
         check(lib.dge_model_import_delta(self._h, _dev_ptr(d_buf), float(scale)))
 
 
-TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7, "hs_cold": 8, "hs_wave": 9}      # include/dge.h: DGE_TUNE_*
+TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7, "hs_cold": 8, "hs_wave": 9,
+                "full_table": 10, "alloc": 11}      # include/dge.h: DGE_TUNE_*
 
 
 class tuning:
     """Context manager around dge_set_tuning (ablation / test knobs of the trainer; process-wide):
-    `with tuning(hot_rows=100): model.train(...)`.  Leaving the block puts the knobs back to the library's own rules."""
+    `with tuning(hot_rows=100): model.train(...)`.  Leaving the block puts the knobs back to what they were before it."""
 
     def __init__(self, **knobs):
         self.knobs = {TUNING_KNOBS[k]: int(v) for k, v in knobs.items()}
+        self.before = {}
 
     def __enter__(self):
         for k, v in self.knobs.items():
+            old = C.c_int64(-1)
+            check(lib.dge_get_tuning(k, C.byref(old)))
+            self.before[k] = old.value
             check(lib.dge_set_tuning(k, v))
         return self
 
     def __exit__(self, *exc):
         for k in self.knobs:
-            check(lib.dge_set_tuning(k, -1))
+            check(lib.dge_set_tuning(k, self.before.get(k, -1)))
         return False

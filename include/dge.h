@@ -311,9 +311,13 @@ enum {
     DGE_TUNE_STATIC_WALKS = 7,    /* > 0: the lock kernels' worker w trains walks w, w + workers, ... instead of taking them from a launch-wide counter */
     DGE_TUNE_HS_COLD = 8,         /* hierarchical softmax under atomics: inner nodes [0, value) take plain read-modify-write (default: those on < 2e-5 of the paths) */
     DGE_TUNE_HS_WAVE = 9,         /* hierarchical softmax under atomics: 0 = the workers issue their atomics themselves, 1 = through the workgroup's atomics wave (default: the wave from 65 536 rows on) */
-    DGE_TUNE_COUNT = 10
+    DGE_TUNE_FULL_TABLE = 10,     /* > 0: models created from now on keep word2vec's flat unigram table (4 B per slot) and the trainers read it instead of its rank-block form */
+    DGE_TUNE_ALLOC = 11,          /* how dge_model_create obtains syn0 / syn1neg / lock words / table: 0 hipMalloc, 1 hipExtMallocWithFlags(hipDeviceMallocContiguous),
+                                     2 virtual-memory API with a 1 GiB-aligned address range per array (placement experiments, profiles/r03_placement.txt) */
+    DGE_TUNE_COUNT = 12
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
+int  dge_get_tuning(int32_t knob, int64_t* value);   /* -1 = the library's own rule */
 
 /* ------------------------------------------------------------------------------------------------
  * Device self-test of the commit-lock protocol of update_policy 5 (new; no reference counterpart): n_workers groups
