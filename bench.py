@@ -69,9 +69,12 @@ def main():
     ap.add_argument("--force-exchange", action="store_true", help="run the delta exchange even with one rank (plumbing check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (debugging the multi-rank plumbing)")
-    ap.add_argument("--placement-trials", type=int, default=3,
-                    help="models created side by side before the timed region, one launch timed on each, the fastest kept (where the driver "
-                         "puts the tables is worth up to 15 %%: profiles/r02_box_drift.txt); 1 = the first model, whatever it got")
+    ap.add_argument("--placement-candidates", type=int, default=3,
+                    help="the library's placement search before the timed region (dge_model_tune_placement: each large array of the model is tried "
+                         "in up to N - 1 other allocations on a quarter-batch probe launch, the faster placement stays; tables restored afterwards; "
+                         "which physical memory an array received is worth up to 15 %%: profiles/r03_placement.txt); 1 = whatever the first allocation got")
+    ap.add_argument("--placement-trials", type=int, default=1,
+                    help="round 2's whole-model form of the same (SgnsModel.create_placed: this many models side by side, the fastest kept); default 1 = off")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="dge_set_tuning knob for experiments (hot_rows, hs_drain, sorted_chunk, sorted_walks, ...)")
     ap.add_argument("--rendezvous-check", action="store_true",
@@ -200,6 +203,17 @@ def main():
             return ms
         model, trial_ms = E.SgnsModel.create_placed(cfg, counts, local_rank, probe, trials=args.placement_trials, first=model)
         stage("placement trials: %s ms per launch, kept the fastest" % ", ".join("%.1f" % x for x in trial_ms))
+    placement = None
+    if args.placement_candidates > 1:
+        n_probe = max(min(BG if blocks else B, 1024), (BG if blocks else B) // 4)
+        if blocks:
+            model.set_partition(NB, rank if N > 1 else 0, rank if N > 1 else 0)
+        before, after, moved = model.tune_placement(corpus, 0, n_probe, candidates=args.placement_candidates)
+        if blocks:
+            model.set_partition(1)
+        placement = {"candidates": args.placement_candidates, "probe_walks": n_probe, "probe_ms_before": round(before, 2), "probe_ms_after": round(after, 2),
+                     "arrays_moved": moved}
+        stage("placement search: probe launch %.1f -> %.1f ms, %d arrays moved" % (before, after, moved))
     exchange = (N > 1 and not blocks) or args.force_exchange
     if exchange and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
@@ -302,12 +316,14 @@ def main():
             "config": {"workload": wl["name"], "vertices": NV, "edges": int(n_edges), "timeslices": T, "dim": D,
                        "negatives": K, "walk_len": L, "window": L, "walks_per_step_per_gpu": B,
                        "pairs_per_step_per_gpu": st["pairs"] / args.steps, "vocabulary": int((counts >= 2).sum().item()),
-                       "sgns_workers": args.workers, "placement_trial_ms": trial_ms and [round(x, 1) for x in trial_ms], "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, syn1neg partitions passed round a ring" % N if blocks and N > 1
+                       "sgns_workers": args.workers, "placement_search": placement, "placement_trial_ms": trial_ms and [round(x, 1) for x in trial_ms],
+                       "lr_horizon_epochs": 1000, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, syn1neg partitions passed round a ring" % N if blocks and N > 1
                                        else "SIMULATED rank 0 of a %d-rank block schedule on one GPU (value = this rank's share only)" % NB if blocks
                                        else "walk-shard x%d, RCCL all-reduce of deltas per step (comparison mode)" % N if N > 1 else "1 GPU"),
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None if (args.dim or args.negative >= 0 or NB > 1) else measured_traffic(args.workload, "hs" if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch),
+                         "traffic_source": "profiles/traffic.json: bytes per pair from the committed rocprofv3 PMC passes of this workload x the pairs of this run (not counters of this run)",
                          "kernel": kernel_name, "schedule": sched,
                          "ms_per_launch": ms_per_launch,
                          "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,

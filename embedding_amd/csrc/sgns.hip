@@ -30,7 +30,7 @@
 #include "sgns_model.h"
 
 
-int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
@@ -41,105 +41,6 @@ extern "C" int dge_get_tuning(int32_t knob, int64_t* value) {
     *value = g_dge_tuning[knob];
     return DGE_OK;
 }
-
-// ------------------------------------------------------------------------------------------ the model's large arrays
-// syn0, syn1neg, the lock words and the negative-sampling table are what a training launch reads and writes at random; where they lie
-// decides the launch time by up to 15 % (profiles/r02_box_drift.txt, profiles/r03_placement.txt).  They are obtained here, in one place,
-// so that the rule can be changed (and probed: DGE_TUNE_ALLOC) without touching the callers.
-struct BigAlloc { int mode; size_t bytes; size_t chunk; std::vector<hipMemGenericAllocationHandle_t> h; };
-static std::map<void*, BigAlloc> g_big_allocs;
-static std::mutex g_big_mu;
-static int big_alloc_mode() { return g_dge_tuning[DGE_TUNE_ALLOC] < 0 ? 0 : (int)g_dge_tuning[DGE_TUNE_ALLOC]; }
-static void big_free(void* p) {
-    if (!p) return;
-    BigAlloc a{0, 0, 0, {}};
-    { std::lock_guard<std::mutex> g(g_big_mu); auto it = g_big_allocs.find(p); if (it != g_big_allocs.end()) { a = it->second; g_big_allocs.erase(it); } }
-    if (a.mode >= 2) {
-        (void)hipMemUnmap(p, a.bytes);
-        for (auto& h : a.h) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(p, a.bytes);
-        return;
-    }
-    (void)hipFree(p);
-}
-// the arrays of one model, obtained together (modes 5 and 6 draw the arrays' physical chunks from one shuffled pool)
-static int big_alloc_group(int device, int n, void*** out, const size_t* bytes_in) {
-    const int mode = big_alloc_mode();
-    for (int i = 0; i < n; i++) *out[i] = nullptr;
-    if (mode <= 1) {
-        for (int i = 0; i < n; i++) {
-            const size_t bytes = bytes_in[i] ? bytes_in[i] : 4;
-            if (mode == 1) {
-                hipError_t e = hipExtMallocWithFlags(out[i], bytes, hipDeviceMallocContiguous);
-                if (e != hipSuccess) { (void)hipGetLastError(); DGE_FAIL(DGE_ERR_DEVICE, "hipExtMallocWithFlags(contiguous, %zu bytes) failed: %s", bytes, hipGetErrorName(e)); }
-            } else DGE_HIP(hipMalloc(out[i], bytes));
-        }
-        return DGE_OK;
-    }
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
-    size_t gran = 0;
-    DGE_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-    gran = std::max<size_t>(gran, (size_t)2 << 20);       // (the runtime recommends 4 KiB: a handle per 2 MiB is what the page tables can map as one fragment)
-    // physical chunk per handle: the whole array (2), the granularity (3, 4, 5), 16 MiB (6)
-    const size_t chunk0 = mode == 6 ? std::max<size_t>(gran, (size_t)16 << 20) : gran;
-    std::vector<size_t> sz(n), nch(n);
-    std::vector<std::vector<hipMemGenericAllocationHandle_t>> hs(n);
-    size_t total_chunks = 0;
-    for (int i = 0; i < n; i++) {
-        const size_t bytes = bytes_in[i] ? bytes_in[i] : 4;
-        const size_t ck = mode == 2 ? (bytes + gran - 1) / gran * gran : chunk0;
-        sz[i] = (bytes + ck - 1) / ck * ck; nch[i] = sz[i] / ck; total_chunks += nch[i];
-    }
-    // create every chunk first (the order of creation is the order the driver hands out physical memory) ...
-    std::vector<hipMemGenericAllocationHandle_t> pool;
-    auto fail_pool = [&]() { for (auto& h : pool) (void)hipMemRelease(h); };
-    for (int i = 0; i < n; i++)
-        for (size_t c = 0; c < nch[i]; c++) {
-            hipMemGenericAllocationHandle_t h;
-            hipError_t e = hipMemCreate(&h, sz[i] / nch[i], &prop, 0);
-            if (e != hipSuccess) { fail_pool(); DGE_FAIL(DGE_ERR_DEVICE, "hipMemCreate failed: %s", hipGetErrorName(e)); }
-            pool.push_back(h);
-        }
-    // ... then deal them out: in order (2, 3), shuffled inside each array (4), shuffled across the arrays of the group (5, 6: equal chunk sizes)
-    uint64_t rs = 0x9E3779B97F4A7C15ull;
-    auto shuffle = [&](size_t lo, size_t hi) { for (size_t k = hi; k > lo + 1; k--) { rs = rs * 6364136223846793005ull + 1442695040888963407ull; std::swap(pool[k - 1], pool[lo + (size_t)((rs >> 33) % (k - lo))]); } };
-    if (mode == 4) { size_t o = 0; for (int i = 0; i < n; i++) { shuffle(o, o + nch[i]); o += nch[i]; } }
-    if (mode == 5 || mode == 6) shuffle(0, pool.size());
-    size_t o = 0;
-    int rc = DGE_OK;
-    for (int i = 0; i < n && rc == DGE_OK; i++) {
-        void* va = nullptr;
-        hipError_t e = hipMemAddressReserve(&va, sz[i], (size_t)1 << 30, nullptr, 0);
-        if (e != hipSuccess) { dge_set_error("hipMemAddressReserve failed: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; break; }
-        const size_t ck = sz[i] / nch[i];
-        BigAlloc rec{mode, sz[i], ck, {}};
-        for (size_t c = 0; c < nch[i]; c++) {
-            e = hipMemMap((char*)va + c * ck, ck, 0, pool[o + c], 0);
-            if (e != hipSuccess) { dge_set_error("hipMemMap failed: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; break; }
-            rec.h.push_back(pool[o + c]);
-        }
-        if (rc == DGE_OK) {
-            hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
-            e = hipMemSetAccess(va, sz[i], &acc, 1);
-            if (e != hipSuccess) { dge_set_error("hipMemSetAccess failed: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; }
-        }
-        if (rc != DGE_OK) {            // this array: undo what was mapped; its handles and the later arrays' are still in the pool
-            if (!rec.h.empty()) (void)hipMemUnmap(va, rec.h.size() * ck);
-            (void)hipMemAddressFree(va, sz[i]);
-            break;
-        }
-        { std::lock_guard<std::mutex> g(g_big_mu); g_big_allocs[va] = rec; }
-        *out[i] = va;
-        o += nch[i];
-    }
-    if (rc != DGE_OK) {
-        for (size_t k = o; k < pool.size(); k++) (void)hipMemRelease(pool[k]);
-        for (int i = 0; i < n; i++) { big_free(*out[i]); *out[i] = nullptr; }
-    }
-    return rc;
-}
-
 
 // ------------------------------------------------------------------------------------------ vocabulary
 __global__ void k_count_tokens(const int32_t* __restrict__ walks, int64_t n, int32_t NV, unsigned long long* counts) {
@@ -206,7 +107,7 @@ __global__ void k_table_pack(const int32_t* __restrict__ table, int64_t T, int64
 // and back (dge_model_table): one thread per slot
 __global__ void k_table_unpack(const uint4* __restrict__ ctab, int64_t T, int32_t* __restrict__ table) {
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a < T) table[a] = neg_table_row(ctab, nullptr, (uint64_t)a);
+    if (a < T) table[a] = neg_table_row(ctab, (uint64_t)a);
 }
 
 // word2vec.c InitNet: syn0[a][b] = ((lcg & 0xFFFF)/65536 - 0.5)/dim, one LCG stream over the whole table
@@ -409,7 +310,7 @@ extern "C" int dge_count_tokens(const dge_walks* w, int64_t row0, int64_t n_rows
 }
 
 static void model_release(dge_model* m) {
-    big_free(m->d_syn0); big_free(m->d_syn1neg); big_free(m->d_locks); big_free(m->d_table); big_free(m->d_ctab);
+    dge_dev_free(m->d_syn0); dge_dev_free(m->d_syn1neg); dge_dev_free(m->d_locks); dge_dev_free(m->d_ctab);
     dge_dev_free(m->d_snap); dge_dev_free(m->d_vocab_ids);
     dge_dev_free(m->d_syn1); dge_dev_free(m->d_hs_off); dge_dev_free(m->d_hs_points); dge_dev_free(m->d_hs_codes);
     dge_dev_free(m->d_counts); dge_dev_free(m->d_remap); dge_dev_free(m->d_exp);
@@ -489,14 +390,9 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     // the two tables and their lock words first: before the unigram table and the 0.8 GB of temporaries its construction takes
     const size_t tab = (size_t)V * (size_t)m->stride;
     m->ctab_blocks = (m->T + DGE_CTAB_SLOTS - 1) / DGE_CTAB_SLOTS;
-    // (the flat table only stays under DGE_TUNE_FULL_TABLE: the trainers read its rank-block form, built below)
-    const bool keep_flat = g_dge_tuning[DGE_TUNE_FULL_TABLE] > 0;
-    {
-        void** ptrs[5] = {(void**)&m->d_syn0, (void**)&m->d_syn1neg, (void**)&m->d_locks, (void**)&m->d_ctab, (void**)&m->d_table};
-        const size_t bytes[5] = {(tab + 64) * sizeof(float), (tab + 64) * sizeof(float), 2 * ((size_t)V + 1) * sizeof(int),     // locks [0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows
-                                 ((size_t)m->ctab_blocks + 1) * sizeof(uint4), (size_t)m->T * sizeof(int32_t)};
-        MC(big_alloc_group(device, keep_flat ? 5 : 4, ptrs, bytes));
-    }
+    MC(dge_dev_alloc(&m->d_syn0, tab + 64)); MC(dge_dev_alloc(&m->d_syn1neg, tab + 64));
+    MC(dge_dev_alloc(&m->d_locks, 2 * ((size_t)V + 1)));      // [0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows
+    MC(dge_dev_alloc(&m->d_ctab, (size_t)m->ctab_blocks + 1));
     MC(dge_dev_alloc(&m->d_vocab_ids, (size_t)V)); MC(dge_dev_alloc(&m->d_counts, (size_t)V)); MC(dge_dev_alloc(&m->d_remap, (size_t)NV));
     if (V) {
         MH(hipMemcpyAsync(m->d_vocab_ids, d_ids_sorted.p, V * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -515,7 +411,8 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     m->total_words = tw;
 
     // --- unigram^0.75 cumulative (word2vec.c InitUnigramTable's running d1; a serial double sum by definition)
-    if (!keep_flat) MC(dge_dev_alloc(&m->d_table, (size_t)m->T));          // a temporary of this function
+    dge_tmp<int32_t> d_flat;                                 // word2vec's one-row-per-slot table: a temporary, the trainers read its rank-block form
+    MC(d_flat.alloc((size_t)m->T));
     if (V > 0) {
         std::vector<double> cum((size_t)V);
         double twp = 0.0; const double power = 0.75;
@@ -558,14 +455,13 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         MH(hipcub::DeviceScan::ExclusiveScan(nullptr, tmp_bytes, d_g.p, d_m.p, hipcub::Min(), (int32_t)0, m->T, st));
         MC(d_tmp2.alloc(tmp_bytes));
         MH(hipcub::DeviceScan::ExclusiveScan((void*)d_tmp2.p, tmp_bytes, d_g.p, d_m.p, hipcub::Min(), (int32_t)0, m->T, st));
-        hipLaunchKernelGGL(k_table_fill, dim3(grid_for(m->T, 256)), dim3(256), 0, st, d_m.p, V, m->T, m->d_table);
+        hipLaunchKernelGGL(k_table_fill, dim3(grid_for(m->T, 256)), dim3(256), 0, st, d_m.p, V, m->T, d_flat.p);
         MH(hipStreamSynchronize(st));
     } else {
-        MH(hipMemsetAsync(m->d_table, 0, (size_t)m->T * sizeof(int32_t), st));
+        MH(hipMemsetAsync(d_flat.p, 0, (size_t)m->T * sizeof(int32_t), st));
     }
-    hipLaunchKernelGGL(k_table_pack, dim3(grid_for(m->ctab_blocks * 3, 256)), dim3(256), 0, st, m->d_table, m->T, m->ctab_blocks, (uint32_t*)m->d_ctab);
+    hipLaunchKernelGGL(k_table_pack, dim3(grid_for(m->ctab_blocks * 3, 256)), dim3(256), 0, st, d_flat.p, m->T, m->ctab_blocks, (uint32_t*)m->d_ctab);
     MH(hipStreamSynchronize(st));
-    if (!keep_flat) { dge_dev_free(m->d_table); m->d_table = nullptr; }
 
     // --- sigmoid LUT (word2vec.c expTable) and weights
     {
@@ -683,7 +579,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     TrainParams p;
     p.sen = m->d_sen; p.len = m->d_len; p.wb = m->d_wb;
     p.syn0 = m->d_syn0; p.syn1neg = m->d_syn1neg; p.exp_table = m->d_exp;
-    p.ctab = m->d_ctab; p.table = (g_dge_tuning[DGE_TUNE_FULL_TABLE] > 0) ? m->d_table : nullptr;     // (null unless the model was created under that knob too)
+    p.ctab = m->d_ctab;
     p.n_rows = n_rows; p.L = L; p.W = m->cfg.window; p.K = m->cfg.negative; p.stride = m->stride;
     p.V = m->V; p.T = m->T; p.seed = m->cfg.seed;
     p.gidx_base = (int64_t)epoch * total_walks + walk_index_base;
@@ -873,6 +769,8 @@ extern "C" int dge_model_walk_and_train(dge_model* m, const dge_graph* g, dge_wa
     return train_rows(m, w->d + row0 * w->L, n_rows, w->L, walk_index_base, epoch, words_before, words_scale, total_walks, w->gen);
 }
 
+extern "C" int dge_model_tune_placement(dge_model* m, const dge_walks* w, int64_t row0, int64_t n_rows, int32_t candidates, double* ms_before, double* ms_after,
+                                        int32_t* arrays_moved);
 extern "C" int dge_train_sgns_device(const dge_walks* w, const dge_train_config* cfg, dge_model** out) {
     if (!w || !cfg || !out) DGE_FAIL(DGE_ERR_ARG, "dge_train_sgns_device: null argument");
     *out = nullptr;
@@ -887,6 +785,11 @@ extern "C" int dge_train_sgns_device(const dge_walks* w, const dge_train_config*
     if (!rc) rc = dge_model_create(w->device, cfg, d_counts, &m);
     dge_dev_free(d_counts);
     if (rc) return rc;
+    // models whose launches are long enough for it to pay get the placement search first (results are unaffected: dge_model_tune_placement)
+    if (!rc && cfg->epochs > 0 && cfg->workers != 1 && m->V >= 262144 && w->n >= 262144) {
+        double before = 0, after = 0; int32_t moved = 0;
+        rc = dge_model_tune_placement(m, w, 0, std::min<int64_t>(w->n / 8, 262144), 3, &before, &after, &moved);
+    }
     for (int ep = 0; ep < cfg->epochs && !rc; ep++) rc = dge_model_train(m, w, 0, w->n, 0, ep, 0, 1.0, w->n);
     if (!rc) { hipError_t e = hipStreamSynchronize(m->stream); if (e != hipSuccess) { dge_set_error("training failed: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; } }
     if (rc) { dge_model_free(m); return rc; }
@@ -1005,7 +908,7 @@ extern "C" int dge_model_stats(const dge_model* mc, dge_train_stats* out) {
 // training speed while the device's copy rate does not move (profiles/r02_box_drift.txt): the difference follows the allocation, and this
 // probe shows which access it is without training anything.  16 lanes per row, 8 rows in flight per group; tables below 4 GiB.
 template <int MODE>
-__global__ void __launch_bounds__(256) k_probe_rows(float* t0, float* t1, int* locks, const uint4* ctab, const int32_t* table, int64_t T, int64_t V, int32_t stride, int64_t reads_per_group,
+__global__ void __launch_bounds__(256) k_probe_rows(float* t0, float* t1, int* locks, const uint4* ctab, int64_t T, int64_t V, int32_t stride, int64_t reads_per_group,
                                                     float* sink) {
     const int lane = threadIdx.x & 15;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -1016,7 +919,7 @@ __global__ void __launch_bounds__(256) k_probe_rows(float* t0, float* t1, int* l
         for (int64_t i = 0; i < reads_per_group; i += 4) {
             int32_t t[4];
 #pragma unroll
-            for (int z = 0; z < 4; z++) { s = s * DGE_W2V_MULT + 11; t[z] = neg_table_row(ctab, table, ((s >> 16) + (uint64_t)lane * 0x9E3779B1ull) % (uint64_t)T); }
+            for (int z = 0; z < 4; z++) { s = s * DGE_W2V_MULT + 11; t[z] = neg_table_row(ctab, ((s >> 16) + (uint64_t)lane * 0x9E3779B1ull) % (uint64_t)T); }
             acc += (float)(t[0] ^ t[1] ^ t[2] ^ t[3]);
         }
     } else if (MODE == 2) {
@@ -1070,7 +973,7 @@ extern "C" int dge_model_row_rates(dge_model* m, double* read_gb_per_s, double* 
         for (int r = 0; r < 3; r++) {
             DGE_HIP(hipEventRecord(e0, m->stream));
             const dim3 grid((unsigned)(groups * 16 / 256));
-#define PROBE(M) hipLaunchKernelGGL(k_probe_rows<M>, grid, dim3(256), 0, m->stream, m->d_syn0, m->d_syn1neg, m->d_locks, m->d_ctab, (g_dge_tuning[DGE_TUNE_FULL_TABLE] > 0) ? m->d_table : nullptr, m->T, m->V, m->stride, reads, sink.p)
+#define PROBE(M) hipLaunchKernelGGL(k_probe_rows<M>, grid, dim3(256), 0, m->stream, m->d_syn0, m->d_syn1neg, m->d_locks, m->d_ctab, m->T, m->V, m->stride, reads, sink.p)
             if (mode == 0) PROBE(0); else if (mode == 1) PROBE(1); else if (mode == 2) PROBE(2); else PROBE(3);
 #undef PROBE
             DGE_HIP(hipEventRecord(e1, m->stream));
@@ -1088,6 +991,91 @@ extern "C" int dge_model_row_rates(dge_model* m, double* read_gb_per_s, double* 
     if (lock_exchanges_per_s) *lock_exchanges_per_s = best[2];
     if (table_lookups_per_s) *table_lookups_per_s = best[3];
     return DGE_OK;
+}
+
+// ---- dge_model_tune_placement.  Which physical memory hipMalloc hands an array decides a training launch's duration by up to 15 %, array by
+// array, and no allocation rule (contiguous blocks, aligned ranges, shuffled 2 MiB chunks) nor any cheap probe of the memory predicts it
+// (profiles/r02_box_drift.txt, profiles/r03_placement.txt).  So the library searches with the only probe that works, the caller's own launch:
+// rows [row0, row0 + n_rows) of `w` are trained once for a baseline; then, one array at a time (negative-sampling table, lock words, syn1neg,
+// syn0), a copy in freshly allocated memory takes the array's place, the same rows are trained again, and the faster placement stays.
+// Rejected placements are only freed at the end (the allocator would hand the same memory out again).  The tables' contents and the
+// model's counters are saved first and restored last: training results are exactly those of an untuned model.
+static int tune_time_launch(dge_model* m, const dge_walks* w, int64_t row0, int64_t n_rows, double* ms) {
+    hipEvent_t a, b;
+    DGE_HIP(hipEventCreate(&a)); DGE_HIP(hipEventCreate(&b));
+    DGE_HIP(hipEventRecord(a, m->stream));
+    int rc = train_rows(m, w->d + row0 * w->L, n_rows, w->L, 0, 0, 0, 1.0, std::max<int64_t>(w->n, 1), w->gen);
+    if (rc == DGE_OK) {
+        if (hipEventRecord(b, m->stream) != hipSuccess || hipEventSynchronize(b) != hipSuccess) { dge_set_error("dge_model_tune_placement: the probe launch failed"); rc = DGE_ERR_DEVICE; }
+        float t = 0.f;
+        if (rc == DGE_OK && hipEventElapsedTime(&t, a, b) == hipSuccess) *ms = t;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return rc;
+}
+
+extern "C" int dge_model_tune_placement(dge_model* m, const dge_walks* w, int64_t row0, int64_t n_rows, int32_t candidates, double* ms_before, double* ms_after,
+                                        int32_t* arrays_moved) {
+    if (!m || !w || row0 < 0 || n_rows <= 0 || row0 + n_rows > w->n || candidates < 1) DGE_FAIL(DGE_ERR_ARG, "dge_model_tune_placement: bad argument");
+    if (w->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_tune_placement: corpus and model live on different devices");
+    DGE_HIP(hipSetDevice(m->device));
+    int rc = drain_events(m);
+    if (rc) return rc;
+    if (ms_before) *ms_before = 0; if (ms_after) *ms_after = 0; if (arrays_moved) *arrays_moved = 0;
+    if (m->V == 0) return DGE_OK;
+    hipStream_t st = m->stream;
+    const size_t tab_bytes = ((size_t)m->V * (size_t)m->stride + 64) * sizeof(float);
+    const size_t lock_bytes = 2 * ((size_t)m->V + 1) * sizeof(int), ctab_bytes = ((size_t)m->ctab_blocks + 1) * sizeof(uint4);
+    // what a probe launch changes: the two tables (syn1 too under hierarchical softmax), the counters, the launch statistics
+    dge_tmp<char> keep0, keep1, keep2;
+    if ((rc = keep0.alloc(tab_bytes)) || (rc = keep1.alloc(tab_bytes))) return rc;
+    if (m->d_syn1 && (rc = keep2.alloc(tab_bytes))) return rc;
+    unsigned long long counters[3] = {0, 0, 0};
+    DGE_HIP(hipMemcpyAsync(keep0.p, m->d_syn0, tab_bytes, hipMemcpyDeviceToDevice, st));
+    DGE_HIP(hipMemcpyAsync(keep1.p, m->d_syn1neg, tab_bytes, hipMemcpyDeviceToDevice, st));
+    if (m->d_syn1) DGE_HIP(hipMemcpyAsync(keep2.p, m->d_syn1, tab_bytes, hipMemcpyDeviceToDevice, st));
+    DGE_HIP(hipMemcpyAsync(counters, m->d_counters, sizeof(counters), hipMemcpyDeviceToHost, st));
+    DGE_HIP(hipStreamSynchronize(st));
+    const double k_ms = m->kernel_ms, w_ms = m->walk_ms; const int64_t launches = m->launches;
+    const int lp = m->last_policy; const int64_t lw = m->last_workers; const int32_t lh = m->last_hot_rows;
+
+    std::vector<void*> graveyard;
+    double best = 0, first = 0;
+    int moved = 0;
+    rc = tune_time_launch(m, w, row0, n_rows, &best);          // warm-up (work buffers, the owner-computes schedule's lazy allocations)
+    if (rc == DGE_OK) rc = tune_time_launch(m, w, row0, n_rows, &best);
+    first = best;
+    struct Slot { void** p; size_t bytes; };
+    Slot slots[4] = {{(void**)&m->d_ctab, ctab_bytes}, {(void**)&m->d_locks, lock_bytes}, {(void**)&m->d_syn1neg, tab_bytes}, {(void**)&m->d_syn0, tab_bytes}};
+    for (int a = 0; a < 4 && rc == DGE_OK; a++)
+        for (int c = 1; c < candidates && rc == DGE_OK; c++) {
+            void* fresh = nullptr;
+            if (hipMalloc(&fresh, slots[a].bytes) != hipSuccess) { (void)hipGetLastError(); break; }      // out of memory: keep what we have
+            void* old = *slots[a].p;
+            if (hipMemcpyAsync(fresh, old, slots[a].bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { (void)hipFree(fresh); dge_set_error("dge_model_tune_placement: copy failed"); rc = DGE_ERR_DEVICE; break; }
+            *slots[a].p = fresh;
+            double t = 0;
+            rc = tune_time_launch(m, w, row0, n_rows, &t);
+            if (rc == DGE_OK && t < best * 0.995) { best = t; graveyard.push_back(old); moved++; }
+            else { *slots[a].p = old; graveyard.push_back(fresh); }
+        }
+    hipError_t e = hipStreamSynchronize(st);
+    for (void* g : graveyard) (void)hipFree(g);
+    if (rc == DGE_OK && e != hipSuccess) { dge_set_error("dge_model_tune_placement: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; }
+    // put everything back as it was before the probes
+    DGE_HIP(hipMemcpyAsync(m->d_syn0, keep0.p, tab_bytes, hipMemcpyDeviceToDevice, st));
+    DGE_HIP(hipMemcpyAsync(m->d_syn1neg, keep1.p, tab_bytes, hipMemcpyDeviceToDevice, st));
+    if (m->d_syn1) DGE_HIP(hipMemcpyAsync(m->d_syn1, keep2.p, tab_bytes, hipMemcpyDeviceToDevice, st));
+    DGE_HIP(hipMemsetAsync(m->d_locks, 0, lock_bytes, st));
+    DGE_HIP(hipMemcpyAsync(m->d_counters, counters, sizeof(counters), hipMemcpyHostToDevice, st));
+    DGE_HIP(hipStreamSynchronize(st));
+    int rc2 = drain_events(m);
+    m->kernel_ms = k_ms; m->walk_ms = w_ms; m->launches = launches;
+    m->last_policy = lp; m->last_workers = lw; m->last_hot_rows = lh;
+    m->seen_gen = 0;                                           // (the next launch derives its rows again)
+    if (rc == DGE_OK) rc = rc2;
+    if (ms_before) *ms_before = first; if (ms_after) *ms_after = best; if (arrays_moved) *arrays_moved = moved;
+    return rc;
 }
 
 extern "C" int dge_model_schedule(const dge_model* m, int32_t* update_policy, int64_t* workers, int32_t* hot_rows) {

@@ -25,8 +25,7 @@
 struct TrainParams {
     const int32_t* sen; const int64_t* len; const int64_t* wb;
     float* syn0; float* syn1neg;
-    const int32_t* table;     // word2vec's unigram^0.75 table, one row number per slot (400 MB at the default 1e8 slots) — ablation only (DGE_TUNE_FULL_TABLE); null otherwise
-    const uint4* ctab;        // the same table in rank-block form (neg_table_row): 16 B per 96 slots
+    const uint4* ctab;        // word2vec's unigram^0.75 table in rank-block form (neg_table_row): 16 B per 96 slots
     const float* exp_table;
     int64_t n_rows; int32_t L, W, K, stride;
     int32_t D;                // the rows' meaningful floats (stride = D rounded up to 64: the rest is zero padding and stays zero)
@@ -96,11 +95,10 @@ __device__ __forceinline__ int32_t part_row(int32_t t, int32_t n, int32_t part, 
 
 // The unigram^0.75 table of word2vec.c (InitUnigramTable) is a step function: table[a + 1] - table[a] is 0 or 1 (k_table_fill).  So it is kept
 // as rank blocks — per 96 slots one 16-byte record {row of the block's first slot, 96 step bits} — and a look-up is ONE 16-byte load plus three
-// popcounts: row(a) = first + #steps in (96b, a].  1e8 slots are 16.7 MB instead of 400 MB: the look-ups of a launch (5 per pair, 1.9e9 on cfg3)
-// hit the Infinity Cache and 8 translation entries instead of drawing a random 64-byte sector and a TLB miss each.  Same rows as table[a], bit for bit.
+// popcounts: row(a) = first + #steps in (96b, a].  1e8 slots are 16.7 MB instead of 400 MB, cache resident, 8.0e10 instead of 5.5e10 look-ups/s alone;
+// inside the trainer it is worth nothing measurable (profiles/r03_placement.txt) — it is kept for the 383 MB.  Same rows as table[a], bit for bit.
 #define DGE_CTAB_SLOTS 96u
-__device__ __forceinline__ int32_t neg_table_row(const uint4* __restrict__ ctab, const int32_t* __restrict__ table, uint64_t slot) {
-    if (table) return table[slot];                       // (ablation: the flat table)
+__device__ __forceinline__ int32_t neg_table_row(const uint4* __restrict__ ctab, uint64_t slot) {
     const uint32_t a = (uint32_t)slot, b = a / DGE_CTAB_SLOTS, j = a - b * DGE_CTAB_SLOTS;
     const uint4 r = ctab[b];
     // steps at positions 1..j of the block (bit 0 of every block is clear)
@@ -688,7 +686,7 @@ k_sgns_train(TrainParams p) {
             const uint64_t sl = s * mA + cA;
             int32_t t = -1;
             if (lane < kc) {
-                t = neg_table_row(p.ctab, p.table, (sl >> 16) % (uint64_t)p.T);
+                t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
                 if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                 if (PART) t = part_row(t, p.part_n, p.part_tgt, p.V);
                 if (t == word) t = -1;
@@ -1068,7 +1066,7 @@ k_sgns_train_locked(TrainParams p) {
             } else {
                 const uint64_t sl = s * mA + cA;
                 if (lane < kc) {
-                    t = neg_table_row(p.ctab, p.table, (sl >> 16) % (uint64_t)p.T);
+                    t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
                     if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                     if (PART) t = part_row(t, p.part_n, p.part_tgt, p.V);
                     if (t == word) t = -1;

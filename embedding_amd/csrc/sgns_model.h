@@ -36,8 +36,7 @@ struct dge_model {
     int32_t* d_vocab_ids = nullptr;
     int64_t* d_counts = nullptr;
     int32_t* d_remap = nullptr;
-    int32_t* d_table = nullptr;                 // word2vec's flat unigram table: only under DGE_TUNE_FULL_TABLE (ablation)
-    uint4* d_ctab = nullptr; int64_t ctab_blocks = 0;   // its rank-block form (neg_table_row), what the trainers read
+    uint4* d_ctab = nullptr; int64_t ctab_blocks = 0;   // word2vec's unigram table in rank-block form (neg_table_row)
     int32_t hs_cold_auto = 0;                   // hierarchical softmax: inner nodes [0, hs_cold_auto) are each on fewer than 2e-5 of the paths
     float* d_exp = nullptr;
     // per-call work buffers

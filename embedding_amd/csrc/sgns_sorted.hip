@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
                         if (K <= 16) {                                                    // (more negatives than lanes: one pair per trip, below)
                             const uint64_t sl = s * mA + cA;
                             if (lane < K) {
-                                int32_t t = neg_table_row(p.ctab, p.table, (sl >> 16) % (uint64_t)p.T);
+                                int32_t t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
                                 if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                                 tv[z] = t;
                             }
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
                             const int kc = min(16, K - kd);
                             const uint64_t sl = s * mA + cA;
                             if (lane < kc) {
-                                int32_t t = neg_table_row(p.ctab, p.table, (sl >> 16) % (uint64_t)p.T);
+                                int32_t t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
                                 if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                                 if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
                                 q.key_out[slot + 1 + kd + lane] = t == word ? q.Vk : t / q.kdiv;

@@ -320,6 +320,15 @@ class SgnsModel:
         v = [C.c_double(0) for _ in range(4)]
         check(lib.dge_model_row_rates(self._h, *[C.byref(x) for x in v])); return tuple(x.value for x in v)
 
+    def tune_placement(self, corpus, row0=0, n_rows=None, candidates=3):
+        """Placement search (include/dge.h: dge_model_tune_placement): -> (probe ms before, probe ms after, arrays moved).  The model's tables,
+        counters and statistics are as before the call."""
+        if n_rows is None:
+            n_rows = corpus.shape[0] - row0
+        a, b, n = C.c_double(0), C.c_double(0), C.c_int32(0)
+        check(lib.dge_model_tune_placement(self._h, corpus._h, int(row0), int(n_rows), int(candidates), C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
     def stats(self):
         s = TrainStats()
         check(lib.dge_model_stats(self._h, C.byref(s)))
@@ -367,8 +376,7 @@ class SgnsModel:
         check(lib.dge_model_import_delta(self._h, _dev_ptr(d_buf), float(scale)))
 
 
-TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7, "hs_cold": 8, "hs_wave": 9,
-                "full_table": 10, "alloc": 11}      # include/dge.h: DGE_TUNE_*
+TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7, "hs_cold": 8, "hs_wave": 9}      # include/dge.h: DGE_TUNE_*
 
 
 class tuning:

@@ -229,6 +229,13 @@ int  dge_model_stats(const dge_model* m, dge_train_stats* out);
    allocation and shows here without training anything. */
 int  dge_model_row_rates(dge_model* m, double* read_gb_per_s, double* rewrite_gb_per_s, double* lock_exchanges_per_s, double* table_lookups_per_s);
 int  dge_model_reset_stats(dge_model* m);
+/* Placement search (profiles/r03_placement.txt): which physical memory the allocator handed each of the model's large arrays decides a launch's
+   duration by up to 15 %, array by array, under no rule that could be asked for.  Trains rows [row0, row0 + n_rows) of w as a probe; then for
+   the negative-sampling table, the lock words, syn1neg and syn0 in turn up to candidates - 1 copies in fresh memory are tried and the faster
+   placement kept.  Tables, counters and statistics are saved before and restored after: the model trains exactly as an untuned one.  Costs
+   (1 + 4 (candidates - 1)) probe launches and transiently 2 x the tables' memory.  ms_before / ms_after: probe launch before and after (may be NULL). */
+int  dge_model_tune_placement(dge_model* m, const dge_walks* w, int64_t row0, int64_t n_rows, int32_t candidates, double* ms_before, double* ms_after,
+                              int32_t* arrays_moved);
 /* what the latest training launch resolved `update_policy` 0 / `workers` 0 to: the policy that ran (0 = in-order plain),
  * the concurrent workers, and for policy 7 the head rows kept out of the lock protocol */
 int  dge_model_schedule(const dge_model* m, int32_t* update_policy, int64_t* workers, int32_t* hot_rows);
@@ -311,10 +318,7 @@ enum {
     DGE_TUNE_STATIC_WALKS = 7,    /* > 0: the lock kernels' worker w trains walks w, w + workers, ... instead of taking them from a launch-wide counter */
     DGE_TUNE_HS_COLD = 8,         /* hierarchical softmax under atomics: inner nodes [0, value) take plain read-modify-write (default: those on < 2e-5 of the paths) */
     DGE_TUNE_HS_WAVE = 9,         /* hierarchical softmax under atomics: 0 = the workers issue their atomics themselves, 1 = through the workgroup's atomics wave (default: the wave from 65 536 rows on) */
-    DGE_TUNE_FULL_TABLE = 10,     /* > 0: models created from now on keep word2vec's flat unigram table (4 B per slot) and the trainers read it instead of its rank-block form */
-    DGE_TUNE_ALLOC = 11,          /* how dge_model_create obtains syn0 / syn1neg / lock words / table: 0 hipMalloc, 1 hipExtMallocWithFlags(hipDeviceMallocContiguous),
-                                     2 virtual-memory API with a 1 GiB-aligned address range per array (placement experiments, profiles/r03_placement.txt) */
-    DGE_TUNE_COUNT = 12
+    DGE_TUNE_COUNT = 10
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
 int  dge_get_tuning(int32_t knob, int64_t* value);   /* -1 = the library's own rule */

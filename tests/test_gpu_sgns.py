@@ -654,3 +654,29 @@ def test_placement_trials_keep_the_fastest_model(dge, oracle):
     assert ms == [5.0, 3.0, 4.0] and best is seen[1] and len(seen) == 3
     assert best.stats()["pairs"] > 0                       # alive; the other two are closed
     assert all(m._h is None or not m._h for m in (seen[0], seen[2]))
+
+
+def test_placement_search_leaves_the_model_as_it_was(dge, oracle):
+    """dge_model_tune_placement re-allocates the model's large arrays one at a time and times probe launches on them; afterwards the tables,
+    the counters and the statistics must be exactly those of a model that was never tuned, and training must continue bit for bit."""
+    import torch
+    walks, NV = _walks(oracle, dge, R=60, T=6, n=3000)
+    corpus = dge.WalkCorpus.from_host(walks, 0)
+    counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0"); corpus.count_tokens(NV, counts)
+    for workers, pol in ((1, 0), (0, 2), (0, 5)):
+        cfg = dge.make_config(64, walks.shape[1], NV, workers=workers, update_policy=pol, table_size=20011)
+        a = dge.SgnsModel.create(cfg, counts, 0); b = dge.SgnsModel.create(cfg, counts, 0)
+        for m in (a, b):
+            m.train(corpus, 0, 1000, walk_index_base=0, total_walks=len(walks))
+        before = (a.vectors()[0].copy(), a.syn1neg().copy(), a.stats())
+        ms0, ms1, moved = a.tune_placement(corpus, 1000, 1500, candidates=3)
+        assert ms0 > 0 and 0 < ms1 <= ms0 and 0 <= moved <= 8
+        after = (a.vectors()[0], a.syn1neg(), a.stats())
+        assert np.array_equal(bits(before[0]), bits(after[0])) and np.array_equal(bits(before[1]), bits(after[1]))
+        assert before[2]["pairs"] == after[2]["pairs"] and before[2]["words"] == after[2]["words"] and before[2]["launches"] == after[2]["launches"]
+        assert np.array_equal(a.table(), b.table())
+        if workers == 1:          # the in-order schedule is deterministic: the tuned model goes on exactly like the untuned one
+            for m in (a, b):
+                m.train(corpus, 1000, 2000, walk_index_base=1000, total_walks=len(walks))
+            assert np.array_equal(bits(a.vectors()[0]), bits(b.vectors()[0])) and np.array_equal(bits(a.syn1neg()), bits(b.syn1neg()))
+            assert a.stats()["pairs"] == b.stats()["pairs"]
