@@ -103,18 +103,29 @@ def main():
     N = world_env
     if args.backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)      # several ranks on one card (debug only)
+    # a rank without a device of its own must say so and leave before the rendezvous: the other ranks would wait for it in init_process_group
+    n_dev = torch.cuda.device_count()
+    if n_dev <= local_rank:
+        sys.exit("bench.py: rank %d needs GPU %d but this node shows %d device(s) (--gpus %d): nothing measured" % (rank, local_rank, n_dev, N))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
+    n_ranks_seen = 1
     if N > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device(dev))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=N)
+        # `n_gpus` of the JSON line is what the collective backend itself counted, not the flag
+        one = torch.ones(1, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        n_ranks_seen = int(one.item())
+        if n_ranks_seen != N:
+            sys.exit("bench.py: %d ranks answered the all-reduce, --gpus %d" % (n_ranks_seen, N))
 
     import embedding_amd as E
     from embedding_amd import synth
-    from embedding_amd.distributed import allreduce_counts, block_schedule_step, exchange_deltas, shard_plan
+    from embedding_amd.distributed import RingTransport, allreduce_counts, block_schedule_step, exchange_deltas, shard_plan
 
     for kv in args.tune:
         k, v = kv.split("=")
@@ -214,6 +225,10 @@ def main():
         placement = {"candidates": args.placement_candidates, "probe_walks": n_probe, "probe_ms_before": round(before, 2), "probe_ms_after": round(after, 2),
                      "arrays_moved": moved}
         stage("placement search: probe launch %.1f -> %.1f ms, %d arrays moved" % (before, after, moved))
+    ring = None
+    if blocks and N > 1:           # how partitions travel: decided once, by all ranks together (a probe transfer, verdict all-reduced)
+        ring = RingTransport.choose(N, rank, dist, device=dev, requested=None if args.ring_transport == "auto" else args.ring_transport)
+        stage("ring transport: %s" % ring.mode)
     exchange = (N > 1 and not blocks) or args.force_exchange
     if exchange and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
@@ -240,7 +255,7 @@ def main():
                 model.train(corpus, 0, BG, walk_index_base=first, epoch=0, words_before=0, words_scale=1.0, total_walks=epoch_walks)
 
         if N > 1:
-            block_schedule_step(model, train_fn, N, rank, part_buf, recv_buf, transport=None if args.ring_transport == "auto" else args.ring_transport)
+            block_schedule_step(model, train_fn, N, rank, part_buf, recv_buf, transport=ring)
         else:                                                  # --sim-ranks: rank 0's episodes, exchange replaced by a local pack/unpack
             for e in range(NB):
                 model.set_partition(NB, 0, e % NB)
@@ -304,7 +319,7 @@ def main():
             "metric": "SGNS training edges/sec",
             "value": value,
             "unit": "edges/s",
-            "n_gpus": N,
+            "n_gpus": n_ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -317,7 +332,7 @@ def main():
                        "negatives": K, "walk_len": L, "window": L, "walks_per_step_per_gpu": B,
                        "pairs_per_step_per_gpu": st["pairs"] / args.steps, "vocabulary": int((counts >= 2).sum().item()),
                        "sgns_workers": args.workers, "placement_search": placement, "placement_trial_ms": trial_ms and [round(x, 1) for x in trial_ms],
-                       "lr_horizon_epochs": 1000, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, syn1neg partitions passed round a ring" % N if blocks and N > 1
+                       "lr_horizon_epochs": 1000, "ring_transport": ring and ring.mode, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, syn1neg partitions passed round a ring" % N if blocks and N > 1
                                        else "SIMULATED rank 0 of a %d-rank block schedule on one GPU (value = this rank's share only)" % NB if blocks
                                        else "walk-shard x%d, RCCL all-reduce of deltas per step (comparison mode)" % N if N > 1 else "1 GPU"),
                        "setup_s": round(setup_s, 1)},

@@ -1222,24 +1222,27 @@ extern "C" int dge_model_import_delta(dge_model* m, const float* d_buf, float sc
 // is dlopen()ed on first use, so a process that already carries a RCCL (PyTorch bundles one) is never handed a second
 // copy at load time.
 #include <dlfcn.h>
+#include <rccl/rccl.h>      // types and enum values only (ncclComm_t, ncclUniqueId, ncclFloat32, ncclSum, ncclResult_t): no RCCL symbol is linked
+static_assert(sizeof(dge_unique_id) == sizeof(ncclUniqueId), "include/dge.h: dge_unique_id must be the size of ncclUniqueId");
 struct dge_comm {
-    void* nccl = nullptr;       // ncclComm_t
+    ncclComm_t nccl = nullptr;
     int rank = 0, nranks = 1, device = 0;
     float* d_buf = nullptr; int64_t buf_floats = 0;
 };
 namespace {
+// the entry points are looked up with dlsym at first use; their prototypes are the header's own (decltype), so a change of rccl.h shows at compile time
 struct RcclApi {
     void* lib = nullptr;
-    int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, dge_unique_id, int) = nullptr;     // ncclUniqueId is a 128-byte struct passed by value
-    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 RcclApi g_rccl;
 int rccl_load() {
@@ -1248,23 +1251,23 @@ int rccl_load() {
     void* h = nullptr;
     for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
     if (!h) DGE_FAIL(DGE_ERR_DEVICE, "cannot load librccl: %s", dlerror());
-    g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
-    g_rccl.CommInitRank = (int (*)(void**, int, dge_unique_id, int))dlsym(h, "ncclCommInitRank");
-    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
-    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
-    g_rccl.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
-    g_rccl.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
-    g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
-    g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
-    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
-    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.GetUniqueId = (decltype(&ncclGetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(&ncclCommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(&ncclAllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.AllGather = (decltype(&ncclAllGather))dlsym(h, "ncclAllGather");
+    g_rccl.Send = (decltype(&ncclSend))dlsym(h, "ncclSend");
+    g_rccl.Recv = (decltype(&ncclRecv))dlsym(h, "ncclRecv");
+    g_rccl.GroupStart = (decltype(&ncclGroupStart))dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(&ncclGroupEnd))dlsym(h, "ncclGroupEnd");
+    g_rccl.CommDestroy = (decltype(&ncclCommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(&ncclGetErrorString))dlsym(h, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy || !g_rccl.Send || !g_rccl.Recv ||
         !g_rccl.GroupStart || !g_rccl.GroupEnd) DGE_FAIL(DGE_ERR_DEVICE, "librccl lacks an expected symbol");
     g_rccl.lib = h;
     return DGE_OK;
 }
 int rccl_fail(int rc, const char* what) {
-    DGE_FAIL(DGE_ERR_DEVICE, "RCCL %s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    DGE_FAIL(DGE_ERR_DEVICE, "RCCL %s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString((ncclResult_t)rc) : "?");
 }
 }  // namespace
 
@@ -1272,7 +1275,7 @@ extern "C" int dge_comm_unique_id(dge_unique_id* out) {
     if (!out) DGE_FAIL(DGE_ERR_ARG, "dge_comm_unique_id: null output");
     int rc = rccl_load();
     if (rc) return rc;
-    int n = g_rccl.GetUniqueId(out);
+    int n = g_rccl.GetUniqueId(reinterpret_cast<ncclUniqueId*>(out));
     return n ? rccl_fail(n, "ncclGetUniqueId") : DGE_OK;
 }
 
@@ -1284,7 +1287,8 @@ extern "C" int dge_comm_create(dge_comm** out, const dge_unique_id* id, int rank
     if ((rc = rccl_load())) return rc;
     dge_comm* c = new dge_comm();
     c->rank = rank; c->nranks = nranks; c->device = device;
-    int n = g_rccl.CommInitRank(&c->nccl, nranks, *id, rank);
+    ncclUniqueId nid; memcpy(&nid, id, sizeof(nid));
+    int n = g_rccl.CommInitRank(&c->nccl, nranks, nid, rank);
     if (n) { delete c; return rccl_fail(n, "ncclCommInitRank"); }
     *out = c;
     return DGE_OK;
@@ -1308,7 +1312,7 @@ extern "C" int dge_model_allreduce_deltas(dge_model* m, dge_comm* c) {
     if (rc) return rc;
     if (c->buf_floats < nfl) { dge_dev_free(c->d_buf); c->d_buf = nullptr; if ((rc = dge_dev_alloc(&c->d_buf, (size_t)nfl + 64))) return rc; c->buf_floats = nfl; }
     if ((rc = dge_model_export_delta(m, c->d_buf))) return rc;
-    int n = g_rccl.AllReduce(c->d_buf, c->d_buf, (size_t)nfl, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->nccl, m->stream);
+    int n = g_rccl.AllReduce(c->d_buf, c->d_buf, (size_t)nfl, ncclFloat32, ncclSum, c->nccl, m->stream);
     if (n) return rccl_fail(n, "ncclAllReduce");
     DGE_HIP(hipStreamSynchronize(m->stream));
     return dge_model_import_delta(m, c->d_buf, 1.0f / (float)c->nranks);
@@ -1340,8 +1344,8 @@ extern "C" int dge_model_ring_pass(dge_model* m, dge_comm* c, int32_t episode) {
     if ((rc = dge_model_export_partition(m, 1, c->nranks, (c->rank + episode) % c->nranks, mine))) return rc;
     const int dst = (c->rank + c->nranks - 1) % c->nranks, src = (c->rank + 1) % c->nranks;
     int n = g_rccl.GroupStart();
-    if (!n) n = g_rccl.Send(mine, (size_t)pf, /*ncclFloat32*/ 7, dst, c->nccl, m->stream);
-    if (!n) n = g_rccl.Recv(next, (size_t)pf, /*ncclFloat32*/ 7, src, c->nccl, m->stream);
+    if (!n) n = g_rccl.Send(mine, (size_t)pf, ncclFloat32, dst, c->nccl, m->stream);
+    if (!n) n = g_rccl.Recv(next, (size_t)pf, ncclFloat32, src, c->nccl, m->stream);
     const int n2 = g_rccl.GroupEnd();
     if (n || n2) return rccl_fail(n ? n : n2, "ncclSend/ncclRecv");
     DGE_HIP(hipStreamSynchronize(m->stream));
@@ -1358,7 +1362,7 @@ extern "C" int dge_model_gather_table(dge_model* m, dge_comm* c, int table) {
     if ((rc = comm_buffers(m, c, pf * ((int64_t)c->nranks + 1)))) return rc;
     float* mine = c->d_buf; float* all = c->d_buf + pf;
     if ((rc = dge_model_export_partition(m, table, c->nranks, c->rank, mine))) return rc;
-    int n = g_rccl.AllGather(mine, all, (size_t)pf, /*ncclFloat32*/ 7, c->nccl, m->stream);
+    int n = g_rccl.AllGather(mine, all, (size_t)pf, ncclFloat32, c->nccl, m->stream);
     if (n) return rccl_fail(n, "ncclAllGather");
     DGE_HIP(hipStreamSynchronize(m->stream));
     for (int r = 0; r < c->nranks; r++)

@@ -58,32 +58,91 @@ def exchange_deltas(model, buf, world, dist_mod=None):
     model.import_delta(buf, 1.0 / world)
 
 
-_RING_TRANSPORT = {"mode": "p2p"}      # "p2p", or "allgather" once point-to-point transfers turned out to be unavailable
+class RingTransport:
+    """How a trained syn1neg partition reaches the next rank — decided ONCE, by all ranks together, never inside a step.
+
+    mode "p2p": one point-to-point transfer per rank and episode; "allgather": the same bytes through an all-gather.
+    `choose` runs a four-float point-to-point probe on every rank, time-boxed, and all-reduces (MIN) the outcome over a control group
+    (a gloo group when the data backend is nccl: a refused or hung RCCL transfer must not be what carries the verdict): all ranks
+    succeeded -> "p2p"; any rank was refused (an exception) -> every rank takes "allgather"; any rank's probe did not finish within the
+    time box -> RuntimeError on every rank (the communicator is not to be trusted: exit non-zero rather than hang).  After the
+    decision a failing transfer raises; no rank ever switches mode on its own."""
+
+    def __init__(self, mode, ctrl=None):
+        if mode not in ("p2p", "allgather"):
+            raise ValueError("ring transport %r" % (mode,))
+        self.mode = mode
+        self.ctrl = ctrl
+
+    @classmethod
+    def choose(cls, world, rank, d, device="cpu", requested=None, timeout_s=60.0):
+        import torch
+        if requested in ("p2p", "allgather"):
+            return cls(requested)
+        ctrl = None
+        if d.get_backend() == "nccl":
+            ctrl = d.new_group(backend="gloo")             # (collective: every rank creates it)
+        ok, why = 1, ""
+        try:
+            staged = str(device).startswith("cuda") and d.get_backend() != "nccl"
+            s = torch.full((4,), float(rank), dtype=torch.float32, device="cpu" if staged else device)
+            r = torch.empty(4, dtype=torch.float32, device="cpu" if staged else device)
+            works = d.batch_isend_irecv([d.P2POp(d.isend, s, (rank - 1) % world), d.P2POp(d.irecv, r, (rank + 1) % world)])
+            # time box: the waits run on a helper thread (gloo only completes a transfer inside wait(); an RCCL transfer whose peer never
+            # posts its half would block a stream synchronisation for good)
+            import threading
+            done = {}
+
+            def _wait_all():
+                try:
+                    for w in works:
+                        w.wait()
+                    if str(device).startswith("cuda"):
+                        torch.cuda.synchronize(device)
+                    done["ok"] = True
+                except Exception as e:  # noqa: BLE001 (reported through the verdict)
+                    done["err"] = e
+            th = threading.Thread(target=_wait_all, daemon=True)
+            th.start(); th.join(timeout_s)
+            if th.is_alive():
+                ok, why = -1, "no completion within %.0f s" % timeout_s
+            elif "err" in done:
+                raise RuntimeError(str(done["err"]))
+            if ok == 1:
+                if float(r[0]) != float((rank + 1) % world):
+                    ok, why = 0, "probe payload wrong"
+        except (RuntimeError, NotImplementedError, ValueError) as e:
+            ok, why = 0, (str(e).splitlines() or ["?"])[0]
+        flag = torch.tensor([ok], dtype=torch.int32)
+        d.all_reduce(flag, op=d.ReduceOp.MIN, group=ctrl)          # (a CPU tensor: the gloo control group under nccl, the default group otherwise)
+        verdict = int(flag.item())
+        if verdict < 0:
+            raise RuntimeError("ring transport: the point-to-point probe hung on at least one rank (rank %d: %s) — not falling back on a "
+                               "communicator in that state" % (rank, why or "ok here"))
+        if verdict == 0:
+            import sys
+            if why or rank == 0:
+                print("[distributed] rank %d: point-to-point transfers unavailable%s: every rank uses all-gather" % (rank, " (%s)" % why if why else ""),
+                      file=sys.stderr, flush=True)
+            return cls("allgather", ctrl)
+        return cls("p2p", ctrl)
 
 
-def _ring_pass(send_buf, recv_buf, world, rank, d, transport=None):
+def _ring_pass(send_buf, recv_buf, world, rank, d, transport):
     """Every rank sends `send_buf` to rank - 1 and receives rank + 1's into `recv_buf` (one point-to-point transfer per rank: over
     xGMI a partition of cfg3, 64 MB, is ~0.5 ms on one link).  Backends that cannot move device tensors point to point (gloo in the
-    CPU/one-GPU tests) are staged through host memory.  transport="allgather" (also chosen for the rest of the run when the
-    backend refuses point-to-point operations) moves the same bytes with an all-gather and keeps rank + 1's share."""
+    CPU/one-GPU tests) are staged through host memory.  transport.mode "allgather" moves the same bytes with an all-gather and keeps
+    rank + 1's share.  The mode was fixed for the whole run by RingTransport.choose; a failure here raises."""
     import torch
     dst, src = (rank - 1) % world, (rank + 1) % world
-    mode = transport or _RING_TRANSPORT["mode"]
-    if mode == "p2p":
+    if transport.mode == "p2p":
         staged = getattr(send_buf, "is_cuda", False) and d.get_backend() != "nccl"
         s, r = (send_buf.cpu(), torch.empty(recv_buf.shape, dtype=recv_buf.dtype)) if staged else (send_buf, recv_buf)
-        try:
-            for w in d.batch_isend_irecv([d.P2POp(d.isend, s, dst), d.P2POp(d.irecv, r, src)]):
-                w.wait()
-            if staged:
-                recv_buf.copy_(r)
-        except (RuntimeError, NotImplementedError) as e:
-            if transport is not None:
-                raise
-            import sys
-            print("[distributed] point-to-point transfer unavailable (%s): all-gather from here on" % (str(e).splitlines()[0],), file=sys.stderr, flush=True)
-            _RING_TRANSPORT["mode"] = mode = "allgather"
-    if mode == "allgather":
+        for w in d.batch_isend_irecv([d.P2POp(d.isend, s, dst), d.P2POp(d.irecv, r, src)]):
+            w.wait()
+        if staged:
+            recv_buf.copy_(r)
+    else:
         allb = torch.empty(send_buf.numel() * world, dtype=send_buf.dtype, device=send_buf.device)
         d.all_gather_into_tensor(allb, send_buf)
         recv_buf.copy_(allb[src * send_buf.numel():(src + 1) * send_buf.numel()])
@@ -100,7 +159,10 @@ def block_schedule_step(model, train_fn, world, rank, part_buf=None, recv_buf=No
     every episode a rank hands the partition it just trained to rank-1 and takes the next one from rank+1 — one partition per
     rank and episode, point to point, instead of an all-gather of all of them; a rank only ever reads the syn1neg partition it
     is about to train and its own syn0 partition.  After the N-th episode partition p is back on rank p: the invariant the
-    next batch starts from (and `gather_table` collects from)."""
+    next batch starts from (and `gather_table` collects from).
+
+    `transport`: a RingTransport (chosen once per run: RingTransport.choose, a collective), or "p2p" / "allgather"; None chooses here, on
+    every rank alike, which costs a probe per call — callers that step repeatedly choose once and pass the object."""
     if world <= 1:
         model.set_partition(1)
         train_fn()
@@ -113,6 +175,8 @@ def block_schedule_step(model, train_fn, world, rank, part_buf=None, recv_buf=No
         dev = getattr(model, "torch_device", None) or "cpu"
         part_buf = torch.empty(pf, dtype=torch.float32, device=dev)
         recv_buf = torch.empty(pf, dtype=torch.float32, device=dev)
+    if not isinstance(transport, RingTransport):
+        transport = RingTransport.choose(world, rank, d, device=part_buf.device, requested=transport)
     for e in range(world):
         tgt = (rank + e) % world
         model.set_partition(world, rank, tgt)
@@ -166,6 +230,8 @@ def fit_distributed(graph, n_walks, walk_len, cfg, world, rank, walk_seed, batch
     nb = int(batch_walks or max(1, n_walks // 10))
     corpus = graph.sample_walks_device(min(nb, n_walks), walk_len, seed=walk_seed, rng_mode=1, first_index=0)
     bufs = (None, None)
+    import torch.distributed as _dist
+    transport = RingTransport.choose(world, rank, dist_mod or _dist, device=tdev) if world > 1 else None     # once, collectively
     for ep in range(cfg.epochs):
         words_before = 0
         for b0 in range(0, n_walks, nb):
@@ -174,7 +240,7 @@ def fit_distributed(graph, n_walks, walk_len, cfg, world, rank, walk_seed, batch
                 graph.sample_walks_into(corpus, 0, n, walk_seed, b0)
             model.reset_stats()
             bufs = block_schedule_step(model, lambda: model.train(corpus, 0, n, walk_index_base=b0, epoch=ep, words_before=words_before,
-                                                                  total_walks=n_walks), world, rank, *bufs, dist_mod=dist_mod)
+                                                                  total_walks=n_walks), world, rank, *bufs, dist_mod=dist_mod, transport=transport)
             words_before += model.stats()["words"]
     gather_table(model, 0, world, rank, dist_mod=dist_mod)
     gather_table(model, 1, world, rank, dist_mod=dist_mod)

@@ -58,3 +58,11 @@ def test_parent_never_imports_torch():
         e.pop(k, None)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT, env=e)
     assert out.returncode == 0 and "clean" in out.stdout, out.stderr[-2000:]
+
+
+def test_rank_without_a_device_leaves_before_the_rendezvous():
+    # one rank, no GPU visible: bench.py must say why and exit non-zero before init_process_group (the other ranks of a real launch would
+    # otherwise wait for it), and print no JSON line
+    out = _run(["--steps", "1", "--warmup", "0", "--workload", "tiny", "--no-cpu-baseline"], env={"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""}, timeout=300)
+    assert out.returncode != 0 and "device(s)" in out.stderr and "nothing measured" in out.stderr, out.stderr[-1500:]
+    assert not [l for l in out.stdout.splitlines() if l.strip().startswith("{")]

@@ -142,3 +142,61 @@ def test_shard_plan_edges():
     assert [shard_plan(10, 4, r) for r in range(4)] == [(0, 2), (2, 2), (4, 2), (6, 2)]
     with pytest.raises(ValueError):
         shard_plan(10, 2, 2)
+
+
+class _FaultyDist:
+    """torch.distributed with point-to-point transfers refused (NotImplementedError) on the ranks in `bad`."""
+
+    def __init__(self, dist, rank, bad):
+        self._d, self._rank, self._bad = dist, rank, bad
+
+    def __getattr__(self, name):
+        return getattr(self._d, name)
+
+    def batch_isend_irecv(self, ops):
+        if self._rank in self._bad:
+            raise NotImplementedError("point-to-point operations are not available (injected)")
+        return self._d.batch_isend_irecv(ops)
+
+
+def _transport_worker(rank, world, port, out_dir, bad, timeout_s):
+    import torch.distributed as dist
+    from embedding_amd.distributed import RingTransport, block_schedule_step
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = _FaultyDist(dist, rank, bad)
+    outcome = "?"
+    try:
+        tr = RingTransport.choose(world, rank, d, device="cpu", timeout_s=timeout_s)
+        outcome = tr.mode
+        m = FakeBlockModel(11, 4)
+        block_schedule_step(m, m.train, world, rank, dist_mod=d, transport=tr)
+        assert np.array_equal(m.tab[1][rank::world], np.full_like(m.tab[1][rank::world], float(world)))
+    except RuntimeError as e:
+        outcome = "raised: " + str(e)[:60]
+    open(os.path.join(out_dir, "t%d.txt" % rank), "w").write(outcome)
+    if not outcome.startswith("raised"):
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        os._exit(0)        # (a rank whose peer never posted its half of the probe still has that transfer pending: leave without the collective teardown)
+
+
+@pytest.mark.parametrize("bad,expect", [((), "p2p"), ((0, 1), "allgather"), ((1,), "raised")])
+def test_ring_transport_is_chosen_by_all_ranks_together(tmp_path, bad, expect):
+    """a rank must never switch transport on its own.  All ranks fine -> p2p; all refused -> all-gather everywhere and the
+    schedule still completes; ONE rank refused (its peer's probe can then never complete) -> every rank raises within the time box
+    instead of hanging in mismatched collectives."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_transport_worker, args=(2, port, str(tmp_path), tuple(bad), 3.0), nprocs=2, join=True)
+    got = [open(str(tmp_path / ("t%d.txt" % i))).read() for i in range(2)]
+    assert all(g.startswith(expect) for g in got), got
+
+
+def test_explicit_transport_is_taken_as_given():
+    from embedding_amd.distributed import RingTransport
+    assert RingTransport.choose(2, 0, None, requested="allgather").mode == "allgather"
+    assert RingTransport.choose(2, 0, None, requested="p2p").mode == "p2p"
+    with pytest.raises(ValueError):
+        RingTransport("carrier pigeon")
