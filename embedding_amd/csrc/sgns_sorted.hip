@@ -27,7 +27,10 @@
 #include <hipcub/hipcub.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <string.h>
+
 #include <algorithm>
+#include <vector>
 
 #include "sgns_kernels.h"
 #include "sgns_model.h"
@@ -50,6 +53,21 @@ struct dge_sorted_work {
     float* shadow = nullptr; int64_t cap_shadow = 0;   // the target rows as phase A leaves them, committed after phase B
     float* scratch = nullptr; int64_t cap_scratch_rows = 0;
     int64_t* d_marks = nullptr; int64_t cap_marks = 0;
+    // Block schedule: the items of ALL n target partitions of a rank's context partition, made once per global batch (k_block_count /
+    // k_block_emit) instead of once per episode: bucket t holds, in walk order, the items of the pairs whose centre row is in partition t.
+    int32_t* st_cnt = nullptr; int64_t* st_off = nullptr; int64_t st_cap_cells = 0;      // pairs per (bucket, walk) cell [n x walks], exclusive prefix
+    void* st_scan_tmp = nullptr; size_t st_scan_bytes = 0;
+    int32_t* st_key = nullptr; uint64_t* st_val = nullptr; int64_t st_cap_items = 0;
+    unsigned long long* st_words = nullptr;      // in-vocabulary tokens of the batch
+    std::vector<int64_t> st_bucket0;             // first pair of every bucket (+ end)
+    bool st_valid = false;
+    struct Key { const int32_t* sen; int64_t n_rows; uint64_t gen; int32_t L, W, K, part_n, part_ctx; int64_t gidx_base, words_done_base, all_words, V, T; double words_scale;
+                 float alpha0, min_alpha; uint64_t seed;
+                 bool operator==(const Key& o) const {
+                     return sen == o.sen && n_rows == o.n_rows && gen == o.gen && L == o.L && W == o.W && K == o.K && part_n == o.part_n && part_ctx == o.part_ctx &&
+                            gidx_base == o.gidx_base && words_done_base == o.words_done_base && all_words == o.all_words && V == o.V && T == o.T &&
+                            words_scale == o.words_scale && alpha0 == o.alpha0 && min_alpha == o.min_alpha && seed == o.seed;
+                 } } st_key_of{};
 };
 
 void dge_sorted_release(dge_model* m) {
@@ -62,6 +80,7 @@ void dge_sorted_release(dge_model* m) {
         if (s->ev_done[x]) (void)hipEventDestroy(s->ev_done[x]);
     }
     dge_dev_free(s->cnt); dge_dev_free(s->off); dge_dev_free(s->scan_tmp); dge_dev_free(s->seg); dge_dev_free(s->scratch); dge_dev_free(s->d_marks); dge_dev_free(s->shadow);
+    dge_dev_free(s->st_cnt); dge_dev_free(s->st_off); dge_dev_free(s->st_scan_tmp); dge_dev_free(s->st_key); dge_dev_free(s->st_val); dge_dev_free(s->st_words);
     delete s;
     m->sorted = nullptr;
 }
@@ -262,6 +281,134 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
     }
 }
 
+// ---- Block schedule, items made once per global batch.  An episode of an n-rank schedule trains the pairs (context row in partition part_ctx,
+// centre row in partition t); run per episode, the count and emit kernels above scan all n x B walks of the global batch n times for 1/n of
+// a rank's pairs each time (profiles/r02_sim8_kernel_stats.csv: k_sorted_emit 24 % of an 8-rank step).  Instead, once per batch: every walk's
+// pairs with context in part_ctx, counted per centre partition (k_block_count), one prefix sum over the [n x walks] cells — bucket after
+// bucket, so every bucket's items are one contiguous run in walk order — and one emit pass that writes each pair's items into its bucket
+// (k_block_emit: one 16-lane group per walk, tokens in registers).  Episode (part_ctx, t) then sorts and trains slices of bucket t: the same
+// items in the same order as the per-episode kernels produce (bit-exact tests: tests/test_gpu_sorted.py).
+__global__ void __launch_bounds__(256) k_block_count(TrainParams p, int32_t* cells, unsigned long long* words_out) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    long long words = 0;
+    if (w < p.n_rows) {
+        const int len = (int)p.len[w];
+        const int32_t* sen = p.sen + w * p.L;
+        uint64_t ctx_mask = 0;
+        for (int j = 0; j < len; j++) ctx_mask |= (uint64_t)(sen[j] % p.part_n == p.part_ctx) << j;
+        words = len;
+        int cnt[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) cnt[t] = 0;
+        for (int i = 0; i < len; i++) {
+            uint64_t s; int lo, hi;
+            unit_window(p, w, i, len, s, lo, hi);
+            const uint64_t wm = (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & (~0ull << lo) & ~(1ull << i);
+            const int n = __popcll(ctx_mask & wm);
+            const int t = sen[i] % p.part_n;
+#pragma unroll
+            for (int z = 0; z < 16; z++) cnt[z] += z == t ? n : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) if (t < p.part_n) cells[(int64_t)t * p.n_rows + w] = cnt[t];
+    }
+    for (int o = 32; o > 0; o >>= 1) words += __shfl_xor(words, o);
+    if ((threadIdx.x & 63) == 0 && words) atomicAdd(words_out, (unsigned long long)words);
+}
+
+__global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t* __restrict__ cell_off, int32_t* __restrict__ key_out, uint64_t* __restrict__ val_out, int32_t Vk) {
+    const int lane = threadIdx.x & 15;
+    const int sh = threadIdx.x & 48;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (w >= p.n_rows) return;
+    const int L = p.L, K = p.K, N = p.part_n;
+    const int len = (int)p.len[w];
+    if (len <= 1) return;
+    const int32_t* sen = p.sen + w * L;
+    const int32_t tk0 = lane < len ? sen[lane] : -1, tk1 = lane + 16 < len ? sen[lane + 16] : -1;
+    const int32_t tk2 = lane + 32 < len ? sen[lane + 32] : -1, tk3 = lane + 48 < len ? sen[lane + 48] : -1;
+    const uint64_t ctx_mask = part_token_mask(tk0, tk1, tk2, tk3, N, p.part_ctx);
+    if (!ctx_mask) return;
+    const int64_t wbw = p.wb[w];
+    const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
+    float alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
+    if (alpha < p.min_alpha) alpha = p.min_alpha;
+    // lane t keeps the next free pair position of bucket t
+    int64_t my_pos = lane < N ? cell_off[(int64_t)lane * p.n_rows + w] : 0;
+    uint64_t mA = 1, cA = 0;
+    for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
+    for (int i = 0; i < len; i++) {
+        uint64_t s; int lo, hi;
+        unit_window(p, w, i, len, s, lo, hi);
+        uint64_t pm = ctx_mask & (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & (~0ull << lo) & ~(1ull << i);
+        if (!pm) continue;
+        const int32_t word = walk_tok(true, sen, i, tk0, tk1, tk2, tk3);
+        const int bucket = word % N;
+        const uint64_t s_centre = s;
+        int64_t slot = (int64_t)shfl16_u64((uint64_t)my_pos, bucket) * (int64_t)(K + 1);
+        const int np = __popcll(pm);
+        if (lane == bucket) my_pos += np;
+        while (pm) {
+            // up to 4 pairs per trip: their table look-ups are in flight together
+            int32_t lastv[4], tv[4]; int cpos[4]; int npair = 0;
+#pragma unroll
+            for (int z = 0; z < 4; z++) {
+                lastv[z] = -1; tv[z] = -1; cpos[z] = 0;
+                if (pm) {
+                    const int c = __builtin_ctzll(pm); pm &= pm - 1ull;
+                    cpos[z] = c;
+                    lastv[z] = walk_tok(true, sen, c, tk0, tk1, tk2, tk3);
+                    if (K <= 16) {
+                        const uint64_t sl = dge_mix64(s_centre + (uint64_t)c) * mA + cA;       // every pair draws from its own stream
+                        if (lane < K) {
+                            int32_t t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
+                            if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                            tv[z] = t;
+                        }
+                    }
+                    npair = z + 1;
+                    if (K > 16) break;
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < 4; z++) {
+                if (z >= npair) break;
+                const uint64_t hi32 = (uint64_t)(uint32_t)lastv[z] << 32;
+                if (lane == 0) { key_out[slot] = word / N; val_out[slot] = hi32 | (uint64_t)__float_as_uint(alpha); }
+                if (K <= 16) {
+                    if (lane < K) {
+                        const int32_t t = part_row(tv[z], N, bucket, p.V);
+                        key_out[slot + 1 + lane] = t == word ? Vk : t / N;
+                        val_out[slot + 1 + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);      // label 0: the sign bit
+                    }
+                } else {
+                    uint64_t sp = dge_mix64(s_centre + (uint64_t)cpos[z]);
+                    for (int kd = 0; kd < K; kd += 16) {
+                        const int kc = min(16, K - kd);
+                        const uint64_t sl = sp * mA + cA;
+                        if (lane < kc) {
+                            int32_t t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
+                            if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                            t = part_row(t, N, bucket, p.V);
+                            key_out[slot + 1 + kd + lane] = t == word ? Vk : t / N;
+                            val_out[slot + 1 + kd + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);
+                        }
+                        sp = shfl16_u64(sl, kc - 1);
+                    }
+                }
+                slot += K + 1;
+            }
+        }
+    }
+    (void)sh;
+}
+__global__ void k_block_tally(unsigned long long* counters, unsigned long long pairs, const unsigned long long* words, int add_words) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (pairs) atomicAdd(&counters[0], pairs);
+        if (add_words && *words) atomicAdd(&counters[1], *words);
+    }
+}
+
 // seg[k] = first position of the sorted keys that is >= k, k = 0 .. Vk+1  (seg[Vk] = number of valid items, seg[Vk+1] = n)
 __global__ void k_sorted_segments(const int32_t* __restrict__ keys, int64_t n, int64_t V, int64_t* seg) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -300,7 +447,7 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
     const TableView own = make_view(PB ? p.syn0 : p.syn1neg, p.V, p.stride);
     const TableView oth = make_view(PB ? p.syn1neg : p.syn0, p.V, p.stride);
     const TableView scr = make_view(q.scratch, 2 * ((q.n_slots + q.chunk - 1) / q.chunk), p.stride);
-    const TableView shd = make_view(q.shadow, p.V, p.stride);
+    const TableView shd = make_view(q.shadow, q.Vk, p.stride);            // (indexed by key: only the rows of the target partition exist in it)
 
     const int32_t kpart = PB ? q.kpart_ctx : q.kpart_tgt;
 #define OWN_ROW(k_) ((k_) * q.kdiv + kpart)
@@ -322,7 +469,7 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
                         r0.v[c_].x += d.v[c_].x; r0.v[c_].y += d.v[c_].y; r0.v[c_].z += d.v[c_].z; r0.v[c_].w += d.v[c_].w; \
                     }                                                                                                  \
                     rowA_store<DCH, 0, false>(r0, own, OWN_ROW(cur), lane);                                            \
-                } else rowA_store<DCH, 0, false>(h, shd, OWN_ROW(cur), lane);                                          \
+                } else rowA_store<DCH, 0, false>(h, shd, cur, lane);                                                   \
             } else rowA_store<DCH, 0, false>(d, scr, (int32_t)(2 * chunk + (seg_start == start ? 0 : 1)), lane);      \
         }                                                                                                              \
     } while (0)
@@ -405,7 +552,7 @@ __global__ void __launch_bounds__(256) k_sorted_fixup(SortedParams q, int phase_
         for (int x = 0; x < DCH; x++) { row.v[x].x += dd.v[x].x; row.v[x].y += dd.v[x].y; row.v[x].z += dd.v[x].z; row.v[x].w += dd.v[x].w; }
     }
     if (phase_b) rowA_store<DCH, 0, false>(row, own, r, lane);
-    else rowA_store<DCH, 0, false>(row, make_view(q.shadow, p.V, p.stride), r, lane);
+    else rowA_store<DCH, 0, false>(row, make_view(q.shadow, q.Vk, p.stride), kr, lane);
 }
 
 // end of a mini-batch: the target rows that had items take the value phase A left in the shadow table
@@ -418,7 +565,7 @@ __global__ void __launch_bounds__(256) k_sorted_commit(SortedParams q, const int
     if (kr >= q.Vk || seg_a[kr + 1] == seg_a[kr]) return;
     const int64_t r = kr * q.kdiv + q.kpart_tgt;
     Row<DCH> row;
-    rowA_load<DCH, 0, false>(row, make_view(q.shadow, p.V, p.stride), (int32_t)r, lane);
+    rowA_load<DCH, 0, false>(row, make_view(q.shadow, q.Vk, p.stride), (int32_t)kr, lane);
     rowA_store<DCH, 0, false>(row, make_view(p.syn1neg, p.V, p.stride), (int32_t)r, lane);
 }
 template <int DCH>
@@ -503,6 +650,72 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     const int64_t n_units = p.n_rows * (int64_t)p.L;
     const int K1 = p.K + 1;
     int rc;
+    // Block schedule: the items of every target partition are made once per global batch (k_block_count / k_block_emit) and kept for the
+    // batch's n episodes — when they fit: at most half of the free memory (cfg3 at 8 ranks: 27.6 GB); otherwise episode by episode as before
+    bool use_store = p.part_n > 1 && p.part_n <= 16 && p.L <= 64 && (int64_t)p.part_n * p.n_rows + 1 < 0x7fffffffll;
+    int64_t total_pairs = 0;
+    if (use_store) {
+        const dge_sorted_work::Key key{p.sen, p.n_rows, m->seen_gen, p.L, p.W, p.K, p.part_n, p.part_ctx, p.gidx_base, p.words_done_base, p.all_words, p.V, p.T,
+                                       p.words_scale, p.alpha0, p.min_alpha, p.seed};
+        const int64_t n_cells = (int64_t)p.part_n * p.n_rows;
+        if (!(s->st_valid && m->seen_gen != 0 && key == s->st_key_of)) {
+            s->st_valid = false;
+            if (n_cells + 1 > s->st_cap_cells) {
+                DGE_HIP(hipStreamSynchronize(st));
+                dge_dev_free(s->st_cnt); dge_dev_free(s->st_off); dge_dev_free(s->st_scan_tmp); s->st_cnt = nullptr; s->st_off = nullptr; s->st_scan_tmp = nullptr; s->st_cap_cells = 0;
+                if ((rc = dge_dev_alloc(&s->st_cnt, (size_t)n_cells + 1))) return rc;
+                if ((rc = dge_dev_alloc(&s->st_off, (size_t)n_cells + 1))) return rc;
+                size_t b = 0;
+                DGE_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b, CountIter(s->st_cnt, CastI64()), s->st_off, n_cells + 1, st));
+                DGE_HIP(hipMalloc(&s->st_scan_tmp, b ? b : 1)); s->st_scan_bytes = b;
+                s->st_cap_cells = n_cells + 1;
+            }
+            if (!s->st_words && (rc = dge_dev_alloc(&s->st_words, 1))) return rc;
+            DGE_HIP(hipMemsetAsync(s->st_words, 0, sizeof(unsigned long long), st));
+            DGE_HIP(hipMemsetAsync(s->st_cnt + n_cells, 0, sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_block_count, dim3(grid_for(p.n_rows, 256)), dim3(256), 0, st, p, s->st_cnt, s->st_words);
+            { size_t b = s->st_scan_bytes; DGE_HIP(hipcub::DeviceScan::ExclusiveSum(s->st_scan_tmp, b, CountIter(s->st_cnt, CastI64()), s->st_off, n_cells + 1, st)); }
+            // first pair of every bucket
+            std::vector<int64_t> cells((size_t)p.part_n + 1);
+            for (int t = 0; t <= p.part_n; t++) cells[(size_t)t] = (int64_t)t * p.n_rows;
+            if (p.part_n + 1 > s->cap_marks) {
+                dge_dev_free(s->d_marks); s->d_marks = nullptr; s->cap_marks = 0;
+                if ((rc = dge_dev_alloc(&s->d_marks, 2 * ((size_t)p.part_n + 1)))) return rc;
+                s->cap_marks = p.part_n + 1;
+            }
+            s->st_bucket0.assign((size_t)p.part_n + 1, 0);
+            DGE_HIP(hipMemcpyAsync(s->d_marks, cells.data(), cells.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_sorted_marks, dim3(1), dim3(256), 0, st, s->st_off, s->d_marks, p.part_n + 1, s->d_marks + s->cap_marks);
+            DGE_HIP(hipMemcpyAsync(s->st_bucket0.data(), s->d_marks + s->cap_marks, cells.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            DGE_HIP(hipStreamSynchronize(st));
+            const int64_t all_items = s->st_bucket0[(size_t)p.part_n] * K1;
+            size_t free_b = 0, total_b = 0;
+            DGE_HIP(hipMemGetInfo(&free_b, &total_b));
+            const size_t have = (size_t)s->st_cap_items * 12;
+            if ((size_t)all_items * 12 > have + (free_b + have) / 2) use_store = false;       // does not fit: this batch runs episode by episode
+            else {
+                if (all_items > s->st_cap_items) {
+                    if (s->aux) DGE_HIP(hipStreamSynchronize(s->aux));
+                    dge_dev_free(s->st_key); dge_dev_free(s->st_val); s->st_key = nullptr; s->st_val = nullptr; s->st_cap_items = 0;
+                    const int64_t cap = all_items + all_items / 16 + 1024;
+                    if ((rc = dge_dev_alloc(&s->st_key, (size_t)cap))) return rc;
+                    if ((rc = dge_dev_alloc(&s->st_val, (size_t)cap))) return rc;
+                    s->st_cap_items = cap;
+                }
+                if (all_items > 0)
+                    hipLaunchKernelGGL(k_block_emit, dim3(grid_for(p.n_rows * 16, 256)), dim3(256), 0, st, p, s->st_off, s->st_key, s->st_val,
+                                       (int32_t)((m->V + p.part_n - 1) / p.part_n));
+                DGE_HIP(hipGetLastError());
+                s->st_key_of = key; s->st_valid = true;
+            }
+        }
+    }
+    if (use_store) {
+        total_pairs = s->st_bucket0[(size_t)p.part_tgt + 1] - s->st_bucket0[(size_t)p.part_tgt];
+        hipLaunchKernelGGL(k_block_tally, dim3(1), dim3(64), 0, st, p.counters, (unsigned long long)total_pairs, s->st_words, p.part_ctx == p.part_tgt ? 1 : 0);
+        if (total_pairs == 0) return DGE_OK;
+    } else {
+    if (n_units + 1 >= 0x7fffffffll) DGE_FAIL(DGE_ERR_ARG, "update_policy 8: %lld (walk, centre) units in one launch exceed the prefix sum's 32-bit item count: train in several calls", (long long)n_units);
     if (n_units + 1 > s->cap_units) {
         DGE_HIP(hipStreamSynchronize(st));
         dge_dev_free(s->cnt); dge_dev_free(s->off); dge_dev_free(s->scan_tmp); s->cnt = nullptr; s->off = nullptr; s->scan_tmp = nullptr; s->cap_units = 0;
@@ -520,10 +733,10 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     { size_t b = s->scan_tmp_bytes; DGE_HIP(hipcub::DeviceScan::ExclusiveSum(s->scan_tmp, b, CountIter(s->cnt, CastI64()), s->off, n_units + 1, st)); }
 
     // mini-batches of whole walks (dge_sorted_batch_items: ~96 items per live row, the hottest row bounded)
-    int64_t total_pairs = 0;
     DGE_HIP(hipMemcpyAsync(&total_pairs, s->off + n_units, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     DGE_HIP(hipStreamSynchronize(st));
     if (total_pairs == 0) return DGE_OK;
+    }
     int64_t want_items = dge_sorted_batch_items(m, p.part_n);
     if (want_items == 0) want_items = 1 << 20;         // asked for explicitly on a vocabulary the rule would not pick it for: smallest mini-batches
     const double items_per_walk = (double)total_pairs * K1 / (double)p.n_rows;
@@ -532,15 +745,17 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     walks_per = std::min(walks_per, p.n_rows);
     const int64_t n_sub = (p.n_rows + walks_per - 1) / walks_per;
     std::vector<int64_t> marks((size_t)n_sub + 1), h_off((size_t)n_sub + 1);
-    for (int64_t k = 0; k <= n_sub; k++) marks[(size_t)k] = std::min(k * walks_per, p.n_rows) * p.L;
+    // marks: the unit (per-episode path) or the (bucket, walk) cell (item store) at which every mini-batch begins -> its first pair
+    for (int64_t k = 0; k <= n_sub; k++) marks[(size_t)k] = use_store ? (int64_t)p.part_tgt * p.n_rows + std::min(k * walks_per, p.n_rows) : std::min(k * walks_per, p.n_rows) * p.L;
     if (n_sub + 1 > s->cap_marks) {
+        DGE_HIP(hipStreamSynchronize(st));
         dge_dev_free(s->d_marks); s->d_marks = nullptr;
         if ((rc = dge_dev_alloc(&s->d_marks, 2 * ((size_t)n_sub + 1)))) return rc;
         s->cap_marks = n_sub + 1;
     }
     DGE_HIP(hipMemcpyAsync(s->d_marks, marks.data(), ((size_t)n_sub + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_sorted_marks, dim3(grid_for(n_sub + 1, 256)), dim3(256), 0, st, s->off, s->d_marks, (int)(n_sub + 1), s->d_marks + n_sub + 1);
-    DGE_HIP(hipMemcpyAsync(h_off.data(), s->d_marks + n_sub + 1, ((size_t)n_sub + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_sorted_marks, dim3(grid_for(n_sub + 1, 256)), dim3(256), 0, st, use_store ? s->st_off : s->off, s->d_marks, (int)(n_sub + 1), s->d_marks + s->cap_marks);
+    DGE_HIP(hipMemcpyAsync(h_off.data(), s->d_marks + s->cap_marks, ((size_t)n_sub + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     DGE_HIP(hipStreamSynchronize(st));
 
     int64_t max_slots = 0;
@@ -585,10 +800,10 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         if ((rc = dge_dev_alloc(&s->seg, 3 * ((size_t)Vk + 2)))) return rc;
         s->cap_seg = Vk + 2;
     }
-    if (m->V > s->cap_shadow) {
+    if (Vk > s->cap_shadow) {
         dge_dev_free(s->shadow); s->shadow = nullptr;
-        if ((rc = dge_dev_alloc(&s->shadow, (size_t)m->V * (size_t)m->stride + 64))) return rc;
-        s->cap_shadow = m->V;
+        if ((rc = dge_dev_alloc(&s->shadow, (size_t)Vk * (size_t)m->stride + 64))) return rc;
+        s->cap_shadow = Vk;
     }
     const int64_t need_rows = 2 * ((s->cap_items + chunk - 1) / chunk) + 2;
     if (need_rows > s->cap_scratch_rows) {
@@ -609,13 +824,15 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         const int64_t n = (h_off[(size_t)k + 1] - h_off[(size_t)k]) * K1;
         if (n == 0) continue;
         const int x = (int)(live++ & 1);
-        q.unit0 = marks[(size_t)k]; q.unit1 = marks[(size_t)k + 1]; q.pair0 = h_off[(size_t)k]; q.n_slots = n;
+        q.unit0 = marks[(size_t)k]; q.unit1 = marks[(size_t)k + 1]; q.pair0 = h_off[(size_t)k]; q.n_slots = n;      // (unit0, unit1, pair0: the per-episode emit only)
         // second stream: items -> (key0, val0); sorted by target row -> (key1, val1); row segments
         if (s->set_used[x]) DGE_HIP(hipStreamWaitEvent(s->aux, s->ev_done[x], 0));         // the mini-batch that held this set has finished
         q.key_out = s->key0[x]; q.val_out = s->val0[x];
-        hipLaunchKernelGGL(k_sorted_emit, dim3(grid_for(q.unit1 - q.unit0 + 15, 256)), dim3(256), 0, s->aux, q);      // one 16-lane group per 16 units
+        const int32_t* src_key = s->key0[x]; const uint64_t* src_val = s->val0[x];
+        if (use_store) { src_key = s->st_key + h_off[(size_t)k] * K1; src_val = s->st_val + h_off[(size_t)k] * K1; }      // the batch's items are already there
+        else hipLaunchKernelGGL(k_sorted_emit, dim3(grid_for(q.unit1 - q.unit0 + 15, 256)), dim3(256), 0, s->aux, q);      // one 16-lane group per 16 units
         size_t b = s->sort_tmp_bytes;
-        DGE_HIP(sort_items(s->sort_tmp[0], b, s->key0[x], s->key1[x], s->val0[x], s->val1[x], n, end_bit, s->aux));
+        DGE_HIP(sort_items(s->sort_tmp[0], b, src_key, s->key1[x], src_val, s->val1[x], n, end_bit, s->aux));
         hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(Vk + 2, 256)), dim3(256), 0, s->aux, s->key1[x], n, Vk, seg_a[x]);
         DGE_HIP(hipEventRecord(s->ev_ready[x], s->aux));
         // model's stream — phase A: target rows move (into the shadow table); (context, target | g) -> (key0, val0)
