@@ -582,6 +582,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.ctab = m->d_ctab;
     p.n_rows = n_rows; p.L = L; p.W = m->cfg.window; p.K = m->cfg.negative; p.stride = m->stride;
     p.V = m->V; p.T = m->T; p.seed = m->cfg.seed;
+    p.T_magic = ~0ull / (uint64_t)std::max<int64_t>(m->T, 1); p.W_magic = ~0ull / (uint64_t)std::max(m->cfg.window, 1);
     p.gidx_base = (int64_t)epoch * total_walks + walk_index_base;
     p.words_done_base = (int64_t)epoch * m->total_words + words_before;
     p.all_words = (int64_t)std::max(m->cfg.epochs, 1) * m->total_words;
@@ -594,6 +595,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
     p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0; p.hs_cold = 0; p.hs_wave = 0;
     p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt; p.syn0_free = 0;
+    p.N_magic = 0xFFFFFFFFu / (uint32_t)std::max(m->part_n, 1);
     p.big_seg_shift = 0;
     p.filler_row = (int32_t)(0xFFFFFFF0u / ((uint32_t)m->stride * 4u)) - 1;      // offset + the largest in-row displacement stays below 2^32
     if (g_dge_tuning[DGE_TUNE_SEGMENT_SHIFT] >= 0) p.big_seg_shift = (int32_t)g_dge_tuning[DGE_TUNE_SEGMENT_SHIFT];   // tests: several segments on a small table

@@ -30,6 +30,8 @@ struct TrainParams {
     int64_t n_rows; int32_t L, W, K, stride;
     int32_t D;                // the rows' meaningful floats (stride = D rounded up to 64: the rest is zero padding and stays zero)
     int64_t V, T;
+    uint64_t T_magic, W_magic;    // floor((2^64 - 1) / T), floor((2^64 - 1) / W): dge_fast_mod (the item generators of sgns_sorted.hip are instruction bound)
+    uint32_t N_magic;             // floor((2^32 - 1) / part_n): dge_fast_div32
     uint64_t seed;
     int64_t gidx_base;        // (epoch*total_walks + walk_index_base): RNG stream key of row 0
     int64_t words_done_base;  // epoch*total_words + words_before
@@ -106,6 +108,24 @@ __device__ __forceinline__ int32_t neg_table_row(const uint4* __restrict__ ctab,
     const uint32_t m1 = j < 32u ? 0u : (j >= 63u ? 0xFFFFFFFFu : ((2u << (j - 32u)) - 1u));
     const uint32_t m2 = j < 64u ? 0u : (j >= 95u ? 0xFFFFFFFFu : ((2u << (j - 64u)) - 1u));
     return (int32_t)(r.x + (uint32_t)__popc(r.y & m0) + (uint32_t)__popc(r.z & m1) + (uint32_t)__popc(r.w & m2));
+}
+
+// x % d for a divisor that is fixed for the launch: q = mulhi(x, floor((2^64 - 1) / d)) falls short of x / d by at most 2 — a dozen instructions
+// instead of the ~70 of a 64-bit division, same remainder
+__device__ __forceinline__ uint64_t dge_fast_mod(uint64_t x, uint64_t d, uint64_t magic) {
+    uint64_t r = x - __umul64hi(x, magic) * d;
+    if (r >= d) r -= d;
+    if (r >= d) r -= d;
+    return r;
+}
+
+// x / d for 0 <= x < 2^31 and a launch-constant divisor, the same way
+__device__ __forceinline__ int32_t dge_fast_div32(int32_t x, int32_t d, uint32_t magic) {
+    uint32_t q = __umulhi((uint32_t)x, magic);
+    uint32_t r = (uint32_t)x - q * (uint32_t)d;
+    if (r >= (uint32_t)d) { r -= (uint32_t)d; q++; }
+    if (r >= (uint32_t)d) { q++; }
+    return (int32_t)q;
 }
 
 template <int DCH> struct Row { float4 v[DCH]; };

@@ -108,7 +108,7 @@ __device__ __forceinline__ void unit_window(const TrainParams& p, int64_t w, int
     const int64_t gbase = (p.gidx_base + w) * (int64_t)p.L;
     s = dge_mix64(p.seed + (uint64_t)(gbase + i));
     s = s * DGE_W2V_MULT + 11;
-    const int radius = p.W - (int)(s % (uint64_t)p.W);
+    const int radius = p.W - (int)dge_fast_mod(s, (uint64_t)p.W, p.W_magic);
     lo = max(0, i - radius);
     hi = min(len - 1, i + radius);
 }
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
                         if (K <= 16) {                                                    // (more negatives than lanes: one pair per trip, below)
                             const uint64_t sl = s * mA + cA;
                             if (lane < K) {
-                                int32_t t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
+                                int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
                                 if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                                 tv[z] = t;
                             }
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
                             const int kc = min(16, K - kd);
                             const uint64_t sl = s * mA + cA;
                             if (lane < kc) {
-                                int32_t t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
+                                int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
                                 if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                                 if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
                                 q.key_out[slot + 1 + kd + lane] = t == word ? q.Vk : t / q.kdiv;
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256) k_block_count(TrainParams p, int32_t* cel
         const int len = (int)p.len[w];
         const int32_t* sen = p.sen + w * p.L;
         uint64_t ctx_mask = 0;
-        for (int j = 0; j < len; j++) ctx_mask |= (uint64_t)(sen[j] % p.part_n == p.part_ctx) << j;
+        for (int j = 0; j < len; j++) { const int32_t v = sen[j]; ctx_mask |= (uint64_t)(v - dge_fast_div32(v, p.part_n, p.N_magic) * p.part_n == p.part_ctx) << j; }
         words = len;
         int cnt[16];
 #pragma unroll
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256) k_block_count(TrainParams p, int32_t* cel
             unit_window(p, w, i, len, s, lo, hi);
             const uint64_t wm = (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & (~0ull << lo) & ~(1ull << i);
             const int n = __popcll(ctx_mask & wm);
-            const int t = sen[i] % p.part_n;
+            const int32_t wv = sen[i]; const int t = wv - dge_fast_div32(wv, p.part_n, p.N_magic) * p.part_n;
 #pragma unroll
             for (int z = 0; z < 16; z++) cnt[z] += z == t ? n : 0;
         }
@@ -343,7 +343,8 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
         uint64_t pm = ctx_mask & (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & (~0ull << lo) & ~(1ull << i);
         if (!pm) continue;
         const int32_t word = walk_tok(true, sen, i, tk0, tk1, tk2, tk3);
-        const int bucket = word % N;
+        const int32_t wkey = dge_fast_div32(word, N, p.N_magic);
+        const int bucket = word - wkey * N;
         const uint64_t s_centre = s;
         int64_t slot = (int64_t)shfl16_u64((uint64_t)my_pos, bucket) * (int64_t)(K + 1);
         const int np = __popcll(pm);
@@ -361,7 +362,7 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
                     if (K <= 16) {
                         const uint64_t sl = dge_mix64(s_centre + (uint64_t)c) * mA + cA;       // every pair draws from its own stream
                         if (lane < K) {
-                            int32_t t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
+                            int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
                             if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                             tv[z] = t;
                         }
@@ -374,11 +375,12 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
             for (int z = 0; z < 4; z++) {
                 if (z >= npair) break;
                 const uint64_t hi32 = (uint64_t)(uint32_t)lastv[z] << 32;
-                if (lane == 0) { key_out[slot] = word / N; val_out[slot] = hi32 | (uint64_t)__float_as_uint(alpha); }
+                if (lane == 0) { key_out[slot] = wkey; val_out[slot] = hi32 | (uint64_t)__float_as_uint(alpha); }
                 if (K <= 16) {
                     if (lane < K) {
-                        const int32_t t = part_row(tv[z], N, bucket, p.V);
-                        key_out[slot + 1 + lane] = t == word ? Vk : t / N;
+                        int32_t tk = dge_fast_div32(tv[z], N, p.N_magic);              // part_row: the row of the bucket's partition nearest below the draw
+                        if ((int64_t)tk * N + bucket >= p.V) tk--;
+                        key_out[slot + 1 + lane] = tk == wkey ? Vk : tk;
                         val_out[slot + 1 + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);      // label 0: the sign bit
                     }
                 } else {
@@ -387,10 +389,11 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
                         const int kc = min(16, K - kd);
                         const uint64_t sl = sp * mA + cA;
                         if (lane < kc) {
-                            int32_t t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
+                            int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
                             if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
-                            t = part_row(t, N, bucket, p.V);
-                            key_out[slot + 1 + kd + lane] = t == word ? Vk : t / N;
+                            int32_t tk = dge_fast_div32(t, N, p.N_magic);
+                            if ((int64_t)tk * N + bucket >= p.V) tk--;
+                            key_out[slot + 1 + kd + lane] = tk == wkey ? Vk : tk;
                             val_out[slot + 1 + kd + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);
                         }
                         sp = shfl16_u64(sl, kc - 1);
