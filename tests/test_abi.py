@@ -52,6 +52,13 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
                 txt = open(os.path.join(d, f), errors="replace").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "dge_oracle" not in txt.replace("oracle/dge_oracle.c", ""), f
+    # ... nor may a CHECKER live inside the product: host restatements that tests compare the kernels with belong to oracle/ (or tests/)
+    ev = open(os.path.join(ROOT, "embedding_amd", "evaluate.py")).read()
+    for name in ("pairwise_estimator", "cosine_distance_matrix", "def dcg_at_k", "def ndcg_at_k", "def ndcg_against("):
+        assert name not in ev, "embedding_amd/evaluate.py holds the host restatement %s: it belongs to oracle/quality.py" % name
+    # ... and the timed region of bench.py may only meet the oracle inside cpu_baseline
+    b = open(os.path.join(ROOT, "bench.py")).read()
+    assert b.count("from oracle") == 1 and b.index("from oracle") > b.index("def cpu_baseline(")
 
 
 def test_cpp_host_mirror_compiles_against_the_abi(tmp_path, dge):

@@ -163,3 +163,72 @@ def test_cfg2_shaped_auto_schedule_resolves_to_owner_computes(dge):
     assert res[0]["sch"]["update_policy"] == 8 and res[2]["sch"]["update_policy"] == 2, res
     assert res[0]["pairs"] == res[2]["pairs"] > 4.0e7
     assert res[0]["auc"] > res[2]["auc"] - 0.01, res
+
+
+def test_cfg5_at_full_size(dge, oracle):
+    """BASELINE configs[4] AT FULL SIZE on one GPU: power-law 10 000 008 vertices / ~874 M edges, 24 slices, D = 256, K = 20, the vocabulary of
+    the 10 M-walk epoch corpus, one bench-sized launch (1 000 008 walks) under auto.  Checked: the auto rule resolves to the mixed policy 7 with a
+    count-derived head below V/8; pairs and words identities; finite tables in which every trained row moved; and the walk half against the
+    ORACLE — the alias table of the largest hub and 2 000 walks, bit for bit (the oracle is handed the out-edges of every vertex those walks
+    visit and every vertex's out-degree: what the walks read)."""
+    import ctypes as C
+
+    import torch
+    from embedding_amd import synth
+    R, T, L, D, K = 416667, 24, 24, 256, 20
+    NV = R * T
+    G = synth.powerlaw_flow_graph_torch(R, T, 1_000_000_000, "cuda:0")
+    n_edges = int(G["n_edges"])
+    assert 8.0e8 < n_edges <= 1.0e9
+    g = dge.DeviceGraph(0); g.add_edges_device(G["src"], G["dst"], G["w"]); sources = G["sources"]; del G
+    torch.cuda.empty_cache()
+    g.set_sources(sources); g.build_alias(False)
+    assert g.num_vertices == NV and g.num_edges == n_edges
+
+    # ---- walk half vs the oracle
+    row_ptr = np.zeros(NV + 1, np.int64); od = np.zeros(NV, np.float64)
+    dge._native.check(dge.lib.dge_graph_get_csr(g._h, row_ptr.ctypes.data_as(C.c_void_p), None, None, None, None, od.ctypes.data_as(C.c_void_p), NV, 0))
+    deg = np.diff(row_ptr)
+    hub = int(deg.argmax())
+    assert deg[hub] >= 100_000                                         # a hub of 1e5 .. 1e6 slots
+    walks = g.sample_walks(2000, L, seed=5, rng_mode=1)
+    visited = np.unique(np.concatenate([walks[walks >= 0], [hub]]))
+    es, ed, ew = [], [], []
+    dev_tables = {}
+    for v in visited:
+        a = g.get_alias(int(v), tables=(int(v) == hub))
+        es.append(np.full(len(a["nbr"]), v, np.int32)); ed.append(a["nbr"]); ew.append(a["weight"])
+        if int(v) == hub:
+            dev_tables = a
+    og = oracle.Graph(); og.reserve_vertices(NV)
+    og.add_edges(np.concatenate(es), np.concatenate(ed), np.concatenate(ew))
+    og.set_out_degree(od)                                              # (the sources' weights are their out-degrees: J/LayeredGraph.java:199-225)
+    og.set_sources(sources); og.build_alias(False)
+    ha = og.get_alias(hub)
+    assert np.array_equal(ha["alias"], dev_tables["alias"]) and np.array_equal(bits(ha["prob"]), bits(dev_tables["prob"]))
+    assert np.array_equal(og.sample_walks(2000, L, seed=5, rng_mode=1), walks)
+    del og, es, ed, ew
+
+    # ---- training half: the epoch's vocabulary, one bench-sized launch
+    epoch = NV                                                         # walks_per_vertex = 1 (bench.py WORKLOADS["cfg5"])
+    corpus = g.sample_walks_device(epoch, L, seed=20171106)
+    counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0"); corpus.count_tokens(NV, counts)
+    B = epoch // 10
+    sub = torch.zeros(NV, dtype=torch.int64, device="cuda:0"); corpus.count_tokens(NV, sub, 0, B)
+    words = int(sub[counts >= 2].sum().item())
+    m = dge.SgnsModel.create(dge.make_config(D, L, NV, negative=K, workers=0, epochs=1, seed=1), counts, 0)
+    before, vid = m.vectors()
+    V = len(vid)
+    assert V >= 3_000_000
+    m.train(corpus, 0, B, walk_index_base=0, total_walks=epoch)
+    st, sch = m.stats(), m.schedule()
+    assert sch["update_policy"] == 7 and 0 < sch["hot_rows"] < V // 8, sch
+    assert st["words"] == words
+    assert 0.5 * 383.3 / 24 < st["pairs"] / st["words"] <= 383.3 / 24 + 0.2          # (dead ends and dropped rare vertices shorten some walks)
+    after = m.vectors()[0]
+    assert np.isfinite(after).all() and np.isfinite(m.syn1neg()).all()
+    trained = np.zeros(NV, bool); trained[np.flatnonzero(sub.cpu().numpy() > 0)] = True
+    rows = trained[vid]
+    moved = np.abs(after - before).max(1) > 0
+    assert moved[rows].mean() > 0.99 and not moved[~rows].any()                        # rows of the launch's tokens moved (as context rows); no other row did
+    assert st["pairs"] / (st["kernel_ms"] * 1e-3) > 5e7                              # and it is the fast path

@@ -147,3 +147,53 @@ def test_random_configuration_lock_kernels_one_worker(dge, oracle, seed):
             assert np.isfinite(syn0).all()
             c0 = cosine_rows(syn0, om.syn0); c1 = cosine_rows(dm.syn1neg() + 1e-30, om.syn1neg + 1e-30)
             assert c0.min() > 1 - 1e-4 and c1.min() > 1 - 1e-4, ("1 - cosine: syn0 %.3g, syn1neg %.3g" % (1 - c0.min(), 1 - c1.min()), seed, pol, cfg)
+
+
+@pytest.mark.parametrize("seed", list(range(40)) + [-s for s in range(1, 17)])
+def test_random_configuration_against_word2vec_order(dge, oracle, seed, request):
+    """The 40 + 16 configurations of test_random_configuration_bit_exact once more, against the oracle in word2vec.c's OWN arithmetic order
+    (arith=0: sequential dot products, unfused multiply-add) instead of the order written to mirror the kernels' lanes — for the in-order
+    schedule (policy 0), memory-side atomics with one worker (2) and the owner-computes policy with one worker (8), plain, with hierarchical
+    softmax and under the 3-rank block schedule: north_star's 1e-4 cosine on EVERY row of syn0, syn1neg and syn1, with the exact pair count.
+    So no schedule's only witness is an oracle mode shaped after the kernel."""
+    import torch
+    from helpers import cosine_rows
+    if seed < 0:
+        knobs = dge.tuning(force_segments=1, segment_shift=3)
+        knobs.__enter__(); request.addfinalizer(lambda: knobs.__exit__(None, None, None))
+        seed = -seed
+    ids, NV, cfg, mode = _case(seed)
+    if mode == "hs" and cfg["negative"] == 0 and cfg["dim"] > 256:
+        cfg["dim"] = 64
+    n_ranks = 3 if mode == "blocks" else 0
+    kw = dict(negative=cfg["negative"], min_count=cfg["min_count"], epochs=cfg["epochs"], seed=cfg["seed"], table_size=cfg["table_size"])
+    om = oracle.train_sgns(ids, NV, cfg["dim"], cfg["window"], arith=0, use_hs=(mode == "hs"), part_n=n_ranks, **kw)
+    if mode == "blocks" and om.V < n_ranks:
+        mode = "plain"
+        om = oracle.train_sgns(ids, NV, cfg["dim"], cfg["window"], arith=0, **kw)
+    for pol in ((0, 2) if mode == "hs" else (0, 2, 8)):          # (hierarchical softmax runs under policies 0 / 2 only)
+        c = dge.make_config(cfg["dim"], cfg["window"], NV, workers=1, update_policy=pol, use_hs=(mode == "hs"), **kw)
+        if mode != "blocks":
+            dm = dge.SgnsModel.fit(ids, c, 0)
+            pairs = dm.stats()["pairs"]
+            s1 = dm.syn1neg()
+        else:
+            corpus = dge.WalkCorpus.from_host(ids, 0)
+            counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0"); corpus.count_tokens(NV, counts)
+            ms = [dge.SgnsModel.create(c, counts, 0) for _ in range(n_ranks)]
+            for ep in range(cfg["epochs"]):
+                simulate_block_schedule(ms, lambda m: m.train(corpus, epoch=ep))
+            simulate_gather_syn0(ms)
+            dm = ms[0]
+            pairs = sum(m.stats()["pairs"] for m in ms)
+            s1 = np.stack([ms[r % n_ranks].syn1neg()[r] for r in range(om.V)]) if om.V else dm.syn1neg()      # partition p is current on rank p
+        syn0, vid = dm.vectors()
+        assert np.array_equal(vid, om.vocab_ids) and pairs == om.pairs, (seed, mode, pol, cfg)
+        if om.V == 0:
+            continue
+        assert np.isfinite(syn0).all()
+        c0 = cosine_rows(syn0, om.syn0).min(); c1 = cosine_rows(s1 + 1e-30, om.syn1neg + 1e-30).min()
+        assert c0 > 1 - 1e-4 and c1 > 1 - 1e-4, ("1 - cosine: syn0 %.3g, syn1neg %.3g" % (1 - c0, 1 - c1), seed, mode, pol, cfg)
+        if mode == "hs" and om.V > 1:
+            c2 = cosine_rows(dm.syn1() + 1e-30, om.syn1 + 1e-30).min()
+            assert c2 > 1 - 1e-4, ("1 - cosine: syn1 %.3g" % (1 - c2), seed, pol, cfg)

@@ -1,5 +1,5 @@
 """GPU: dge_knn_cosine (fused MFMA similarity + top-k) against the host restatement of the reference's pairwiseEstimator
-(embedding_amd/evaluate.py, P/embeddingEvaluation_tract.py:169-196).  Distances within 2e-6 (float32 MFMA vs float64
+(oracle/quality.py, P/embeddingEvaluation_tract.py:169-196).  Distances within 2e-6 (float32 MFMA vs float64
 scipy arithmetic); neighbour indices identical wherever the host distances are separated by more than that."""
 import numpy as np
 import pytest
@@ -8,8 +8,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _check(ev, f, k):
+    from oracle import quality as qo
     idx, dist, ms = ev.knn_cosine_gpu(f, k)
-    d = ev.cosine_distance_matrix(f)
+    d = qo.cosine_distance_matrix(f)
     np.fill_diagonal(d, np.inf)
     n = len(f)
     kk = min(k, n - 1)
@@ -28,6 +29,7 @@ def _check(ev, f, k):
 @pytest.mark.parametrize("n,dim,k", [(77, 2, 10), (300, 20, 10), (801, 20, 64), (1000, 128, 16), (257, 256, 5), (5, 8, 10)])
 def test_knn_matches_the_host_estimator(dge, n, dim, k):
     from embedding_amd import evaluate as ev
+    from oracle import quality as qo
     rng = np.random.default_rng(n + dim)
     f = rng.normal(size=(n, dim)).astype(np.float32)
     if n > 10:
@@ -41,20 +43,21 @@ def test_knn_feeds_ndcg_and_scales(dge):
     """nDCG@10 from GPU neighbour lists equals the host pipeline; one slice of the synthetic cfg3 graph (41 667 regions,
     D=128) runs in well under a second."""
     from embedding_amd import evaluate as ev
+    from oracle import quality as qo
     rng = np.random.default_rng(1)
     f = rng.normal(size=(400, 20)).astype(np.float32); g = (f + 0.05 * rng.normal(size=f.shape)).astype(np.float32)
     rids = list(range(400))
-    host = ev.ndcg_against(g, f, rids, k=10)
+    host = qo.ndcg_against(g, f, rids, k=10)
     idx, _, _ = ev.knn_cosine_gpu(g, 10)
-    gest, gnb = ev.pairwise_estimator(f, rids)
+    gest, gnb = qo.pairwise_estimator(f, rids)
     gnd = {r: dict(v) for r, v in gest.items()}
-    dcg_max = {r: ev.dcg_at_k(10, gnd[r], gnb[r]) for r in rids}
-    gpu = ev.ndcg_at_k(10, rids, {r: idx[r].tolist() for r in rids}, gnd, dcg_max)
+    dcg_max = {r: qo.dcg_at_k(10, gnd[r], gnb[r]) for r in rids}
+    gpu = qo.ndcg_at_k(10, rids, {r: idx[r].tolist() for r in rids}, gnd, dcg_max)
     assert abs(gpu - host) < 1e-6
     dev, _ = ev.ndcg_against_gpu(g, f, k=10)                   # the whole metric on the device (dge_ndcg_at_k)
     assert abs(dev - host) < 1e-5, (dev, host)
     f2 = f.copy(); f2[3] = 0.0                                 # a zero ground vector: its neighbours are at distance 2 (relevance -1)
-    assert abs(ev.ndcg_against_gpu(g, f2, k=10)[0] - ev.ndcg_against(g, f2, rids, k=10)) < 1e-5
+    assert abs(ev.ndcg_against_gpu(g, f2, k=10)[0] - qo.ndcg_against(g, f2, rids, k=10)) < 1e-5
     big = rng.normal(size=(41667, 128)).astype(np.float32)
     idx, dist, ms = ev.knn_cosine_gpu(big, 10)
     flops = 2.0 * 41667 * 41667 * 128

@@ -299,8 +299,8 @@ def test_od_sources_include_a_destination_only_layer0_vertex(tmp_path, oracle):
 
 
 def test_quality_metric_restatement(oracle):
-    """embedding_amd/evaluate.py (P/embeddingEvaluation_tract.py:169-196,249-260): KNN by cosine distance + nDCG@k."""
-    from embedding_amd import evaluate as ev
+    """oracle/quality.py (P/embeddingEvaluation_tract.py:169-196,249-260): KNN by cosine distance + nDCG@k, the host restatement."""
+    from oracle import quality as ev
     rng = np.random.default_rng(0)
     f = rng.normal(size=(12, 5)); f[3] = 0.0                        # a zero vector: cosine is NaN -> distance 2
     rids = [100 + i for i in range(12)]
@@ -322,3 +322,92 @@ def test_quality_metric_restatement(oracle):
     b = oracle.train_sgns(walks, 160, 16, 4, table_size=5003, threads=4)
     sl = [r for r, v in enumerate(a.vocab_ids) if 40 <= v < 80]      # the rows of slice 1
     assert ev.ndcg_against(b.syn0[sl], a.syn0[sl], [int(a.vocab_ids[r]) for r in sl], k=5) > 0.8
+
+
+def test_update_arithmetic_second_reading_in_numpy_float32(oracle):
+    """A second, independent reading of the SGNS / hierarchical-softmax UPDATE (w2v.fit(), J/DeepWalk.java:73-79; word2vec.c's skip-gram loop
+    with DL4J's pair enumeration): every pair of a tiny corpus trained here in numpy float32 — unfused multiply-add, sequential dot product,
+    sigmoid through the 1000-entry table, hierarchical-softmax terms ahead of the negatives, a negative equal to the centre skipped — must
+    leave syn0, syn1neg and syn1 BIT-IDENTICAL to the C oracle's word2vec-order run (arith=0).  The oracle's update thus has two readings
+    that agree; neither is the reference (DL4J's source is absent: parity unpinned)."""
+    f32 = np.float32
+    rng = np.random.default_rng(12)
+    NV, L, n, D, W, K, T, seed = 9, 5, 14, 7, 3, 3, 53, 77
+    walks = rng.integers(0, NV, (n, L)).astype(np.int32)
+    walks[rng.random(walks.shape) < 0.15] = -1
+    for use_hs in (False, True):
+        m0 = oracle.train_sgns(walks, NV, D, W, negative=K, min_count=2, epochs=0, table_size=T, seed=seed, use_hs=use_hs)
+        m1 = oracle.train_sgns(walks, NV, D, W, negative=K, min_count=2, epochs=1, table_size=T, seed=seed, use_hs=use_hs, arith=0)
+        V = m0.V
+        remap = {int(v): r for r, v in enumerate(m0.vocab_ids)}
+        table = m0.table(T)
+        syn0 = m0.syn0.astype(f32).copy(); syn1neg = np.zeros((V, D), f32); syn1 = np.zeros((max(V - 1, 1), D), f32)
+        paths = [m0.code(r) for r in range(V)] if use_hs else None
+        # word2vec.c expTable: exp() in double of a float argument, stored as float; x / (x + 1) in float
+        e = np.array([f32(math.exp(float(f32(f32(f32(i) / f32(1000) * f32(2) - f32(1)) * f32(6))))) for i in range(1000)], f32)
+        e = (e / (e + f32(1))).astype(f32)
+        assert np.array_equal(e, oracle.exp_table())
+
+        def dot(a, b):
+            f = f32(0)
+            for k in range(D):
+                f = f32(f + f32(a[k] * b[k]))
+            return f
+
+        def axpy(y, g, x):                                   # y[k] += g * x[k], unfused
+            for k in range(D):
+                y[k] = f32(y[k] + f32(g * x[k]))
+
+        sens = [[remap[int(t)] for t in row if t >= 0 and int(t) in remap] for row in walks]
+        total_words = sum(len(s) for s in sens)
+        done, pairs = 0, 0
+        for wi, sen in enumerate(sens):
+            alpha = f32(float(f32(0.025)) * (1.0 - done / (total_words + 1)))      # (the configured rate is a float; the schedule runs in double)
+            if alpha < f32(1e-4):
+                alpha = f32(1e-4)
+            for i, word in enumerate(sen):
+                s = mix64((seed + wi * L + i) & M64)
+                s = (s * 25214903917 + 11) & M64
+                b = s % W
+                for a in range(b, 2 * W + 1 - b):
+                    c = i - W + a
+                    if a == W or c < 0 or c >= len(sen):
+                        continue
+                    l1 = syn0[sen[c]]
+                    neu = np.zeros(D, f32)
+                    if use_hs:
+                        pts, cds = paths[word]
+                        for node, code in zip(pts, cds):
+                            f = dot(l1, syn1[node])
+                            if f <= f32(-6) or f >= f32(6):
+                                continue
+                            g = f32(f32(f32(1) - f32(code) - e[int(f32(f32(f + f32(6)) * f32(1000 // 6 // 2)))]) * alpha)
+                            axpy(neu, g, syn1[node]); axpy(syn1[node], g, l1)
+                    for d in range(K + 1):
+                        if d == 0:
+                            target, label = word, f32(1)
+                        else:
+                            s = (s * 25214903917 + 11) & M64
+                            target = int(table[(s >> 16) % T])
+                            if target == 0 and V > 1:
+                                target = s % (V - 1) + 1
+                            if target == word:
+                                continue
+                            label = f32(0)
+                        f = dot(l1, syn1neg[target])
+                        if f > f32(6):
+                            g = f32(f32(label - f32(1)) * alpha)
+                        elif f < f32(-6):
+                            g = f32(label * alpha)
+                        else:
+                            g = f32(f32(label - e[int(f32(f32(f + f32(6)) * f32(1000 // 6 // 2)))]) * alpha)
+                        axpy(neu, g, syn1neg[target]); axpy(syn1neg[target], g, l1)
+                    for k in range(D):
+                        l1[k] = f32(l1[k] + neu[k])
+                    pairs += 1
+            done += len(sen)
+        assert pairs == m1.pairs and pairs > 50
+        assert np.array_equal(syn0.view(np.int32), m1.syn0.view(np.int32)), use_hs
+        assert np.array_equal(syn1neg.view(np.int32), m1.syn1neg.view(np.int32)), use_hs
+        if use_hs and V > 1:
+            assert np.array_equal(syn1[:V - 1].view(np.int32), m1.syn1.view(np.int32))
