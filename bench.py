@@ -364,6 +364,11 @@ def launch_ranks(n):
     port) and return their exit status.  Called before anything imports torch: the parent process never initialises a GPU."""
     import socket
     import subprocess
+    # under rocprofv3 this process already carries the profiler's preloaded library (and with it an initialised GPU): starting ranks from
+    # here would be the launcher hop this pool forbids.  Profile one rank per rocprofv3 process instead (scripts/collect_profiles.sh).
+    if any("rocprofiler" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or os.environ.get("ROCPROF_OUTPUT_PATH"):
+        print("bench.py: --gpus %d under a profiler: run one rank per rocprofv3 process (export RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)" % n, file=sys.stderr)
+        return 2
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]

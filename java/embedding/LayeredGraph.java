@@ -210,13 +210,16 @@ public class LayeredGraph {
      * J/LayeredGraph.java:232-252: one walk of at most numLayer names.  Walks are sampled on the device a batch at a time
      * from the stream position of LayeredGraph.rnd and handed out one by one; after every call rnd stands where the
      * reference's rnd would (one nextDouble per node of the walk), so code that draws from rnd between calls sees the
-     * reference's numbers.  Draws taken from rnd by OTHER code are noticed when a new batch starts, when rnd is replaced,
-     * and whenever numLayer or the graph changes (the batch is dropped and re-sampled from rnd's position).
+     * reference's numbers.  Draws taken from rnd by OTHER code between two calls are noticed at the next call (rnd's state is read —
+     * nothing is consumed — and compared with where this class left it): the rest of the batch is dropped and re-sampled from rnd's
+     * actual position, as it is when rnd is replaced and whenever numLayer or the graph changes.  The state check costs a few
+     * microseconds per call; sampleVertexSequences(n) is the bulk form the writer loops should use.
      */
     public List<String> sampleVertexSequence() {
         if (!aliasBuilt)
             throw new IllegalStateException("call initiateAliasTables() first (J/LayeredGraph.java:195)");
-        if (cachePos >= cacheRows || cacheL != numLayer || cacheRnd != rnd)
+        if (cachePos >= cacheRows || cacheL != numLayer || cacheRnd != rnd
+                || JavaRandomState.peek(rnd) != JavaRandomState.jump(cacheState0, 2 * cacheDraws))     // someone else drew from rnd since our last call
             refill();
         LinkedList<String> seq = new LinkedList<>();
         int base = cachePos * cacheL;

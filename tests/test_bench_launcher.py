@@ -66,3 +66,8 @@ def test_rank_without_a_device_leaves_before_the_rendezvous():
     out = _run(["--steps", "1", "--warmup", "0", "--workload", "tiny", "--no-cpu-baseline"], env={"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""}, timeout=300)
     assert out.returncode != 0 and "device(s)" in out.stderr and "nothing measured" in out.stderr, out.stderr[-1500:]
     assert not [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_launcher_refuses_to_start_ranks_under_a_profiler():
+    out = _run(["--gpus", "2", "--backend", "gloo", "--rendezvous-check"], env={"LD_PRELOAD_PROBE": "", "ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})
+    assert out.returncode == 2 and "one rank per rocprofv3 process" in out.stderr and "torch.distributed.run" not in out.stderr
