@@ -30,7 +30,7 @@
 #include "sgns_model.h"
 
 
-int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
@@ -687,7 +687,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     size_t shmem = 0;
     if (hs) {
         pol = pol == 0 ? 10 : 12;               // dge_model_create admitted policies 0/2/3 only
-        if (pol == 12) {
+        if (pol == 12 && workers > 1) {         // (one worker: the sequential schedule — no LDS accumulators, no cold class, every node by atomics it waits for)
             // LDS accumulators for the inner nodes nearest the root: 30 KB a block (3 blocks a CU stay resident beside the atomics wave's boxes)
             const int64_t row_b = (int64_t)m->stride * 4 + 4;
             p.hs_n_hot = (int32_t)std::min<int64_t>(std::max<int64_t>(m->V - 1, 0), 30720 / row_b);

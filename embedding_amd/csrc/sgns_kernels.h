@@ -496,6 +496,10 @@ __global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HS ? DGE_HS_WAVES :
 k_sgns_train(TrainParams p) {
     using P = Policy<POL>;
     constexpr bool HOT = HS && P::ATOMIC;         // inner nodes near the root combine their updates in LDS (hot_add)
+    // ONE worker under the atomic policy runs the sequential schedule: its float atomics are fire-and-forget, so before it reads rows again it
+    // waits for them (vmcnt counts them), and a row drawn twice within a batch is trained in turn — as for the plain policies
+    const bool solo = P::ATOMIC && p.n_workers == 1;
+#define DGE_SOLO_WAIT() do { if (solo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
     __shared__ float s_exp[EXP_TABLE_SIZE];
     __shared__ __attribute__((aligned(16))) float s_mb[HOT ? LK_MB_WORKERS * 2 * LkBox<DCH>::FLOATS : 4];     // the atomics wave's message boxes
     __shared__ int s_mb_flag[LK_MB_WORKERS * 2];
@@ -638,6 +642,7 @@ k_sgns_train(TrainParams p) {
 
         // ------------------------------------------------------------------ one pair: l1 = syn0[last], target rows in syn1neg
         Row<DCH> l1, neu;
+        DGE_SOLO_WAIT();
         row_load<DCH, P::LOAD_AUX, BIG>(l1, syn0, last, lane);
         if (new_centre) {
             row_load<DCH, P::LOAD_AUX, BIG>(h, syn1neg, word, lane);
@@ -721,7 +726,8 @@ k_sgns_train(TrainParams p) {
                     tg[q] = (base + q < kc) ? v : -1;
                 }
                 bool dup = false;
-                if (!P::ATOMIC) {
+                DGE_SOLO_WAIT();                           // (the previous batch's atomics)
+                if (!P::ATOMIC || solo) {
 #pragma unroll
                     for (int q = 1; q < NEG_BATCH; q++)
 #pragma unroll
@@ -777,6 +783,7 @@ k_sgns_train(TrainParams p) {
     DGE_CLOSE_CENTRE();
 #undef DGE_TOK
 #undef DGE_CLOSE_CENTRE
+#undef DGE_SOLO_WAIT
     if (lane == 0 && !atomics_wave) {
         if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
         if (my_words) atomicAdd(&p.counters[1], my_words);
