@@ -427,8 +427,8 @@ __global__ void k_sorted_segments(const int32_t* __restrict__ keys, int64_t n, i
 // PB == true (phase B): key = context row (owned, syn0), value = target row | g; the row takes the sum of g * syn1neg[target].
 // A row that lies wholly inside the chunk is stored directly; a segment of a row shared with a neighbouring chunk leaves its DELTA in
 // scratch slot 2*chunk (the segment starts the chunk) or 2*chunk+1 (it ends the chunk), summed up by k_sorted_fixup.
-// SORTED_PIPE: rows of the other side in flight per worker
-template <int DCH, bool PB, int SORTED_PIPE>
+#define SORTED_PIPE 4      /* rows of the other side in flight per worker (8 measured the same: cfg2 3.5 ms per launch either way, an 8-rank block 62.5 against 62.7 ms) */
+template <int DCH, bool PB>
 __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
     const TrainParams& p = q.t;
     __shared__ float s_exp[EXP_TABLE_SIZE];
@@ -628,15 +628,8 @@ template <int DCH>
 static void launch_phase(const SortedParams& q, bool phase_b, hipStream_t st) {
     const int64_t chunks = (q.n_slots + q.chunk - 1) / q.chunk;
     const unsigned blocks = grid_for(chunks * 16, 256);
-    // rows in flight per worker: 4; 8 where a row is one 256-byte chunk (DGE_TUNE_SORTED_PIPE: ablation)
-    const int pipe = g_dge_tuning[DGE_TUNE_SORTED_PIPE] > 0 ? (int)g_dge_tuning[DGE_TUNE_SORTED_PIPE] : (DCH == 1 ? 8 : 4);
-    if (pipe >= 8 && DCH <= 2) {
-        if (phase_b) hipLaunchKernelGGL((k_sorted_phase<DCH, true, (DCH <= 2 ? 8 : 4)>), dim3(blocks), dim3(256), 0, st, q);
-        else hipLaunchKernelGGL((k_sorted_phase<DCH, false, (DCH <= 2 ? 8 : 4)>), dim3(blocks), dim3(256), 0, st, q);
-    } else {
-        if (phase_b) hipLaunchKernelGGL((k_sorted_phase<DCH, true, 4>), dim3(blocks), dim3(256), 0, st, q);
-        else hipLaunchKernelGGL((k_sorted_phase<DCH, false, 4>), dim3(blocks), dim3(256), 0, st, q);
-    }
+    if (phase_b) hipLaunchKernelGGL((k_sorted_phase<DCH, true>), dim3(blocks), dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((k_sorted_phase<DCH, false>), dim3(blocks), dim3(256), 0, st, q);
     hipLaunchKernelGGL((k_sorted_fixup<DCH>), dim3(blocks), dim3(256), 0, st, q, phase_b ? 1 : 0);
 }
 static void launch_phase_any(int dch, const SortedParams& q, bool phase_b, hipStream_t st) {

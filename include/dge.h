@@ -318,8 +318,7 @@ enum {
     DGE_TUNE_STATIC_WALKS = 7,    /* > 0: the lock kernels' worker w trains walks w, w + workers, ... instead of taking them from a launch-wide counter */
     DGE_TUNE_HS_COLD = 8,         /* hierarchical softmax under atomics: inner nodes [0, value) take plain read-modify-write (default: those on < 2e-5 of the paths) */
     DGE_TUNE_HS_WAVE = 9,         /* hierarchical softmax under atomics: 0 = the workers issue their atomics themselves, 1 = through the workgroup's atomics wave (default: the wave from 65 536 rows on) */
-    DGE_TUNE_SORTED_PIPE = 10,    /* update_policy 8: rows of the other table a worker keeps in flight (4 or 8; default 8 for rows of one 256-byte chunk, else 4) */
-    DGE_TUNE_COUNT = 11
+    DGE_TUNE_COUNT = 10
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
 int  dge_get_tuning(int32_t knob, int64_t* value);   /* -1 = the library's own rule */
