@@ -81,7 +81,7 @@ def test_bench_workloads_and_traffic_table():
     assert {"cfg1", "cfg2", "cfg3", "cfg3_zipf", "cfg5"} <= set(bench.WORKLOADS)
     w = bench.WORKLOADS["cfg3"]
     assert w["R"] * w["T"] == 1000008 and w["dim"] == 128 and w["negative"] == 5 and w["L"] == 24      # the configuration the metric is quoted on
-    assert bench.measured_traffic("cfg3", "policy5", 1000.0) == 7274.0 * 1000.0
+    assert bench.measured_traffic("cfg3", "policy5", 1000.0) == 7197.0 * 1000.0          # profiles/r03_cfg3_pmc.csv
     assert bench.measured_traffic("cfg5", "policy7", 1.0) > 45056 and bench.measured_traffic("cfg3", "hs", 1.0) > 0
     assert bench.measured_traffic("cfg3", "policy99", 1.0) is None
     table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
