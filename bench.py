@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--force-exchange", action="store_true", help="run the delta exchange even with one rank (plumbing check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (debugging the multi-rank plumbing)")
-    ap.add_argument("--placement-candidates", type=int, default=3,
+    ap.add_argument("--placement-candidates", type=int, default=4,
                     help="the library's placement search before the timed region (dge_model_tune_placement: each large array of the model is tried "
                          "in up to N - 1 other allocations on a quarter-batch probe launch, the faster placement stays; tables restored afterwards; "
                          "which physical memory an array received is worth up to 15 %%: profiles/r03_placement.txt); 1 = whatever the first allocation got")

@@ -612,7 +612,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     if (m->cfg.update_policy == 0 && m->cfg.workers == 0 && !hs && (uint64_t)m->V * (uint64_t)m->stride * 4ull < 0xFFFFFFFFull) {
         const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
         const bool locks_work = m->V >= 262144 && (fail < 0.25 || m->hot_rows_auto <= m->V / 8);   // -> commit locks, all rows (5) or the tail (7)
-        if (part) sorted_auto = m->part_n >= 3 && dge_sorted_batch_items(m, m->part_n) > 0;         // (per rank on cfg3, owner-computes vs locks: N = 2 7.2e8 vs 7.7e8, N = 4 7.1e8 vs 5.9e8, N = 8 6.4e8 vs 4.0e8)
+        if (part) sorted_auto = m->part_n >= 2 && dge_sorted_batch_items(m, m->part_n) > 0;         // (per rank on cfg3, owner-computes vs locks, round 3 with the items made once per batch: N = 2 7.5e8 vs 7.2e8, N = 4 7.8e8 vs 7.4e8, N = 8 7.5e8 vs 4.8e8)
         else sorted_auto = !locks_work && dge_sorted_batch_items(m, 1) > 0;                         // (what used to fall back to atomics)
     }
     if ((m->cfg.update_policy == 8 && m->cfg.workers != 1) || sorted_auto) {
@@ -790,7 +790,7 @@ extern "C" int dge_train_sgns_device(const dge_walks* w, const dge_train_config*
     // models whose launches are long enough for it to pay get the placement search first (results are unaffected: dge_model_tune_placement)
     if (!rc && cfg->epochs > 0 && cfg->workers != 1 && m->V >= 262144 && w->n >= 262144) {
         double before = 0, after = 0; int32_t moved = 0;
-        rc = dge_model_tune_placement(m, w, 0, std::min<int64_t>(w->n / 8, 262144), 3, &before, &after, &moved);
+        rc = dge_model_tune_placement(m, w, 0, std::min<int64_t>(w->n / 8, 262144), 4, &before, &after, &moved);
     }
     for (int ep = 0; ep < cfg->epochs && !rc; ep++) rc = dge_model_train(m, w, 0, w->n, 0, ep, 0, 1.0, w->n);
     if (!rc) { hipError_t e = hipStreamSynchronize(m->stream); if (e != hipSuccess) { dge_set_error("training failed: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; } }
@@ -1049,18 +1049,25 @@ extern "C" int dge_model_tune_placement(dge_model* m, const dge_walks* w, int64_
     first = best;
     struct Slot { void** p; size_t bytes; };
     Slot slots[4] = {{(void**)&m->d_ctab, ctab_bytes}, {(void**)&m->d_locks, lock_bytes}, {(void**)&m->d_syn1neg, tab_bytes}, {(void**)&m->d_syn0, tab_bytes}};
-    for (int a = 0; a < 4 && rc == DGE_OK; a++)
-        for (int c = 1; c < candidates && rc == DGE_OK; c++) {
-            void* fresh = nullptr;
-            if (hipMalloc(&fresh, slots[a].bytes) != hipSuccess) { (void)hipGetLastError(); break; }      // out of memory: keep what we have
-            void* old = *slots[a].p;
-            if (hipMemcpyAsync(fresh, old, slots[a].bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { (void)hipFree(fresh); dge_set_error("dge_model_tune_placement: copy failed"); rc = DGE_ERR_DEVICE; break; }
-            *slots[a].p = fresh;
-            double t = 0;
-            rc = tune_time_launch(m, w, row0, n_rows, &t);
-            if (rc == DGE_OK && t < best * 0.995) { best = t; graveyard.push_back(old); moved++; }
-            else { *slots[a].p = old; graveyard.push_back(fresh); }
-        }
+    // A pass tries every array in up to candidates - 1 other allocations.  A pass that found nothing ends the search (a model that started
+    // well costs one pass); one that did means the model started badly, and arrays it left alone may still be badly placed: up to three passes
+    // (one box in three needed the second: 119.4 -> 115.7 ms after one pass, 447.8 ms per launch where its neighbours ran 414).
+    for (int pass = 0; pass < 3 && rc == DGE_OK; pass++) {
+        const int moved_before = moved;
+        for (int a = 0; a < 4 && rc == DGE_OK; a++)
+            for (int c = 1; c < candidates && rc == DGE_OK; c++) {
+                void* fresh = nullptr;
+                if (hipMalloc(&fresh, slots[a].bytes) != hipSuccess) { (void)hipGetLastError(); break; }      // out of memory: keep what we have
+                void* old = *slots[a].p;
+                if (hipMemcpyAsync(fresh, old, slots[a].bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { (void)hipFree(fresh); dge_set_error("dge_model_tune_placement: copy failed"); rc = DGE_ERR_DEVICE; break; }
+                *slots[a].p = fresh;
+                double t = 0;
+                rc = tune_time_launch(m, w, row0, n_rows, &t);
+                if (rc == DGE_OK && t < best * 0.995) { best = t; graveyard.push_back(old); moved++; break; }      // this array is well placed now: next array
+                else { *slots[a].p = old; graveyard.push_back(fresh); }
+            }
+        if (moved == moved_before) break;
+    }
     hipError_t e = hipStreamSynchronize(st);
     for (void* g : graveyard) (void)hipFree(g);
     if (rc == DGE_OK && e != hipSuccess) { dge_set_error("dge_model_tune_placement: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; }

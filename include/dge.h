@@ -153,7 +153,7 @@ typedef struct dge_train_config {
                                     distribution is flat enough for lock attempts to succeed (expected failure
                                     rate < 0.25) and no single row is busy enough to serialise its pairs behind its lock
                                     (workers x p_row <= 0.5); otherwise (a skewed vocabulary, a small one, a block of a schedule of
-                                    >= 3 ranks) 8 when the tables are below 4 GiB and there are >= 32768 live rows; else 7 / 2 as
+                                    >= 2 ranks) 8 when the tables are below 4 GiB and there are >= 32768 live rows; else 7 / 2 as
                                     before (a head of at most V/8 rows carries the skew / everything by atomics);
                                 1 = agent-scope row read-modify-write, write-through (last writer of a row wins);
                                 2 = agent-scope loads + memory-side float atomics (no update is lost);
