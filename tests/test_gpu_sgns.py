@@ -663,16 +663,17 @@ def test_placement_search_leaves_the_model_as_it_was(dge, oracle):
     walks, NV = _walks(oracle, dge, R=60, T=6, n=3000)
     corpus = dge.WalkCorpus.from_host(walks, 0)
     counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0"); corpus.count_tokens(NV, counts)
-    for workers, pol in ((1, 0), (0, 2), (0, 5)):
-        cfg = dge.make_config(64, walks.shape[1], NV, workers=workers, update_policy=pol, table_size=20011)
+    for workers, pol, hs in ((1, 0, False), (0, 2, False), (0, 5, False), (1, 0, True), (0, 2, True)):
+        cfg = dge.make_config(64, walks.shape[1], NV, workers=workers, update_policy=pol, table_size=20011, use_hs=hs)
         a = dge.SgnsModel.create(cfg, counts, 0); b = dge.SgnsModel.create(cfg, counts, 0)
         for m in (a, b):
             m.train(corpus, 0, 1000, walk_index_base=0, total_walks=len(walks))
-        before = (a.vectors()[0].copy(), a.syn1neg().copy(), a.stats())
+        before = (a.vectors()[0].copy(), a.syn1neg().copy(), a.stats(), a.syn1().copy() if hs else None)
         ms0, ms1, moved = a.tune_placement(corpus, 1000, 1500, candidates=3)
-        assert ms0 > 0 and 0 < ms1 <= ms0 and 0 <= moved <= 8
-        after = (a.vectors()[0], a.syn1neg(), a.stats())
+        assert ms0 > 0 and 0 < ms1 <= ms0 and 0 <= moved <= 12
+        after = (a.vectors()[0], a.syn1neg(), a.stats(), a.syn1() if hs else None)
         assert np.array_equal(bits(before[0]), bits(after[0])) and np.array_equal(bits(before[1]), bits(after[1]))
+        assert not hs or np.array_equal(bits(before[3]), bits(after[3]))
         assert before[2]["pairs"] == after[2]["pairs"] and before[2]["words"] == after[2]["words"] and before[2]["launches"] == after[2]["launches"]
         assert np.array_equal(a.table(), b.table())
         if workers == 1:          # the in-order schedule is deterministic: the tuned model goes on exactly like the untuned one
@@ -680,3 +681,21 @@ def test_placement_search_leaves_the_model_as_it_was(dge, oracle):
                 m.train(corpus, 1000, 2000, walk_index_base=1000, total_walks=len(walks))
             assert np.array_equal(bits(a.vectors()[0]), bits(b.vectors()[0])) and np.array_equal(bits(a.syn1neg()), bits(b.syn1neg()))
             assert a.stats()["pairs"] == b.stats()["pairs"]
+
+
+def test_one_shot_fit_runs_the_placement_search_on_large_models(dge):
+    """dge_train_sgns_device (w2v.fit()) calls the placement search itself when vocabulary and corpus are large enough for it to pay; the
+    search's probe launches must leave no trace: the pair and word counts are those of create + train on the same corpus."""
+    import torch
+    NV, L, n = 300_000, 8, 300_000
+    g = torch.Generator(device="cuda:0"); g.manual_seed(7)
+    walks = torch.randint(0, NV, (n, L), generator=g, device="cuda:0", dtype=torch.int32).cpu().numpy()
+    corpus = dge.WalkCorpus.from_host(walks, 0)
+    cfg = dge.make_config(64, L, NV, workers=0, min_count=1, table_size=1_000_003)
+    a = dge.SgnsModel.fit(corpus, cfg, 0)
+    counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0"); corpus.count_tokens(NV, counts)
+    b = dge.SgnsModel.create(cfg, counts, 0); b.train(corpus)
+    sa, sb = a.stats(), b.stats()
+    assert len(a.vectors()[1]) >= 262144                                   # large enough for the search to have run
+    assert sa["pairs"] == sb["pairs"] and sa["words"] == sb["words"] == int(counts.sum().item()) and sa["launches"] == sb["launches"] == 1
+    assert np.isfinite(a.vectors()[0]).all() and a.schedule()["update_policy"] == b.schedule()["update_policy"]
