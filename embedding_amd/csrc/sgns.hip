@@ -1050,9 +1050,10 @@ extern "C" int dge_model_tune_placement(dge_model* m, const dge_walks* w, int64_
     struct Slot { void** p; size_t bytes; };
     Slot slots[4] = {{(void**)&m->d_ctab, ctab_bytes}, {(void**)&m->d_locks, lock_bytes}, {(void**)&m->d_syn1neg, tab_bytes}, {(void**)&m->d_syn0, tab_bytes}};
     // A pass tries every array in up to candidates - 1 other allocations.  A pass that found nothing ends the search (a model that started
-    // well costs one pass); one that did means the model started badly, and arrays it left alone may still be badly placed: up to three passes
-    // (one box in three needed the second: 119.4 -> 115.7 ms after one pass, 447.8 ms per launch where its neighbours ran 414).
-    for (int pass = 0; pass < 3 && rc == DGE_OK; pass++) {
+    // well costs one pass); one that did means the model started badly, and arrays it left alone may still be badly placed: passes go on while
+    // they find something, at most six (a single pass left one process in three at 119.4 -> 115.7 ms: 447.8 ms per launch where its neighbours ran
+    // 414; at most three passes left one in six at 112.4: 434.5; profiles/r03_bench_repeat_search.txt).
+    for (int pass = 0; pass < 6 && rc == DGE_OK; pass++) {
         const int moved_before = moved;
         for (int a = 0; a < 4 && rc == DGE_OK; a++)
             for (int c = 1; c < candidates && rc == DGE_OK; c++) {

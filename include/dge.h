@@ -232,8 +232,8 @@ int  dge_model_reset_stats(dge_model* m);
 /* Placement search (profiles/r03_placement.txt): which physical memory the allocator handed each of the model's large arrays decides a launch's
    duration by up to 15 %, array by array, under no rule that could be asked for.  Trains rows [row0, row0 + n_rows) of w as a probe; then for
    the negative-sampling table, the lock words, syn1neg and syn0 in turn up to candidates - 1 copies in fresh memory are tried and the faster
-   placement kept.  Tables, counters and statistics are saved before and restored after: the model trains exactly as an untuned one.  Costs
-   (1 + 4 (candidates - 1)) probe launches and transiently 2 x the tables' memory.  ms_before / ms_after: probe launch before and after (may be NULL). */
+   placement kept.  Tables, counters and statistics are saved before and restored after: the model trains exactly as an untuned one.  The arrays are gone
+   through in passes until a pass moves nothing (at most six): 2 + 4 (candidates - 1) probe launches per pass, transiently 2 x the tables' memory.  ms_before / ms_after: probe launch before and after (may be NULL). */
 int  dge_model_tune_placement(dge_model* m, const dge_walks* w, int64_t row0, int64_t n_rows, int32_t candidates, double* ms_before, double* ms_after,
                               int32_t* arrays_moved);
 /* what the latest training launch resolved `update_policy` 0 / `workers` 0 to: the policy that ran (0 = in-order plain),
