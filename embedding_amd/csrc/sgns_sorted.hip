@@ -208,6 +208,14 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
     uint64_t mA = 1, cA = 0;
     for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
     const int K = p.K;
+    // K <= 16: a TRIP takes up to P = 16 / K pairs of the centre at once — lane l = z * K + d draws negative d of the trip's pair z, lanes
+    // 0 .. pairs - 1 write the positives: one round of table look-ups and four store instructions per trip instead of four per pair.
+    // Streams: one stream per centre (lane l stands l + 1 steps behind the trip's start, the next trip starts where lane pairs * K - 1 stood);
+    // under the block schedule one stream per pair (lane l stands d + 1 steps behind its pair's start).
+    const int P = K == 0 ? 16 : max(1, 16 / max(K, 1));
+    const int z_l = K ? lane / K : lane, d_l = K ? lane - z_l * K : 0;
+    uint64_t mD = 1, cD = 0;
+    for (int j = 0; j <= d_l; j++) { mD *= DGE_W2V_MULT; cD = cD * DGE_W2V_MULT + 11; }
     while (todo) {
         const int ul = __builtin_ctz(todo); todo &= todo - 1;
         const int64_t u = u0 + ul;
@@ -226,53 +234,49 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
             if (cj <= hi && cj != i) { tok = sen[cj]; if (p.part_n > 1 && tok % p.part_n != p.part_ctx) tok = -1; }
             unsigned live = (unsigned)(__ballot(tok >= 0) >> sh) & 0xFFFFu;
             while (live) {
-                // up to 4 pairs per trip: their table look-ups are in flight together
-                int32_t lastv[4], tv[4]; int npair = 0;
-#pragma unroll
-                for (int z = 0; z < 4; z++) {
-                    lastv[z] = -1; tv[z] = -1;
-                    if (live) {
+                if (K <= 16) {
+                    const int npair = min(P, __popc(live));
+                    int cl_mine = 0, cl_pos = 0;                 // candidate lane of the pair my negative belongs to / of pair `lane`
+                    for (int z = 0; z < npair; z++) {
                         const int cl = __builtin_ctz(live); live &= live - 1;
-                        lastv[z] = __shfl(tok, cl, 16);
-                        if (p.part_n > 1) s = dge_mix64(s_centre + (uint64_t)(c0 + cl));     // block schedule: every pair draws from its own stream
-                        if (K <= 16) {                                                    // (more negatives than lanes: one pair per trip, below)
-                            const uint64_t sl = s * mA + cA;
-                            if (lane < K) {
-                                int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
-                                if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
-                                tv[z] = t;
-                            }
-                            if (K > 0) s = shfl16_u64(sl, K - 1);
-                        }
-                        npair = z + 1;
-                        if (K > 16) break;
+                        if (z == z_l) cl_mine = cl;
+                        if (z == lane) cl_pos = cl;
                     }
-                }
-#pragma unroll
-                for (int z = 0; z < 4; z++) {
-                    if (z >= npair) break;
-                    const uint64_t hi32 = (uint64_t)(uint32_t)lastv[z] << 32;
+                    const int32_t last_mine = __shfl(tok, cl_mine, 16), last_pos = __shfl(tok, cl_pos, 16);
+                    const bool neg_on = K > 0 && lane < npair * K;
+                    const uint64_t sl = p.part_n > 1 ? dge_mix64(s_centre + (uint64_t)(c0 + cl_mine)) * mD + cD : s * mA + cA;
+                    if (neg_on) {
+                        int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                        if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                        if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
+                        const int64_t at = slot + (int64_t)z_l * (K + 1) + 1 + d_l;
+                        q.key_out[at] = t == word ? q.Vk : t / q.kdiv;
+                        q.val_out[at] = ((uint64_t)(uint32_t)last_mine << 32) | (uint64_t)__float_as_uint(-alpha);      // label 0: the sign bit
+                    }
+                    if (lane < npair) {
+                        const int64_t at = slot + (int64_t)lane * (K + 1);
+                        q.key_out[at] = word / q.kdiv;
+                        q.val_out[at] = ((uint64_t)(uint32_t)last_pos << 32) | (uint64_t)__float_as_uint(alpha);
+                    }
+                    if (K > 0 && p.part_n <= 1) s = shfl16_u64(sl, npair * K - 1);
+                    slot += (int64_t)npair * (K + 1);
+                } else {                                         // more negatives than lanes: one pair per trip, 16 draws at a time
+                    const int cl = __builtin_ctz(live); live &= live - 1;
+                    const int32_t lastv = __shfl(tok, cl, 16);
+                    if (p.part_n > 1) s = dge_mix64(s_centre + (uint64_t)(c0 + cl));
+                    const uint64_t hi32 = (uint64_t)(uint32_t)lastv << 32;
                     if (lane == 0) { q.key_out[slot] = word / q.kdiv; q.val_out[slot] = hi32 | (uint64_t)__float_as_uint(alpha); }
-                    if (K <= 16) {
-                        if (lane < K) {
-                            int32_t t = tv[z];
+                    for (int kd = 0; kd < K; kd += 16) {
+                        const int kc = min(16, K - kd);
+                        const uint64_t sl = s * mA + cA;
+                        if (lane < kc) {
+                            int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                            if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                             if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
-                            q.key_out[slot + 1 + lane] = t == word ? q.Vk : t / q.kdiv;
-                            q.val_out[slot + 1 + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);      // label 0: the sign bit
+                            q.key_out[slot + 1 + kd + lane] = t == word ? q.Vk : t / q.kdiv;
+                            q.val_out[slot + 1 + kd + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);
                         }
-                    } else {
-                        for (int kd = 0; kd < K; kd += 16) {
-                            const int kc = min(16, K - kd);
-                            const uint64_t sl = s * mA + cA;
-                            if (lane < kc) {
-                                int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
-                                if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
-                                if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
-                                q.key_out[slot + 1 + kd + lane] = t == word ? q.Vk : t / q.kdiv;
-                                q.val_out[slot + 1 + kd + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);
-                            }
-                            s = shfl16_u64(sl, kc - 1);
-                        }
+                        s = shfl16_u64(sl, kc - 1);
                     }
                     slot += K + 1;
                 }
@@ -337,6 +341,15 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
     int64_t my_pos = lane < N ? cell_off[(int64_t)lane * p.n_rows + w] : 0;
     uint64_t mA = 1, cA = 0;
     for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
+    // K <= 16: up to P = 16 / K pairs of a centre per trip (k_sorted_emit): lane l = z * K + d draws negative d of the trip's pair z from that
+    // pair's own stream, lanes 0 .. pairs - 1 write the positives
+    const int P = K == 0 ? 16 : max(1, 16 / max(K, 1));
+    const int z_l = K ? lane / K : lane, d_l = K ? lane - z_l * K : 0;
+    uint64_t mD = 1, cD = 0;
+    for (int j = 0; j <= d_l; j++) { mD *= DGE_W2V_MULT; cD = cD * DGE_W2V_MULT + 11; }
+    // token at walk position c, c different in every lane: lane c & 15 holds it in register c >> 4
+#define BLOCK_TOK(c_) ({ const int c__ = (c_); const int32_t a0 = __shfl(tk0, c__ & 15, 16), a1 = __shfl(tk1, c__ & 15, 16), a2 = __shfl(tk2, c__ & 15, 16), a3 = __shfl(tk3, c__ & 15, 16); \
+                         (c__ >> 4) == 0 ? a0 : ((c__ >> 4) == 1 ? a1 : ((c__ >> 4) == 2 ? a2 : a3)); })
     for (int i = 0; i < len; i++) {
         uint64_t s; int lo, hi;
         unit_window(p, w, i, len, s, lo, hi);
@@ -350,59 +363,56 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
         const int np = __popcll(pm);
         if (lane == bucket) my_pos += np;
         while (pm) {
-            // up to 4 pairs per trip: their table look-ups are in flight together
-            int32_t lastv[4], tv[4]; int cpos[4]; int npair = 0;
-#pragma unroll
-            for (int z = 0; z < 4; z++) {
-                lastv[z] = -1; tv[z] = -1; cpos[z] = 0;
-                if (pm) {
+            if (K <= 16) {
+                const int npair = min(P, __popcll(pm));
+                int c_mine = 0, c_pos = 0;                   // context position of the pair my negative belongs to / of pair `lane`
+                for (int z = 0; z < npair; z++) {
                     const int c = __builtin_ctzll(pm); pm &= pm - 1ull;
-                    cpos[z] = c;
-                    lastv[z] = walk_tok(true, sen, c, tk0, tk1, tk2, tk3);
-                    if (K <= 16) {
-                        const uint64_t sl = dge_mix64(s_centre + (uint64_t)c) * mA + cA;       // every pair draws from its own stream
-                        if (lane < K) {
-                            int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
-                            if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
-                            tv[z] = t;
-                        }
-                    }
-                    npair = z + 1;
-                    if (K > 16) break;
+                    if (z == z_l) c_mine = c;
+                    if (z == lane) c_pos = c;
                 }
-            }
-#pragma unroll
-            for (int z = 0; z < 4; z++) {
-                if (z >= npair) break;
-                const uint64_t hi32 = (uint64_t)(uint32_t)lastv[z] << 32;
+                const int32_t last_pos = BLOCK_TOK(c_pos);
+                const int32_t last_mine = __shfl(last_pos, z_l, 16);
+                if (K > 0 && lane < npair * K) {
+                    const uint64_t sl = dge_mix64(s_centre + (uint64_t)c_mine) * mD + cD;       // every pair draws from its own stream
+                    int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                    if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                    int32_t tk = dge_fast_div32(t, N, p.N_magic);              // part_row: the row of the bucket's partition nearest below the draw
+                    if ((int64_t)tk * N + bucket >= p.V) tk--;
+                    const int64_t at = slot + (int64_t)z_l * (K + 1) + 1 + d_l;
+                    key_out[at] = tk == wkey ? Vk : tk;
+                    val_out[at] = ((uint64_t)(uint32_t)last_mine << 32) | (uint64_t)__float_as_uint(-alpha);      // label 0: the sign bit
+                }
+                if (lane < npair) {
+                    const int64_t at = slot + (int64_t)lane * (K + 1);
+                    key_out[at] = wkey;
+                    val_out[at] = ((uint64_t)(uint32_t)last_pos << 32) | (uint64_t)__float_as_uint(alpha);
+                }
+                slot += (int64_t)npair * (K + 1);
+            } else {                                         // more negatives than lanes: one pair per trip, 16 draws at a time
+                const int c = __builtin_ctzll(pm); pm &= pm - 1ull;
+                const int32_t lastv = walk_tok(true, sen, c, tk0, tk1, tk2, tk3);
+                const uint64_t hi32 = (uint64_t)(uint32_t)lastv << 32;
                 if (lane == 0) { key_out[slot] = wkey; val_out[slot] = hi32 | (uint64_t)__float_as_uint(alpha); }
-                if (K <= 16) {
-                    if (lane < K) {
-                        int32_t tk = dge_fast_div32(tv[z], N, p.N_magic);              // part_row: the row of the bucket's partition nearest below the draw
+                uint64_t sp = dge_mix64(s_centre + (uint64_t)c);
+                for (int kd = 0; kd < K; kd += 16) {
+                    const int kc = min(16, K - kd);
+                    const uint64_t sl = sp * mA + cA;
+                    if (lane < kc) {
+                        int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                        if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                        int32_t tk = dge_fast_div32(t, N, p.N_magic);
                         if ((int64_t)tk * N + bucket >= p.V) tk--;
-                        key_out[slot + 1 + lane] = tk == wkey ? Vk : tk;
-                        val_out[slot + 1 + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);      // label 0: the sign bit
+                        key_out[slot + 1 + kd + lane] = tk == wkey ? Vk : tk;
+                        val_out[slot + 1 + kd + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);
                     }
-                } else {
-                    uint64_t sp = dge_mix64(s_centre + (uint64_t)cpos[z]);
-                    for (int kd = 0; kd < K; kd += 16) {
-                        const int kc = min(16, K - kd);
-                        const uint64_t sl = sp * mA + cA;
-                        if (lane < kc) {
-                            int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
-                            if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
-                            int32_t tk = dge_fast_div32(t, N, p.N_magic);
-                            if ((int64_t)tk * N + bucket >= p.V) tk--;
-                            key_out[slot + 1 + kd + lane] = tk == wkey ? Vk : tk;
-                            val_out[slot + 1 + kd + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);
-                        }
-                        sp = shfl16_u64(sl, kc - 1);
-                    }
+                    sp = shfl16_u64(sl, kc - 1);
                 }
                 slot += K + 1;
             }
         }
     }
+#undef BLOCK_TOK
     (void)sh;
 }
 __global__ void k_block_tally(unsigned long long* counters, unsigned long long pairs, const unsigned long long* words, int add_words) {
