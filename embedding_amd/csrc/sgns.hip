@@ -124,21 +124,26 @@ __global__ void k_init_syn0(float* syn0, int64_t V, int32_t D, int32_t stride, u
 }
 
 // vertex ids -> vocabulary rows, out-of-vocabulary tokens dropped and the walk left-packed (word2vec / DL4J
-// filter the sentence before windowing); len = tokens kept
-__global__ void k_remap_compact(const int32_t* __restrict__ walks, int64_t n_rows, int32_t L, const int32_t* __restrict__ remap,
-                                int32_t NV, int32_t* __restrict__ sen, int64_t* __restrict__ len_out) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// filter the sentence before windowing); len = tokens kept.  One 16-lane group per walk: lane j takes tokens j, j + 16, ... (coalesced
+// 64-byte reads and writes; one thread per walk, every thread striding through its own row, ran 6.3 ms per 8 M walks of 24 tokens)
+__global__ void __launch_bounds__(256) k_remap_compact(const int32_t* __restrict__ walks, int64_t n_rows, int32_t L, const int32_t* __restrict__ remap,
+                                                        int32_t NV, int32_t* __restrict__ sen, int64_t* __restrict__ len_out) {
+    const int lane = threadIdx.x & 15, sh = threadIdx.x & 48;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (r >= n_rows) return;
     const int32_t* in = walks + r * L;
     int32_t* out = sen + r * L;
     int len = 0;
-    for (int j = 0; j < L; j++) {
-        int32_t t = in[j];
-        int32_t v = (t >= 0 && t < NV) ? remap[t] : -1;
-        if (v >= 0) out[len++] = v;
+    for (int j0 = 0; j0 < L; j0 += 16) {
+        const int j = j0 + lane;
+        int32_t v = -1;
+        if (j < L) { const int32_t t = in[j]; if (t >= 0 && t < NV) v = remap[t]; }
+        const unsigned keep = (unsigned)(__ballot(v >= 0) >> sh) & 0xFFFFu;
+        if (v >= 0) out[len + __popc(keep & ((1u << lane) - 1u))] = v;
+        len += __popc(keep);
     }
-    for (int j = len; j < L; j++) out[j] = -1;
-    len_out[r] = len;
+    for (int j = len + lane; j < L; j += 16) out[j] = -1;
+    if (lane == 0) len_out[r] = len;
 }
 
 // ------------------------------------------------------------------------------------------ lock protocol self-test
@@ -570,7 +575,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     // vocabulary rows of the walks, left-packed, and the words that precede each walk: kept while the same unchanged rows come again
     // (the N episodes of a block-schedule batch train the same walks N times)
     if (!(m->seen_rows == d_rows && m->seen_n == n_rows && m->seen_L == L && m->seen_gen == corpus_gen && corpus_gen != 0)) {
-        hipLaunchKernelGGL(k_remap_compact, dim3(grid_for(n_rows, 256)), dim3(256), 0, st, d_rows, n_rows, L, m->d_remap, m->NV, m->d_sen, m->d_len);
+        hipLaunchKernelGGL(k_remap_compact, dim3(grid_for(n_rows * 16, 256)), dim3(256), 0, st, d_rows, n_rows, L, m->d_remap, m->NV, m->d_sen, m->d_len);
         size_t bytes = m->scan_tmp_bytes;
         DGE_HIP(hipcub::DeviceScan::ExclusiveSum(m->d_scan_tmp, bytes, m->d_len, m->d_wb, n_rows, st));
         m->seen_rows = d_rows; m->seen_n = n_rows; m->seen_L = L; m->seen_gen = corpus_gen;
