@@ -30,7 +30,7 @@
 #include "sgns_model.h"
 
 
-int64_t g_dge_tuning[DGE_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;

@@ -1,6 +1,7 @@
 // sgns_model.h — the trainer's handle (vocabulary + tables + per-call work buffers), shared by sgns.hip (host side of the C ABI)
 // and sgns_sorted.hip (the owner-computes schedule).
 #pragma once
+#include <atomic>
 #include <vector>
 
 #include "dge_internal.h"
@@ -8,7 +9,7 @@
 struct EventPair { hipEvent_t a, b; int kind; };
 
 // ablation / test knobs (dge_set_tuning, include/dge.h): -1 = the library's own rule
-extern int64_t g_dge_tuning[DGE_TUNE_COUNT];
+extern std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT];      // (set from the host's thread, read by whichever thread launches: relaxed atomics, no ordering implied)
 
 struct dge_sorted_work;       // buffers of the owner-computes schedule (sgns_sorted.hip)
 

@@ -304,7 +304,7 @@ int  dge_ndcg_at_k(int device, const float* features, int32_t dim, const float* 
                    double* ndcg, double* ms_kernels);
 
 /* ------------------------------------------------------------------------------------------------
- * Ablation / test knobs of the trainer (process-wide, not thread-safe; nothing in a normal run sets them).  value < 0 puts
+ * Ablation / test knobs of the trainer (process-wide relaxed atomics; nothing in a normal run sets them).  value < 0 puts
  * a knob back to the library's own rule.
  * ---------------------------------------------------------------------------------------------- */
 enum {
