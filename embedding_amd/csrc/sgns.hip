@@ -1008,9 +1008,12 @@ extern "C" int dge_model_row_rates(dge_model* m, double* read_gb_per_s, double* 
 // Rejected placements are only freed at the end (the allocator would hand the same memory out again).  The tables' contents and the
 // model's counters are saved first and restored last: training results are exactly those of an untuned model.
 static int tune_time_launch(dge_model* m, const dge_walks* w, int64_t row0, int64_t n_rows, double* ms) {
-    hipEvent_t a, b;
-    DGE_HIP(hipEventCreate(&a)); DGE_HIP(hipEventCreate(&b));
-    DGE_HIP(hipEventRecord(a, m->stream));
+    hipEvent_t a = nullptr, b = nullptr;
+    DGE_HIP(hipEventCreate(&a));
+    if (hipEventCreate(&b) != hipSuccess || hipEventRecord(a, m->stream) != hipSuccess) {
+        (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b);
+        DGE_FAIL(DGE_ERR_DEVICE, "dge_model_tune_placement: cannot time the probe launch");
+    }
     int rc = train_rows(m, w->d + row0 * w->L, n_rows, w->L, 0, 0, 0, 1.0, std::max<int64_t>(w->n, 1), w->gen);
     if (rc == DGE_OK) {
         if (hipEventRecord(b, m->stream) != hipSuccess || hipEventSynchronize(b) != hipSuccess) { dge_set_error("dge_model_tune_placement: the probe launch failed"); rc = DGE_ERR_DEVICE; }
