@@ -82,6 +82,7 @@ class RingTransport:
         ctrl = None
         if d.get_backend() == "nccl":
             ctrl = d.new_group(backend="gloo")             # (collective: every rank creates it)
+        d.barrier(group=ctrl)                              # the time box below starts on every rank together (ranks arrive from set-up work of different length)
         ok, why = 1, ""
         try:
             staged = str(device).startswith("cuda") and d.get_backend() != "nccl"
