@@ -42,6 +42,110 @@ extern "C" int dge_get_tuning(int32_t knob, int64_t* value) {
     return DGE_OK;
 }
 
+// ------------------------------------------------------------------------------------------ where the tables lie
+// Which memory a table of random rows lies in decides how fast rows can be read AND WRITTEN BACK in it: allocations of half a gigabyte fall into
+// two classes 15 % apart (a microbenchmark of random 512-byte rows read and stored back reaches 6.3 or 7.3 TB/s on them, nothing in between),
+// a launch of the lock kernel takes 412-415 ms with both tables in fast memory and 473-479 ms with both in slow memory, and no property of
+// the allocation visible from user space tells the classes apart (profiles/r03_placement.txt: not contiguity, alignment, page-table fragments,
+// position or the neighbours) — but a 2-millisecond probe does.  So a table is the best of several virtual-memory allocations under that
+// probe: candidates are created one after the other (all held, or the allocator would hand the same memory out again) until the fast class has
+// shown (the best at least 14 % above the worst: probe rates come in three levels, ~4150 / ~4620 / ~4810 GB/s) or TABLE_CANDIDATES have been seen;
+// the best stays.  Fast memory is 1 allocation in 2 ... 6 on
+// most boxes.  Virtual-memory allocations because hipMalloc's come from one class only on some boxes.
+#define TABLE_CANDIDATES 24
+typedef unsigned int pv4u __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_probe_table(char* base, uint64_t rows, int iters, float* sink) {
+    const int lane = threadIdx.x & 15;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    uint64_t s = 0x9E3779B97F4A7C15ull * (group + 1);
+    float acc = 0.f;
+    for (int i = 0; i < iters; i += 8) {
+        pv4u v[8][2]; char* pp[8];
+#pragma unroll
+        for (int z = 0; z < 8; z++) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            pp[z] = base + ((s >> 20) % rows) * 512u + (uint32_t)lane * 16u;
+            v[z][0] = __builtin_nontemporal_load((pv4u*)pp[z]); v[z][1] = __builtin_nontemporal_load((pv4u*)(pp[z] + 256));
+        }
+#pragma unroll
+        for (int z = 0; z < 8; z++) {
+            acc += __uint_as_float(v[z][0].x ^ v[z][1].y);
+            __hip_atomic_store((unsigned*)pp[z], v[z][0].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              // the same bytes back, write-through
+            __hip_atomic_store((unsigned*)(pp[z] + 256), v[z][1].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+struct VmAlloc { size_t bytes; hipMemGenericAllocationHandle_t h; };
+static std::map<void*, VmAlloc> g_vm_allocs;
+static std::mutex g_vm_mu;
+static int vm_alloc(void** out, size_t bytes, int device) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+    const size_t g = (size_t)2 << 20, sz = (bytes + g - 1) / g * g;
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, sz, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return DGE_ERR_DEVICE; }
+    void* va = nullptr;
+    if (hipMemAddressReserve(&va, sz, g, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return DGE_ERR_DEVICE; }
+    hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemMap(va, sz, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemAddressFree(va, sz); (void)hipMemRelease(h); return DGE_ERR_DEVICE; }
+    if (hipMemSetAccess(va, sz, &acc, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap(va, sz); (void)hipMemAddressFree(va, sz); (void)hipMemRelease(h); return DGE_ERR_DEVICE; }
+    { std::lock_guard<std::mutex> lk(g_vm_mu); g_vm_allocs[va] = VmAlloc{sz, h}; }
+    *out = va;
+    return DGE_OK;
+}
+// frees what table_alloc (or hipMalloc) returned
+static void table_free(void* p) {
+    if (!p) return;
+    VmAlloc a{0, {}};
+    { std::lock_guard<std::mutex> lk(g_vm_mu); auto it = g_vm_allocs.find(p); if (it != g_vm_allocs.end()) { a = it->second; g_vm_allocs.erase(it); } }
+    if (a.bytes) { (void)hipMemUnmap(p, a.bytes); (void)hipMemRelease(a.h); (void)hipMemAddressFree(p, a.bytes); }
+    else (void)hipFree(p);
+}
+static int table_alloc(float** out, size_t floats, int device, hipStream_t st, int* seen, double* rate_best, double* rate_worst) {
+    *out = nullptr;
+    const size_t bytes = floats * sizeof(float);
+    if (seen) *seen = 0;
+    // small tables live in the caches: nothing to choose (and the probe needs rows to draw from)
+    size_t free_b = 0, total_b = 0;
+    if (bytes < ((size_t)64 << 20) || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return dge_dev_alloc(out, floats);
+    const int n_max = (int)std::max<size_t>(1, std::min<size_t>(TABLE_CANDIDATES, free_b / 4 / bytes));      // candidates may take a quarter of the free memory
+    dge_tmp<float> sink;
+    int rc = sink.alloc(4);
+    if (rc) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); (void)hipGetLastError(); return dge_dev_alloc(out, floats); }
+    std::vector<void*> cand; std::vector<double> rate;
+    double best = 0, worst = 1e30;
+    for (int k = 0; k < n_max; k++) {
+        void* q = nullptr;
+        if (vm_alloc(&q, bytes, device) != DGE_OK) break;                      // (the virtual-memory API refused, or memory ran out: what we have, or hipMalloc below)
+        double r = 0;
+        bool ok = hipMemsetAsync(q, 0, bytes, st) == hipSuccess;
+        for (int rep = 0; rep < 3 && ok; rep++) {
+            ok = hipEventRecord(e0, st) == hipSuccess;
+            hipLaunchKernelGGL(k_probe_table, dim3(4096), dim3(256), 0, st, (char*)q, (uint64_t)(bytes / 512), 64, sink.p);
+            ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+            float ms = 0.f;
+            if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0) r = std::max(r, 65536.0 * 64 * 1024.0 / (ms * 1e-3) / 1e9);
+        }
+        if (!ok) { (void)hipGetLastError(); table_free(q); break; }
+        cand.push_back(q); rate.push_back(r);
+        best = std::max(best, r); worst = std::min(worst, r);
+        if (cand.size() >= 2 && best >= 1.14 * worst) break;                   // the fast class has shown (an intermediate one, ~11 % above the slowest, exists too)
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (cand.empty()) return dge_dev_alloc(out, floats);
+    size_t pick = 0;
+    for (size_t k = 1; k < cand.size(); k++) if (rate[k] > rate[pick]) pick = k;
+    for (size_t k = 0; k < cand.size(); k++) if (k != pick) table_free(cand[k]);
+    *out = (float*)cand[pick];
+    if (seen) *seen = (int)cand.size();
+    if (rate_best) *rate_best = best;
+    if (rate_worst) *rate_worst = worst;
+    return DGE_OK;
+}
+
 // ------------------------------------------------------------------------------------------ vocabulary
 __global__ void k_count_tokens(const int32_t* __restrict__ walks, int64_t n, int32_t NV, unsigned long long* counts) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -315,9 +419,9 @@ extern "C" int dge_count_tokens(const dge_walks* w, int64_t row0, int64_t n_rows
 }
 
 static void model_release(dge_model* m) {
-    dge_dev_free(m->d_syn0); dge_dev_free(m->d_syn1neg); dge_dev_free(m->d_locks); dge_dev_free(m->d_ctab);
+    table_free(m->d_syn0); table_free(m->d_syn1neg); dge_dev_free(m->d_locks); dge_dev_free(m->d_ctab);
     dge_dev_free(m->d_snap); dge_dev_free(m->d_vocab_ids);
-    dge_dev_free(m->d_syn1); dge_dev_free(m->d_hs_off); dge_dev_free(m->d_hs_points); dge_dev_free(m->d_hs_codes);
+    table_free(m->d_syn1); dge_dev_free(m->d_hs_off); dge_dev_free(m->d_hs_points); dge_dev_free(m->d_hs_codes);
     dge_dev_free(m->d_counts); dge_dev_free(m->d_remap); dge_dev_free(m->d_exp);
     dge_dev_free(m->d_sen); dge_dev_free(m->d_len); dge_dev_free(m->d_wb); dge_dev_free(m->d_scan_tmp); dge_dev_free(m->d_counters);
     dge_sorted_release(m);
@@ -395,7 +499,8 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     // the two tables and their lock words first: before the unigram table and the 0.8 GB of temporaries its construction takes
     const size_t tab = (size_t)V * (size_t)m->stride;
     m->ctab_blocks = (m->T + DGE_CTAB_SLOTS - 1) / DGE_CTAB_SLOTS;
-    MC(dge_dev_alloc(&m->d_syn0, tab + 64)); MC(dge_dev_alloc(&m->d_syn1neg, tab + 64));
+    MC(table_alloc(&m->d_syn0, tab + 64, device, st, &m->placed_seen[0], &m->placed_best[0], &m->placed_worst[0]));
+    MC(table_alloc(&m->d_syn1neg, tab + 64, device, st, &m->placed_seen[1], &m->placed_best[1], &m->placed_worst[1]));
     MC(dge_dev_alloc(&m->d_locks, 2 * ((size_t)V + 1)));      // [0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows
     MC(dge_dev_alloc(&m->d_ctab, (size_t)m->ctab_blocks + 1));
     MC(dge_dev_alloc(&m->d_vocab_ids, (size_t)V)); MC(dge_dev_alloc(&m->d_counts, (size_t)V)); MC(dge_dev_alloc(&m->d_remap, (size_t)NV));
@@ -490,7 +595,7 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         { int64_t tot = 0; for (int64_t c : m->h_counts) tot += c;
           const int64_t limit = (int64_t)((double)tot * 2e-5);
           m->hs_cold_auto = (int32_t)(std::upper_bound(node_w.begin(), node_w.end(), limit) - node_w.begin()); }
-        MC(dge_dev_alloc(&m->d_syn1, tab + 64));
+        MC(table_alloc(&m->d_syn1, tab + 64, device, st, &m->placed_seen[2], &m->placed_best[2], &m->placed_worst[2]));
         MH(hipMemsetAsync(m->d_syn1, 0, (tab + 64) * sizeof(float), st));
         if (longest > 40) { model_release(m); delete m; DGE_FAIL(DGE_ERR_ARG, "dge_model_create: a Huffman code of %d bits exceeds word2vec's MAX_CODE_LENGTH 40", longest); }
         MC(dge_dev_alloc(&m->d_hs_off, (size_t)V + 1)); MC(dge_dev_alloc(&m->d_hs_points, m->h_hs_points.size())); MC(dge_dev_alloc(&m->d_hs_codes, (size_t)V));
@@ -1078,7 +1183,7 @@ extern "C" int dge_model_tune_placement(dge_model* m, const dge_walks* w, int64_
         if (moved == moved_before) break;
     }
     hipError_t e = hipStreamSynchronize(st);
-    for (void* g : graveyard) (void)hipFree(g);
+    for (void* g : graveyard) table_free(g);                  // (a table that came from table_alloc is a virtual-memory allocation)
     if (rc == DGE_OK && e != hipSuccess) { dge_set_error("dge_model_tune_placement: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; }
     // put everything back as it was before the probes
     DGE_HIP(hipMemcpyAsync(m->d_syn0, keep0.p, tab_bytes, hipMemcpyDeviceToDevice, st));
@@ -1094,6 +1199,14 @@ extern "C" int dge_model_tune_placement(dge_model* m, const dge_walks* w, int64_
     if (rc == DGE_OK) rc = rc2;
     if (ms_before) *ms_before = first; if (ms_after) *ms_after = best; if (arrays_moved) *arrays_moved = moved;
     return rc;
+}
+
+extern "C" int dge_model_table_placement(const dge_model* m, int32_t table, int32_t* candidates, double* best_gb_per_s, double* worst_gb_per_s) {
+    if (!m || table < 0 || table > 2) DGE_FAIL(DGE_ERR_ARG, "dge_model_table_placement: table is 0 (syn0), 1 (syn1neg) or 2 (syn1)");
+    if (candidates) *candidates = m->placed_seen[table];
+    if (best_gb_per_s) *best_gb_per_s = m->placed_best[table];
+    if (worst_gb_per_s) *worst_gb_per_s = m->placed_worst[table];
+    return DGE_OK;
 }
 
 extern "C" int dge_model_schedule(const dge_model* m, int32_t* update_policy, int64_t* workers, int32_t* hot_rows) {

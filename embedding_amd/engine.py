@@ -320,6 +320,16 @@ class SgnsModel:
         v = [C.c_double(0) for _ in range(4)]
         check(lib.dge_model_row_rates(self._h, *[C.byref(x) for x in v])); return tuple(x.value for x in v)
 
+    def table_placement(self):
+        """What dge_model_create's probe-selected table allocation saw: [(candidates probed, best GB/s = the one kept, worst GB/s)] for syn0, syn1neg
+        (and syn1 under hierarchical softmax)."""
+        out = []
+        for t in range(3 if self.cfg.use_hs else 2):
+            n, a, b = C.c_int32(0), C.c_double(0), C.c_double(0)
+            check(lib.dge_model_table_placement(self._h, t, C.byref(n), C.byref(a), C.byref(b)))
+            out.append((n.value, round(a.value), round(b.value)))
+        return out
+
     def tune_placement(self, corpus, row0=0, n_rows=None, candidates=3):
         """Placement search (include/dge.h: dge_model_tune_placement): -> (probe ms before, probe ms after, arrays moved).  The model's tables,
         counters and statistics are as before the call."""

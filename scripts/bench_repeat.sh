@@ -8,6 +8,6 @@ import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
         o=json.loads(l); r=o['roofline']; c=o['config']
-        print('run $i: %.3e edges/s  frac %.3f  %.1f ms/launch  step %.1f ms  search %s  trials %s  copy %.0f GB/s' % (o['value'], r['frac'], r['ms_per_launch'], o['ms_per_step'], c.get('placement_search'), c.get('placement_trial_ms'), r['box_copy_GBps'] or 0), flush=True)
+        print('run $i: %.3e edges/s  frac %.3f  %.1f ms/launch  step %.1f ms  tables %s  search %s  copy %.0f GB/s' % (o['value'], r['frac'], r['ms_per_launch'], o['ms_per_step'], c.get('table_placement'), c.get('placement_search'), r['box_copy_GBps'] or 0), flush=True)
 "
 done
