@@ -51,7 +51,7 @@ extern "C" int dge_get_tuning(int32_t knob, int64_t* value) {
 // probe: candidates are created one after the other (all held, or the allocator would hand the same memory out again) until the fast class has
 // shown (the best at least 14 % above the worst: probe rates come in three levels, ~4150 / ~4620 / ~4810 GB/s) or TABLE_CANDIDATES have been seen;
 // the best stays.  Fast memory is 1 allocation in 2 ... 6 on most boxes; candidates are hipMalloc and virtual-memory allocations in turn.
-#define TABLE_CANDIDATES 24
+#define TABLE_CANDIDATES 32
 typedef unsigned int pv4u __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_probe_table(char* base, uint64_t rows, int iters, float* sink) {
     const int lane = threadIdx.x & 15;
@@ -422,11 +422,7 @@ extern "C" int dge_count_tokens(const dge_walks* w, int64_t row0, int64_t n_rows
 }
 
 static void model_release(dge_model* m) {
-    table_free(m->d_syn0);
-    if (m->d_syn1neg != m->d_block1) table_free(m->d_syn1neg);      // (moved out of the shared block by the placement search)
-    if (!m->locks_interior) dge_dev_free(m->d_locks);
-    if (!m->ctab_interior) dge_dev_free(m->d_ctab);
-    table_free(m->d_block1);
+    table_free(m->d_syn0); table_free(m->d_syn1neg); dge_dev_free(m->d_locks); dge_dev_free(m->d_ctab);
     dge_dev_free(m->d_snap); dge_dev_free(m->d_vocab_ids);
     table_free(m->d_syn1); dge_dev_free(m->d_hs_off); dge_dev_free(m->d_hs_points); dge_dev_free(m->d_hs_codes);
     dge_dev_free(m->d_counts); dge_dev_free(m->d_remap); dge_dev_free(m->d_exp);
@@ -506,19 +502,14 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
     // the two tables and their lock words first: before the unigram table and the 0.8 GB of temporaries its construction takes
     const size_t tab = (size_t)V * (size_t)m->stride;
     m->ctab_blocks = (m->T + DGE_CTAB_SLOTS - 1) / DGE_CTAB_SLOTS;
+    // syn1neg first: fast memory is scarce on some boxes, and a pair touches K + 1 rows of syn1neg for one of syn0 (syn1neg in fast memory and syn0 in slow:
+    // 415 ms per launch; the other way round 423-456).  The lock words and the negative-sampling table are too small for the probe to classify (cache resident
+    // when probed alone) and do NOT share a table's allocation: a table with them appended (511 MiB instead of 487) never landed in fast memory in 32 tries,
+    // on any of three boxes — allocations of 511 ... 520 MiB never do (scripts/micro/size_class.hip) — so their placement is left to dge_model_tune_placement.
+    MC(table_alloc(&m->d_syn1neg, tab + 64, device, st, &m->placed_seen[1], &m->placed_best[1], &m->placed_worst[1]));
     MC(table_alloc(&m->d_syn0, tab + 64, device, st, &m->placed_seen[0], &m->placed_best[0], &m->placed_worst[0]));
-    {   // syn1neg, the lock words ([0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows) and the negative-sampling table share ONE probe-selected allocation: the two
-        // small arrays are too small to be classified by the probe themselves (they are cache resident when probed alone), yet a launch is 10 % slower
-        // with either of them in slow memory (table_alloc: both tables in fast memory and the small arrays wherever hipMalloc put them: 412-422 ms in
-        // four processes, 458-461 in two; small arrays inside the fast block: 408-425 in eight)
-        auto up = [](size_t b) { return (b + 4095) / 4096 * 4096; };
-        const size_t b1 = up((tab + 64) * sizeof(float)), b2 = up(2 * ((size_t)V + 1) * sizeof(int)), b3 = up(((size_t)m->ctab_blocks + 1) * sizeof(uint4));
-        float* base = nullptr;
-        MC(table_alloc(&base, (b1 + b2 + b3) / sizeof(float), device, st, &m->placed_seen[1], &m->placed_best[1], &m->placed_worst[1]));
-        m->d_block1 = base; m->d_syn1neg = base;
-        m->d_locks = (int*)((char*)base + b1); m->locks_interior = true;
-        m->d_ctab = (uint4*)((char*)base + b1 + b2); m->ctab_interior = true;
-    }
+    MC(dge_dev_alloc(&m->d_locks, 2 * ((size_t)V + 1)));      // [0,V]: syn1neg rows, [V+1,2V+1]: syn0 rows
+    MC(dge_dev_alloc(&m->d_ctab, (size_t)m->ctab_blocks + 1));
     MC(dge_dev_alloc(&m->d_vocab_ids, (size_t)V)); MC(dge_dev_alloc(&m->d_counts, (size_t)V)); MC(dge_dev_alloc(&m->d_remap, (size_t)NV));
     if (V) {
         MH(hipMemcpyAsync(m->d_vocab_ids, d_ids_sorted.p, V * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -1193,14 +1184,7 @@ extern "C" int dge_model_tune_placement(dge_model* m, const dge_walks* w, int64_
                 *slots[a].p = fresh;
                 double t = 0;
                 rc = tune_time_launch(m, w, row0, n_rows, &t);
-                if (rc == DGE_OK && t < best * 0.995) {      // this array is well placed now: next array
-                    best = t; moved++;
-                    // (arrays inside the shared block are not freed one by one: the block goes when the model does)
-                    if (a == 0 && m->ctab_interior) m->ctab_interior = false;
-                    else if (a == 1 && m->locks_interior) m->locks_interior = false;
-                    else if (old != (void*)m->d_block1) graveyard.push_back(old);
-                    break;
-                }
+                if (rc == DGE_OK && t < best * 0.995) { best = t; graveyard.push_back(old); moved++; break; }      // this array is well placed now: next array
                 else { *slots[a].p = old; graveyard.push_back(fresh); }
             }
         if (moved == moved_before) break;

@@ -28,7 +28,6 @@ struct dge_model {
     int64_t hot_rows_serial = 0;                // head rows whose own pairs, serialised by the row's lock, would outlast a launch
     int n_cus = 256;
     float *d_syn0 = nullptr, *d_syn1neg = nullptr, *d_snap = nullptr;
-    float* d_block1 = nullptr; bool locks_interior = false, ctab_interior = false;   // the allocation syn1neg, the lock words and the negative-sampling table share (dge_model_create)
     int placed_seen[3] = {0, 0, 0}; double placed_best[3] = {0, 0, 0}, placed_worst[3] = {0, 0, 0};   // table_alloc's report for syn0, syn1neg, syn1: candidates probed, their best and worst rate (GB/s)
     // hierarchical softmax (cfg.use_hs): inner-node table and the Huffman paths in CSR form
     float* d_syn1 = nullptr;
