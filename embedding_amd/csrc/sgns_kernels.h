@@ -622,7 +622,7 @@ k_sgns_train(TrainParams p) {
             word = DGE_TOK(i);
             s = dge_mix64(p.seed + (uint64_t)(gbase + i));
             s = s * DGE_W2V_MULT + 11;
-            const int radius = W - (int)(s % (uint64_t)W);
+            const int radius = W - (int)dge_fast_mod(s, (uint64_t)W, p.W_magic);
             c = max(0, i - radius);
             c_hi = min(len - 1, i + radius);
             if (c_hi == i) c_hi--;
@@ -711,7 +711,7 @@ k_sgns_train(TrainParams p) {
             const uint64_t sl = s * mA + cA;
             int32_t t = -1;
             if (lane < kc) {
-                t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
+                t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
                 if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                 if (PART) t = part_row(t, p.part_n, p.part_tgt, p.V);
                 if (t == word) t = -1;
@@ -1049,7 +1049,7 @@ k_sgns_train_locked(TrainParams p) {
             word = LK_TOK(i);
             s = dge_mix64(p.seed + (uint64_t)(gbase + i));
             s = s * DGE_W2V_MULT + 11;
-            const int radius = W - (int)(s % (uint64_t)W);
+            const int radius = W - (int)dge_fast_mod(s, (uint64_t)W, p.W_magic);
             c = max(0, i - radius);
             c_hi = min(len - 1, i + radius);
             if (c_hi == i) c_hi--;
@@ -1093,7 +1093,7 @@ k_sgns_train_locked(TrainParams p) {
             } else {
                 const uint64_t sl = s * mA + cA;
                 if (lane < kc) {
-                    t = neg_table_row(p.ctab, (sl >> 16) % (uint64_t)p.T);
+                    t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
                     if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                     if (PART) t = part_row(t, p.part_n, p.part_tgt, p.V);
                     if (t == word) t = -1;
