@@ -345,7 +345,10 @@ def main():
                          "walk_kernel_ms_per_launch": st["walk_kernel_ms"] / launches,
                          "walk_steps_per_s": (B * L) / (st["walk_kernel_ms"] / launches * 1e-3) if st["walk_kernel_ms"] > 0 else None,
                          "walk_bytes_per_step": 36, "box_copy_GBps": copy_rate,
-                         "row_read_GBps": row_rates and round(row_rates[0], 1), "row_rewrite_GBps": row_rates and round(row_rates[1], 1)},
+                         "row_read_GBps": row_rates and round(row_rates[0], 1), "row_rewrite_GBps": row_rates and round(row_rates[1], 1),
+                         # what the lock kernel actually runs against (profiles/r03_shape_sweep.txt): requests at the L2's memory side — reads leave as 128 bytes,
+                         # writes as 64 — at ~8.5e10/s in every shape measured; from the committed PMC passes like `traffic`, not from counters of this run
+                         "fabric_requests_per_s": None if (args.dim or args.negative >= 0 or NB > 1) else measured_requests(args.workload, "hs" if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch, ms_per_launch)},
         }
         if "expect_policy" in wl and not (args.policy or args.workers or args.hs or NB > 1) and sched["update_policy"] != wl["expect_policy"]:
             print("warning: workload %s resolved to policy %d, the committed traffic profile is for policy %d" % (args.workload, sched["update_policy"], wl["expect_policy"]), file=sys.stderr)
@@ -414,6 +417,16 @@ def measured_traffic(workload, policy, pairs_per_launch):       # policy: "polic
         e = t.get("%s/%s" % (workload, policy))
         return None if e is None else e["bytes_per_pair"] * pairs_per_launch
     except (ValueError, KeyError):
+        return None
+
+
+def measured_requests(workload, policy, pairs_per_launch, ms_per_launch):
+    """Requests per second at the L2's memory side: requests per pair from the committed PMC passes (profiles/traffic.json) x this run's pair rate."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        e = json.load(open(path)).get("%s/%s" % (workload, policy))
+        return None if not e or "requests_per_pair" not in e or not ms_per_launch else e["requests_per_pair"] * pairs_per_launch / (ms_per_launch * 1e-3)
+    except (OSError, ValueError, KeyError):
         return None
 
 
