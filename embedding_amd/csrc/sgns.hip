@@ -30,7 +30,7 @@
 #include "sgns_model.h"
 
 
-std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
@@ -340,6 +340,69 @@ extern "C" int dge_selftest_locked_rows(int device, int32_t n_rows, int64_t n_wo
         for (int c = 0; c < stride; c++) worst = std::max(worst, fabs((double)tab[(size_t)r * stride + c] - (double)cnt[(size_t)r]));
     }
     *total_increments = total; *max_abs_error = worst;
+    return DGE_OK;
+}
+
+// The atomics wave in isolation (lk_post / lk_atomics_wave with its LDS accumulators of the hottest rows): the 12 workers of every workgroup post
+// messages "add 1.0 to every element of these rows" — half of the rows among the n_acc hottest — and afterwards every element of row r must equal
+// the number of times r was posted (counted with integer atomics; integers < 2^24 are exact in float): nothing parked in LDS may be lost or added twice.
+__global__ void __launch_bounds__(256) k_selftest_atomics_wave(float* table, unsigned long long* counts, int32_t n_rows, int stride, int iters, uint64_t seed, int n_acc, int drain) {
+    constexpr int DCH = 2;
+    __shared__ __attribute__((aligned(16))) float s_mb[LK_MB_WORKERS * 2 * LkBox<DCH>::FLOATS];
+    __shared__ int s_mb_flag[LK_MB_WORKERS * 2];
+    __shared__ int s_mb_done;
+    __shared__ float s_acc[LK_ACC_ROWS(DCH) * DCH * 64];
+    __shared__ int s_acc_cnt[LK_ACC_ROWS(DCH)];
+    if (threadIdx.x < LK_MB_WORKERS * 2) s_mb_flag[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_mb_done = 0;
+    for (int i = threadIdx.x; i < LK_ACC_ROWS(DCH) * DCH * 64; i += blockDim.x) s_acc[i] = 0.f;
+    if (threadIdx.x < LK_ACC_ROWS(DCH)) s_acc_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 15, wk = threadIdx.x >> 4;
+    TableView tv = make_view(table, n_rows, stride);
+    tv.valid = (uint32_t)stride;
+    if (wk >= LK_MB_WORKERS) { lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, LK_MB_WORKERS, tv, tv, tv, s_acc, s_acc_cnt, min(n_acc, LK_ACC_ROWS(DCH)), max(drain, 1)); return; }
+    unsigned n_posts = 0;
+    Row<DCH> ones;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) ones.v[c] = make_float4(1.f, 1.f, 1.f, 1.f);
+    const int64_t worker = (int64_t)blockIdx.x * LK_MB_WORKERS + wk;
+    for (int it = 0; it < iters; it++) {
+        int32_t row = -1;
+        if (lane < NEG_BATCH) {
+            const uint64_t hsh = dge_mix64(seed + (uint64_t)((worker * iters + it) * 16 + lane));
+            row = (int32_t)((hsh & 1ull) ? (hsh >> 1) % (uint64_t)min(8, n_rows) : (hsh >> 1) % (uint64_t)n_rows);
+            atomicAdd(&counts[row], 1ULL);
+        }
+        lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, row, 1.0f, ones, lane);
+    }
+    if (lane == 0) __hip_atomic_fetch_add(&s_mb_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+extern "C" int dge_selftest_atomics_wave(int device, int32_t n_rows, int32_t n_acc, int32_t drain, int32_t blocks, int32_t iters, uint64_t seed,
+                                         int64_t* total_updates, double* max_abs_error) {
+    if (n_rows <= 0 || blocks <= 0 || iters <= 0 || n_acc < 0 || drain <= 0 || !total_updates || !max_abs_error) DGE_FAIL(DGE_ERR_ARG, "dge_selftest_atomics_wave: bad argument");
+    int rc = dge_require_device(device);
+    if (rc) return rc;
+    const int stride = 128;
+    float* d_tab = nullptr; unsigned long long* d_cnt = nullptr;
+    if ((rc = dge_dev_alloc(&d_tab, (size_t)n_rows * stride))) return rc;
+    if ((rc = dge_dev_alloc(&d_cnt, (size_t)n_rows))) return rc;
+    DGE_HIP(hipMemset(d_tab, 0, (size_t)n_rows * stride * sizeof(float)));
+    DGE_HIP(hipMemset(d_cnt, 0, (size_t)n_rows * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_selftest_atomics_wave, dim3((unsigned)blocks), dim3(256), 0, 0, d_tab, d_cnt, n_rows, stride, iters, seed, n_acc, drain);
+    DGE_HIP(hipGetLastError());
+    DGE_HIP(hipDeviceSynchronize());
+    std::vector<float> tab((size_t)n_rows * stride); std::vector<unsigned long long> cnt((size_t)n_rows);
+    DGE_HIP(hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(float), hipMemcpyDeviceToHost));
+    DGE_HIP(hipMemcpy(cnt.data(), d_cnt, cnt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    dge_dev_free(d_tab); dge_dev_free(d_cnt);
+    double worst = 0.0; int64_t total = 0;
+    for (int32_t r = 0; r < n_rows; r++) {
+        total += (int64_t)cnt[(size_t)r];
+        for (int c = 0; c < stride; c++) worst = std::max(worst, fabs((double)tab[(size_t)r * stride + c] - (double)cnt[(size_t)r]));
+    }
+    *total_updates = total; *max_abs_error = worst;
     return DGE_OK;
 }
 
@@ -711,7 +774,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.locks = m->d_locks;
     p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
     p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0; p.hs_cold = 0; p.hs_wave = 0;
-    p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt; p.syn0_free = 0;
+    p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt; p.syn0_free = 0; p.acc_rows = 0; p.acc_drain = 16;
     p.N_magic = 0xFFFFFFFFu / (uint32_t)std::max(m->part_n, 1);
     p.big_seg_shift = 0;
     p.filler_row = (int32_t)(0xFFFFFFF0u / ((uint32_t)m->stride * 4u)) - 1;      // offset + the largest in-row displacement stays below 2^32
@@ -774,6 +837,9 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // a flat vocabulary with a few busy rows: only those; a skewed one: the whole head
         p.hot_rows = (int32_t)std::min<int64_t>((m->cfg.update_policy == 0 && fail_all < 0.25) ? m->hot_rows_serial : std::max(m->hot_rows_auto, m->hot_rows_serial), m->V);
         if (g_dge_tuning[DGE_TUNE_HOT_ROWS] >= 0) p.hot_rows = (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_HOT_ROWS], m->V);     // ablation knob
+        // off unless asked for: measured on cfg3_zipf it buys 2-4 % and shifts the trained scores (profiles/r03_zipf_ablation.txt)
+        p.acc_rows = g_dge_tuning[DGE_TUNE_ACC_ROWS] > 0 ? (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_ACC_ROWS], 64) : 0;       // (the kernel caps it at what its LDS holds)
+        if (g_dge_tuning[DGE_TUNE_ACC_DRAIN] > 0) p.acc_drain = (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_ACC_DRAIN], 1 << 20);
     }
     if (pol == 100 || (workers == 1 && pol != 5 && pol != 6 && pol != 7 && pol != 2 && pol != 1)) pol = 0;   // in-order: plain accesses
     if (pol == 3 || pol == 8) pol = 0;          // (policy 8 with one worker: the in-order schedule)

@@ -25,6 +25,7 @@
 struct TrainParams {
     const int32_t* sen; const int64_t* len; const int64_t* wb;
     float* syn0; float* syn1neg;
+    int32_t acc_rows, acc_drain;  // update_policy 7: the hottest rows [0, acc_rows) combine their syn1neg updates in the atomics wave's LDS accumulators, `acc_drain` updates a flush
     const uint4* ctab;        // word2vec's unigram^0.75 table in rank-block form (neg_table_row): 16 B per 96 slots
     const float* exp_table;
     int64_t n_rows; int32_t L, W, K, stride;
@@ -451,8 +452,28 @@ __device__ __forceinline__ void lk_post4(float* boxes, int* flags, int wk, unsig
 // atomics wave: all 64 lanes on ONE message at a time — an atomic instruction then covers 256 contiguous bytes of a row (a wave can have ~63
 // memory instructions outstanding, and atomics on a saturated unit complete slowly: with one 16-lane group per message, 64 bytes an instruction,
 // the wave itself would cap the workgroup's atomic rate).  Returns when every worker of the workgroup has left and every box is free.
+// The hottest rows of a skewed vocabulary (update_policy 7; rows are ordered by count, so they are rows [0, n_acc)) do not go out update by update:
+// the wave adds their syn1neg updates up in LDS accumulators of its own (acc: n_acc rows; it is the only wave that touches them, so plain LDS
+// read-modify-writes) and sends a row's sum as ONE set of atomics after `drain` updates, and whatever is left when the workgroup ends.  On a power law
+// with 20 negatives a pair the unigram^0.75 table sends 9 % of all draws to the 30 hottest rows (cfg5: the head's syn1neg atomics are a quarter of a
+// launch, profiles/r03_zipf_ablation.txt).  Readers still read memory: they see this workgroup's parked updates of such a row at most `drain` late.
+// OFF by default (dge_set_tuning DGE_TUNE_ACC_ROWS): cfg3_zipf gains 2-4 % with 16 rows whatever the drain (4 .. 64), cfg5 nothing, and with 16 updates a
+// flush the hottest rows lag enough to move the trained scores (mean score of linked pairs 2.45 against 1.34, AUC unchanged; 1.37 with 4 a flush).
+#define LK_ACC_ROWS(DCH) ((DCH) <= 2 ? 16 : ((DCH) <= 4 ? 12 : 8))
 template <int DCH>
-__device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* done, int n_workers_here, const TableView& syn0, const TableView& syn1neg, const TableView& syn1) {
+__device__ __forceinline__ void lk_acc_flush(float* acc, int row, const TableView& t, int wl) {
+    float* a = acc + row * (DCH * 64) + wl;
+    float* pr = t.base + (size_t)row * (t.row_bytes / 4) + wl;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        const float v = a[c * 64];
+        a[c * 64] = 0.f;
+        if ((uint32_t)(c * 64 + wl) < t.valid) atomicAdd(pr + c * 64, v);
+    }
+}
+template <int DCH>
+__device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* done, int n_workers_here, const TableView& syn0, const TableView& syn1neg, const TableView& syn1,
+                                                float* acc = nullptr, int* acc_cnt = nullptr, int n_acc = 0, int drain = 1) {
     const int wl = threadIdx.x & 63;
     for (;;) {
         bool any = false;
@@ -474,6 +495,15 @@ __device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* d
                 const int j = __builtin_ctz(left);
                 const int32_t row = __builtin_amdgcn_readlane(my_row, j);
                 const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_step), j));
+                if (f == 1 && row < n_acc) {                // one of the hottest rows: into its accumulator
+                    float* a = acc + row * (DCH * 64) + wl;
+#pragma unroll
+                    for (int c = 0; c < DCH; c++) a[c * 64] = fmaf(g, v[c], a[c * 64]);
+                    const int n = __builtin_amdgcn_readfirstlane(acc_cnt[row]) + 1;
+                    if (n >= drain) lk_acc_flush<DCH>(acc, row, syn1neg, wl);
+                    if (wl == 0) acc_cnt[row] = n >= drain ? 0 : n;
+                    continue;
+                }
                 float* pr = t.base + (size_t)row * (t.row_bytes / 4) + wl;
 #pragma unroll
                 for (int c = 0; c < DCH; c++)
@@ -485,7 +515,11 @@ __device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* d
             if (d >= n_workers_here) {                      // every worker has left: whatever it posted is visible now — one last look
                 bool left_over = false;
                 for (int b = 0; b < LK_MB_WORKERS * 2; b++) left_over |= __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b])) != 0;
-                if (!left_over) return;
+                if (!left_over) {
+                    for (int r = 0; r < n_acc; r++)         // what is still parked goes out
+                        if (__builtin_amdgcn_readfirstlane(acc_cnt[r]) > 0) lk_acc_flush<DCH>(acc, r, syn1neg, wl);
+                    return;
+                }
             } else __builtin_amdgcn_s_sleep(2);
         }
     }
@@ -925,9 +959,15 @@ k_sgns_train_locked(TrainParams p) {
     __shared__ __attribute__((aligned(16))) float s_mb[HOTMIX ? LK_MB_WORKERS * 2 * LkBox<DCH>::FLOATS : 4];     // the atomics wave's message boxes
     __shared__ int s_mb_flag[LK_MB_WORKERS * 2];
     __shared__ int s_mb_done;
+    __shared__ float s_acc[HOTMIX ? LK_ACC_ROWS(DCH) * DCH * 64 : 4];        // the atomics wave's accumulators of the hottest rows (lk_atomics_wave)
+    __shared__ int s_acc_cnt[LK_ACC_ROWS(DCH)];
     for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
     if (threadIdx.x < LK_MB_WORKERS * 2) s_mb_flag[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_mb_done = 0;
+    if (HOTMIX) {
+        for (int i = threadIdx.x; i < LK_ACC_ROWS(DCH) * DCH * 64; i += blockDim.x) s_acc[i] = 0.f;
+        if (threadIdx.x < LK_ACC_ROWS(DCH)) s_acc_cnt[threadIdx.x] = 0;
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 15;
@@ -942,7 +982,8 @@ k_sgns_train_locked(TrainParams p) {
     syn0.valid = syn1neg.valid = (uint32_t)p.D;
     if (use_mb && wk >= LK_MB_WORKERS) {
         const int64_t here = min((int64_t)LK_MB_WORKERS, p.n_workers - (int64_t)blockIdx.x * LK_MB_WORKERS);
-        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(here, (int64_t)0), syn0, syn1neg, syn1neg);
+        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(here, (int64_t)0), syn0, syn1neg, syn1neg, s_acc, s_acc_cnt,
+                             min(min(p.acc_rows, p.hot_rows), LK_ACC_ROWS(DCH)), max(p.acc_drain, 1));
         return;
     }
     if (worker >= p.n_workers) return;

@@ -324,7 +324,9 @@ enum {
     DGE_TUNE_STATIC_WALKS = 7,    /* > 0: the lock kernels' worker w trains walks w, w + workers, ... instead of taking them from a launch-wide counter */
     DGE_TUNE_HS_COLD = 8,         /* hierarchical softmax under atomics: inner nodes [0, value) take plain read-modify-write (default: those on < 2e-5 of the paths) */
     DGE_TUNE_HS_WAVE = 9,         /* hierarchical softmax under atomics: 0 = the workers issue their atomics themselves, 1 = through the workgroup's atomics wave (default: the wave from 65 536 rows on) */
-    DGE_TUNE_COUNT = 10
+    DGE_TUNE_ACC_ROWS = 10,       /* update_policy 7: the hottest rows [0, value) add their syn1neg updates up in LDS (one set of atomics per DGE_TUNE_ACC_DRAIN updates; the kernel caps the value at what its LDS holds, 8 .. 16); default 0 = none: measured it buys 2-4 % and, from 16 updates a flush on, shifts the trained scores */
+    DGE_TUNE_ACC_DRAIN = 11,      /* updates of such a row between two flushes (default 16) */
+    DGE_TUNE_COUNT = 12
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
 int  dge_get_tuning(int32_t knob, int64_t* value);   /* -1 = the library's own rule */
@@ -338,6 +340,10 @@ int  dge_get_tuning(int32_t knob, int64_t* value);   /* -1 = the library's own r
 int  dge_selftest_locked_rows(int device, int32_t n_rows, int64_t n_workers, int32_t iters, uint64_t seed,
                               int32_t commit /* 0 relaxed (policy 5), 1 strict (policy 6), 2 agent release fence */,
                               int64_t* total_increments, double* max_abs_error);
+/* The atomics wave of the mixed kernels in isolation, LDS accumulators of the n_acc hottest rows included: `blocks` workgroups x 12 workers x `iters`
+   messages of 5 rows each, half of them among the 8 hottest; every element of a row must end at the number of times the row was posted. */
+int  dge_selftest_atomics_wave(int device, int32_t n_rows, int32_t n_acc, int32_t drain, int32_t blocks, int32_t iters, uint64_t seed,
+                               int64_t* total_updates, double* max_abs_error);
 /* the LDS combining of the hierarchical-softmax updates near the root (hot_add) in isolation: n_workers workers add 1.0
  * to skewed pseudo-random rows `iters` times with the given drain period; max_abs_error = worst |row element - additions
  * that row received| (0 when no addition is lost or doubled). */

@@ -206,6 +206,17 @@ def test_commit_lock_protocol_conservation(dge):
     assert run(1024, 12288, 10, 2)[0] == 0.0                                  # agent release fence: exact
 
 
+def test_atomics_wave_conserves_every_update(dge):
+    """The atomics wave of the mixed kernels (update_policy 7) with its LDS accumulators of the hottest rows: 12 workers a workgroup post
+    "add 1.0 to these rows"; every element of every row must end at exactly the number of times the row was posted — with no accumulators, with
+    accumulators flushed after every update, after 16 (the default) and only when the workgroup ends."""
+    import ctypes as C
+    for n_rows, n_acc, drain, blocks, iters in ((1000, 0, 1, 64, 50), (1000, 16, 1, 64, 50), (1000, 16, 16, 256, 100), (5, 16, 7, 32, 40), (100000, 8, 1 << 20, 128, 60)):
+        total = C.c_int64(0); err = C.c_double(-1)
+        assert dge.lib.dge_selftest_atomics_wave(0, n_rows, n_acc, drain, blocks, iters, 11, C.byref(total), C.byref(err)) == 0
+        assert total.value == blocks * 12 * iters * 5 and err.value == 0.0, (n_rows, n_acc, drain, total.value, err.value)
+
+
 def test_locked_policies_match_the_in_order_result(dge, oracle):
     """Policies 5 and 6 (layout with 16 B per lane, the centre's delta summed in LDS) against the oracle: one worker reproduces the
     sequential word2vec result to rounding, 16 workers stay within Hogwild noise."""
