@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DGE_VERSION 102
+#define DGE_VERSION 103   /* 103: dge_get_tuning, dge_model_tune_placement, dge_model_table_placement, dge_selftest_atomics_wave, tuning knobs 8 .. 11 (additions only) */
 
 enum {
     DGE_OK = 0,
