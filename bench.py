@@ -331,7 +331,7 @@ def main():
             "config": {"workload": wl["name"], "vertices": NV, "edges": int(n_edges), "timeslices": T, "dim": D,
                        "negatives": K, "walk_len": L, "window": L, "walks_per_step_per_gpu": B,
                        "pairs_per_step_per_gpu": st["pairs"] / args.steps, "vocabulary": int((counts >= 2).sum().item()),
-                       "sgns_workers": args.workers, "table_placement": model.table_placement(), "placement_search": placement, "placement_trial_ms": trial_ms and [round(x, 1) for x in trial_ms],
+                       "sgns_workers": args.workers, "table_placement": model.table_placement(), "table_runs": model.table_runs(), "placement_search": placement, "placement_trial_ms": trial_ms and [round(x, 1) for x in trial_ms],
                        "lr_horizon_epochs": 1000, "ring_transport": ring and ring.mode, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, syn1neg partitions passed round a ring" % N if blocks and N > 1
                                        else "SIMULATED rank 0 of a %d-rank block schedule on one GPU (value = this rank's share only)" % NB if blocks
                                        else "walk-shard x%d, RCCL all-reduce of deltas per step (comparison mode)" % N if N > 1 else "1 GPU"),

@@ -77,6 +77,7 @@ SIGNATURES = {
     "dge_model_stats": (_int, [_vp, _P(TrainStats)]),
     "dge_model_row_rates": (_int, [_vp, _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "dge_model_table_placement": (_int, [_vp, _i32, _vp, _vp, _vp]),
+    "dge_model_table_runs": (_int, [_vp, _vp, _vp]),
     "dge_model_tune_placement": (_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "dge_model_reset_stats": (_int, [_vp]),
     "dge_model_schedule": (_int, [_vp, _P(_i32), _P(_i64), _P(_i32)]),

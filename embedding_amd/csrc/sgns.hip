@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <limits>
 #include <map>
 #include <mutex>
 
@@ -30,7 +31,7 @@
 #include "sgns_model.h"
 
 
-std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
@@ -191,6 +192,18 @@ __global__ void k_table_fill(const int32_t* __restrict__ m, int64_t V, int64_t T
     if (a >= T) return;
     int64_t i = a + (int64_t)min(0, m[a]);
     table[a] = (int32_t)min(i, V - 1);
+}
+
+// the run form of the table (neg_row_by_runs) against the table itself, slot by slot: the slots at which they differ
+__global__ void k_runs_verify(const int32_t* __restrict__ table, int64_t T, const double* base, const uint32_t* row, const uint32_t* exc_slot,
+                              const int32_t* exc_row, int n_exc, double T_inv, int64_t V, unsigned* n_bad, uint32_t* bad_slot, int32_t* bad_row, unsigned cap) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= T) return;
+    const int32_t r = neg_row_by_runs((uint32_t)a, base, row, exc_slot, exc_row, n_exc, T_inv, V);
+    if (r != -2 && r != table[a]) {
+        const unsigned idx = atomicAdd(n_bad, 1u);
+        if (idx < cap) { bad_slot[idx] = (uint32_t)a; bad_row[idx] = table[a]; }
+    }
 }
 
 // the table in rank-block form (neg_table_row, sgns_kernels.h): thread (block b, word k) collects the step bits of slots 96b + 32k .. + 31
@@ -486,6 +499,7 @@ extern "C" int dge_count_tokens(const dge_walks* w, int64_t row0, int64_t n_rows
 
 static void model_release(dge_model* m) {
     table_free(m->d_syn0); table_free(m->d_syn1neg); dge_dev_free(m->d_locks); dge_dev_free(m->d_ctab);
+    dge_dev_free(m->d_run_base); dge_dev_free(m->d_run_row); dge_dev_free(m->d_exc_slot); dge_dev_free(m->d_exc_row);
     dge_dev_free(m->d_snap); dge_dev_free(m->d_vocab_ids);
     table_free(m->d_syn1); dge_dev_free(m->d_hs_off); dge_dev_free(m->d_hs_points); dge_dev_free(m->d_hs_codes);
     dge_dev_free(m->d_counts); dge_dev_free(m->d_remap); dge_dev_free(m->d_exp);
@@ -637,6 +651,62 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         MH(hipcub::DeviceScan::ExclusiveScan((void*)d_tmp2.p, tmp_bytes, d_g.p, d_m.p, hipcub::Min(), (int32_t)0, m->T, st));
         hipLaunchKernelGGL(k_table_fill, dim3(grid_for(m->T, 256)), dim3(256), 0, st, d_m.p, V, m->T, d_flat.p);
         MH(hipStreamSynchronize(st));
+        // --- the run form of the table, if this vocabulary has one (neg_row_by_runs): runs of adjacent rows of equal count, checked against the table
+        if (m->T < 0xFFFFFFFFll && g_dge_tuning[DGE_TUNE_TABLE_RUNS] != 0) {
+            std::vector<double> rb(DGE_RUN_MAX, std::numeric_limits<double>::infinity());
+            std::vector<uint32_t> rr(DGE_RUN_MAX + 1, (uint32_t)V);
+            // the runs are collected from the vocabulary's END — the tail is where equal counts abound — until the arrays are full; head rows in front of the
+            // first run keep the table look-up (cfg3: 1 716 runs cover its whole vocabulary of a million rows, counts 2 .. 6 905, and match the table in
+            // every one of its 1e8 slots; a vocabulary of several thousand distinct counts keeps its most frequent rows on the table)
+            int runs = 0; int64_t i = V;
+            std::vector<int64_t> starts;
+            const int max_runs = g_dge_tuning[DGE_TUNE_TABLE_RUNS] > 0 ? (int)std::min<int64_t>(g_dge_tuning[DGE_TUNE_TABLE_RUNS], DGE_RUN_MAX - 2) : DGE_RUN_MAX - 2;
+            while (i > 0 && runs < max_runs) {
+                int64_t j = i - 1;
+                while (j > 0 && m->h_counts[(size_t)j - 1] == m->h_counts[(size_t)i - 1]) j--;
+                starts.push_back(j); runs++; i = j;
+            }
+            std::reverse(starts.begin(), starts.end());
+            for (int r = 0; r < runs; r++) {
+                const int64_t r0 = starts[(size_t)r];
+                rb[(size_t)r] = r0 == 0 ? 0.0 : cum[(size_t)r0 - 1];
+                rr[(size_t)r] = (uint32_t)r0;
+            }
+            rb[(size_t)runs] = cum[(size_t)V - 1];       // the boundary behind the last run (behind it: +inf, row V)
+            {   // whether the run form is kept is decided by comparing it with the table
+                dge_tmp<unsigned> d_nbad; dge_tmp<uint32_t> d_bs; dge_tmp<int32_t> d_br;
+                const unsigned cap = 4096;
+                MC(d_nbad.alloc(1)); MC(d_bs.alloc(cap)); MC(d_br.alloc(cap));
+                MC(dge_dev_alloc(&m->d_run_base, DGE_RUN_MAX)); MC(dge_dev_alloc(&m->d_run_row, DGE_RUN_MAX + 1));
+                MC(dge_dev_alloc(&m->d_exc_slot, DGE_RUN_EXC)); MC(dge_dev_alloc(&m->d_exc_row, DGE_RUN_EXC));
+                MH(hipMemcpyAsync(m->d_run_base, rb.data(), DGE_RUN_MAX * sizeof(double), hipMemcpyHostToDevice, st));
+                MH(hipMemcpyAsync(m->d_run_row, rr.data(), (DGE_RUN_MAX + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                std::vector<uint32_t> es(DGE_RUN_EXC, 0xFFFFFFFFu); std::vector<int32_t> er(DGE_RUN_EXC, 0);
+                unsigned n_bad = 0; int n_exc = 0; bool good = false;
+                for (int round = 0; round < 2; round++) {      // first without exceptions (collects them), then with them (must leave nothing)
+                    MH(hipMemsetAsync(d_nbad.p, 0, sizeof(unsigned), st));
+                    MH(hipMemcpyAsync(m->d_exc_slot, es.data(), DGE_RUN_EXC * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                    MH(hipMemcpyAsync(m->d_exc_row, er.data(), DGE_RUN_EXC * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                    hipLaunchKernelGGL(k_runs_verify, dim3(grid_for(m->T, 256)), dim3(256), 0, st, d_flat.p, m->T, m->d_run_base, m->d_run_row, m->d_exc_slot, m->d_exc_row,
+                                       n_exc, 1.0 / (double)m->T, V, d_nbad.p, d_bs.p, d_br.p, cap);
+                    MH(hipMemcpyAsync(&n_bad, d_nbad.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                    MH(hipStreamSynchronize(st));
+                    if (round == 1) { good = n_bad == 0; break; }
+                    if (n_bad > DGE_RUN_EXC) break;
+                    if (n_bad > 0) {
+                        std::vector<uint32_t> bs(n_bad); std::vector<int32_t> br(n_bad);
+                        MH(hipMemcpy(bs.data(), d_bs.p, n_bad * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                        MH(hipMemcpy(br.data(), d_br.p, n_bad * sizeof(int32_t), hipMemcpyDeviceToHost));
+                        std::vector<size_t> order(n_bad);
+                        for (size_t q = 0; q < n_bad; q++) order[q] = q;
+                        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return bs[x] < bs[y]; });
+                        for (size_t q = 0; q < n_bad; q++) { es[q] = bs[order[q]]; er[q] = br[order[q]]; }
+                    }
+                    n_exc = (int)n_bad;
+                }
+                if (good) { m->n_runs = runs; m->n_exc = n_exc; }
+            }
+        }
     } else {
         MH(hipMemsetAsync(d_flat.p, 0, (size_t)m->T * sizeof(int32_t), st));
     }
@@ -760,6 +830,8 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.sen = m->d_sen; p.len = m->d_len; p.wb = m->d_wb;
     p.syn0 = m->d_syn0; p.syn1neg = m->d_syn1neg; p.exp_table = m->d_exp;
     p.ctab = m->d_ctab;
+    p.run_base = m->d_run_base; p.run_row = m->d_run_row; p.exc_slot = m->d_exc_slot; p.exc_row = m->d_exc_row;
+    p.n_runs = g_dge_tuning[DGE_TUNE_TABLE_RUNS] == 0 ? 0 : m->n_runs; p.n_exc = m->n_exc; p.T_inv = 1.0 / (double)std::max<int64_t>(m->T, 1);
     p.n_rows = n_rows; p.L = L; p.W = m->cfg.window; p.K = m->cfg.negative; p.stride = m->stride;
     p.V = m->V; p.T = m->T; p.seed = m->cfg.seed;
     p.T_magic = ~0ull / (uint64_t)std::max<int64_t>(m->T, 1); p.W_magic = ~0ull / (uint64_t)std::max(m->cfg.window, 1);
@@ -1290,6 +1362,13 @@ extern "C" int dge_model_table_placement(const dge_model* m, int32_t table, int3
     if (candidates) *candidates = m->placed_seen[table];
     if (best_gb_per_s) *best_gb_per_s = m->placed_best[table];
     if (worst_gb_per_s) *worst_gb_per_s = m->placed_worst[table];
+    return DGE_OK;
+}
+
+extern "C" int dge_model_table_runs(const dge_model* m, int32_t* n_runs, int32_t* n_exceptions) {
+    if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_table_runs: null model");
+    if (n_runs) *n_runs = m->n_runs;
+    if (n_exceptions) *n_exceptions = m->n_exc;
     return DGE_OK;
 }
 

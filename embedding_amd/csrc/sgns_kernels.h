@@ -27,6 +27,11 @@ struct TrainParams {
     float* syn0; float* syn1neg;
     int32_t acc_rows, acc_drain;  // update_policy 7: the hottest rows [0, acc_rows) combine their syn1neg updates in the atomics wave's LDS accumulators, `acc_drain` updates a flush
     const uint4* ctab;        // word2vec's unigram^0.75 table in rank-block form (neg_table_row): 16 B per 96 slots
+    // the same table in RUN form (neg_row_by_runs) when the vocabulary has few distinct counts: n_runs runs of equally frequent rows, and the n_exc slots
+    // at which the closed form is off by one (found by comparing it with the table slot by slot when the model is created); n_runs == 0: not available
+    const double* run_base; const uint32_t* run_row; const uint32_t* exc_slot; const int32_t* exc_row;
+    int32_t n_runs, n_exc;
+    double T_inv;
     const float* exp_table;
     int64_t n_rows; int32_t L, W, K, stride;
     int32_t D;                // the rows' meaningful floats (stride = D rounded up to 64: the rest is zero padding and stays zero)
@@ -109,6 +114,42 @@ __device__ __forceinline__ int32_t neg_table_row(const uint4* __restrict__ ctab,
     const uint32_t m1 = j < 32u ? 0u : (j >= 63u ? 0xFFFFFFFFu : ((2u << (j - 32u)) - 1u));
     const uint32_t m2 = j < 64u ? 0u : (j >= 95u ? 0xFFFFFFFFu : ((2u << (j - 64u)) - 1u));
     return (int32_t)(r.x + (uint32_t)__popc(r.y & m0) + (uint32_t)__popc(r.z & m1) + (uint32_t)__popc(r.w & m2));
+}
+
+// The table without the table.  Rows are ordered by count, so rows of equal count form runs, and inside a run word2vec's cumulative d1 grows by the
+// same increment: the slot -> row map is a few hundred straight segments.  Run r = rows [row[r], row[r + 1]) with cumulative base[r] before its first
+// row (the increment is (base[r + 1] - base[r]) / rows of the run); table[a] = #{rows whose cumulative value is below (a - 1) / T} wherever no slot holds two rows' ends (elsewhere, and
+// where the arithmetic here rounds differently from the serial sum, the slot is in the exception list: the model's creation compares this function with
+// the real table slot by slot and keeps the run form only if at most DGE_RUN_EXC slots differ).  The arrays live in LDS: a look-up is 8 compares there
+// and a handful of f64 operations instead of a request to memory — the lock kernel runs against a request rate and its 5 look-ups a pair cost 7 % of a
+// launch (profiles/r03_shape_sweep.txt).  base[] is padded with +inf to DGE_RUN_MAX entries.  The runs cover the vocabulary's tail, rows [row[0], V);
+// a slot of the head rows in front of it returns -2: the caller reads the table for it.
+#define DGE_RUN_MAX 2048
+#define DGE_RUN_EXC 64
+template <typename PD, typename PU, typename PI>
+__device__ __forceinline__ int32_t neg_row_by_runs(uint32_t a, const PD base, const PU row, const PU exc_slot, const PI exc_row, int n_exc, double T_inv, int64_t V) {
+    if (a == 0u) return -2;
+    const double x = (double)(a - 1u) * T_inv;
+    if (!(base[0] < x)) return -2;                  // the head rows in front of the first run (and slots 0, 1): the table itself answers
+    int lo = 0;
+#pragma unroll
+    for (int st = DGE_RUN_MAX / 2; st >= 1; st >>= 1) if (base[lo + st] < x) lo += st;          // the last boundary below x (base[0] < x)
+    const int64_t n = (int64_t)row[lo + 1] - (int64_t)row[lo];                                  // (behind the last run: base = +inf, row = V: n = 0)
+    int64_t k = 0;
+    if (n > 0) {
+        // rows of this run with cumulative value below x: the m-th has base + m (next base - base) / n, so m < q
+        const double q = (x - base[lo]) * (double)n / (base[lo + 1] - base[lo]);
+        k = (int64_t)ceil(q) - 1;
+        k = k < 0 ? 0 : (k > n ? n : k);
+    }
+    int32_t r = (int32_t)min((int64_t)row[lo] + k, V - 1);
+    if (n_exc > 0) {
+        int e = 0;
+#pragma unroll
+        for (int st = DGE_RUN_EXC / 2; st >= 1; st >>= 1) if (e + st < n_exc && exc_slot[e + st] <= a) e += st;
+        if (exc_slot[e] == a) r = exc_row[e];
+    }
+    return r;
 }
 
 // x % d for a divisor that is fixed for the launch: q = mulhi(x, floor((2^64 - 1) / d)) falls short of x / d by at most 2 — a dozen instructions
@@ -961,6 +1002,17 @@ k_sgns_train_locked(TrainParams p) {
     __shared__ int s_mb_done;
     __shared__ float s_acc[HOTMIX ? LK_ACC_ROWS(DCH) * DCH * 64 : 4];        // the atomics wave's accumulators of the hottest rows (lk_atomics_wave)
     __shared__ int s_acc_cnt[LK_ACC_ROWS(DCH)];
+    // the negative-sampling table's run form (neg_row_by_runs), where the model has one (not in the mixed kernels: skewed vocabularies have none)
+    __shared__ double s_run_base[HOTMIX ? 1 : DGE_RUN_MAX];
+    __shared__ uint32_t s_run_row[HOTMIX ? 1 : DGE_RUN_MAX + 1];
+    __shared__ uint32_t s_exc_slot[HOTMIX ? 1 : DGE_RUN_EXC];
+    __shared__ int32_t s_exc_row[HOTMIX ? 1 : DGE_RUN_EXC];
+    const bool use_runs = !HOTMIX && p.n_runs > 0;
+    if (use_runs) {
+        for (int i = threadIdx.x; i < DGE_RUN_MAX; i += blockDim.x) s_run_base[HOTMIX ? 0 : i] = p.run_base[i];
+        for (int i = threadIdx.x; i < DGE_RUN_MAX + 1; i += blockDim.x) s_run_row[HOTMIX ? 0 : i] = p.run_row[i];
+        for (int i = threadIdx.x; i < DGE_RUN_EXC; i += blockDim.x) { s_exc_slot[HOTMIX ? 0 : i] = p.exc_slot[i]; s_exc_row[HOTMIX ? 0 : i] = p.exc_row[i]; }
+    }
     for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
     if (threadIdx.x < LK_MB_WORKERS * 2) s_mb_flag[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_mb_done = 0;
@@ -1134,7 +1186,11 @@ k_sgns_train_locked(TrainParams p) {
             } else {
                 const uint64_t sl = s * mA + cA;
                 if (lane < kc) {
-                    t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                    {
+                        const uint64_t slot = dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic);
+                        t = use_runs ? neg_row_by_runs((uint32_t)slot, s_run_base, s_run_row, s_exc_slot, s_exc_row, p.n_exc, p.T_inv, p.V) : -2;
+                        if (t == -2) t = neg_table_row(p.ctab, slot);
+                    }
                     if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                     if (PART) t = part_row(t, p.part_n, p.part_tgt, p.V);
                     if (t == word) t = -1;

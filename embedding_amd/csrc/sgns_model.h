@@ -39,6 +39,10 @@ struct dge_model {
     int64_t* d_counts = nullptr;
     int32_t* d_remap = nullptr;
     uint4* d_ctab = nullptr; int64_t ctab_blocks = 0;   // word2vec's unigram table in rank-block form (neg_table_row)
+    // ... and in run form (neg_row_by_runs) when the vocabulary has at most DGE_RUN_MAX distinct adjacent counts and the closed form matches the table
+    // everywhere but in at most DGE_RUN_EXC slots; n_runs == 0: not available
+    double* d_run_base = nullptr; uint32_t* d_run_row = nullptr; uint32_t* d_exc_slot = nullptr; int32_t* d_exc_row = nullptr;
+    int32_t n_runs = 0, n_exc = 0;
     int32_t hs_cold_auto = 0;                   // hierarchical softmax: inner nodes [0, hs_cold_auto) are each on fewer than 2e-5 of the paths
     float* d_exp = nullptr;
     // per-call work buffers

@@ -320,6 +320,12 @@ class SgnsModel:
         v = [C.c_double(0) for _ in range(4)]
         check(lib.dge_model_row_rates(self._h, *[C.byref(x) for x in v])); return tuple(x.value for x in v)
 
+    def table_runs(self):
+        """(runs, exceptions) of the negative-sampling table's run form (include/dge.h, dge_model_table_runs); (0, 0): this model has none."""
+        n, e = C.c_int32(0), C.c_int32(0)
+        check(lib.dge_model_table_runs(self._h, C.byref(n), C.byref(e)))
+        return n.value, e.value
+
     def table_placement(self):
         """What dge_model_create's probe-selected table allocation saw: [(candidates probed, best GB/s = the one kept, worst GB/s)] for syn0, syn1neg
         (and syn1 under hierarchical softmax)."""
@@ -386,7 +392,7 @@ class SgnsModel:
         check(lib.dge_model_import_delta(self._h, _dev_ptr(d_buf), float(scale)))
 
 
-TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7, "hs_cold": 8, "hs_wave": 9, "acc_rows": 10, "acc_drain": 11}      # include/dge.h: DGE_TUNE_*
+TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7, "hs_cold": 8, "hs_wave": 9, "acc_rows": 10, "acc_drain": 11, "table_runs": 12}      # include/dge.h: DGE_TUNE_*
 
 
 class tuning:

@@ -235,6 +235,12 @@ int  dge_model_reset_stats(dge_model* m);
    stops as soon as one candidate is 14 % above the slowest seen.  This reports, for table 0 (syn0), 1 (syn1neg) or 2 (syn1), how many candidates were
    probed and the best (= the one kept) and worst probe rate in GB/s (0 candidates: the table was small or of 4 GiB and more, or the probe could not run). */
 int  dge_model_table_placement(const dge_model* m, int32_t table, int32_t* candidates, double* best_gb_per_s, double* worst_gb_per_s);
+/* The negative-sampling table's run form.  Rows are ordered by count; the rows of equal count form runs (up to 2 046 of them, counted from the vocabulary's tail; the head rows in front keep the table), the
+   slot -> row map of word2vec's unigram^0.75 table is that many straight segments, and the lock kernels compute a negative's row from the run arrays in
+   LDS instead of reading the table (5 requests to memory a pair less; profiles/r03_shape_sweep.txt).  dge_model_create compares the closed form with
+   the table slot by slot and keeps it only if at most 64 slots differ (those are listed and looked up): the rows drawn are the table's, bit for bit.
+   n_runs = 0: this model has no run form (a skewed vocabulary, or too many exceptions). */
+int  dge_model_table_runs(const dge_model* m, int32_t* n_runs, int32_t* n_exceptions);
 /* Placement search (profiles/r03_placement.txt): which physical memory the allocator handed each of the model's large arrays decides a launch's
    duration by up to 15 %, array by array, under no rule that could be asked for.  Trains rows [row0, row0 + n_rows) of w as a probe; then for
    the negative-sampling table, the lock words, syn1neg and syn0 in turn up to candidates - 1 copies in fresh memory are tried and the faster
@@ -326,7 +332,8 @@ enum {
     DGE_TUNE_HS_WAVE = 9,         /* hierarchical softmax under atomics: 0 = the workers issue their atomics themselves, 1 = through the workgroup's atomics wave (default: the wave from 65 536 rows on) */
     DGE_TUNE_ACC_ROWS = 10,       /* update_policy 7: the hottest rows [0, value) add their syn1neg updates up in LDS (one set of atomics per DGE_TUNE_ACC_DRAIN updates; the kernel caps the value at what its LDS holds, 8 .. 16); default 0 = none: measured it buys 2-4 % and, from 16 updates a flush on, shifts the trained scores */
     DGE_TUNE_ACC_DRAIN = 11,      /* updates of such a row between two flushes (default 16) */
-    DGE_TUNE_COUNT = 12
+    DGE_TUNE_TABLE_RUNS = 12,     /* the negative-sampling table's run form (dge_model_table_runs): 0 = not built / not used (the lock kernels read the table), N > 0 = built from at most N runs of the vocabulary's tail (tests: the head rows in front stay on the table); default: up to 2 046 runs */
+    DGE_TUNE_COUNT = 13
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
 int  dge_get_tuning(int32_t knob, int64_t* value);   /* -1 = the library's own rule */

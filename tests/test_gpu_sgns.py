@@ -217,6 +217,32 @@ def test_atomics_wave_conserves_every_update(dge):
         assert total.value == blocks * 12 * iters * 5 and err.value == 0.0, (n_rows, n_acc, drain, total.value, err.value)
 
 
+def test_negative_table_run_form_draws_the_tables_rows(dge, oracle):
+    """The lock kernels compute a negative's row from the table's run form in LDS (dge_model_table_runs) instead of reading the table: the rows must be
+    the table's.  One worker, policy 5: bit-identical tables whether the run form is used for the whole vocabulary, only for its last three runs (the
+    head rows in front stay on the table), or not at all — and equal to the sequential oracle to rounding."""
+    walks, NV = _walks(oracle, dge, n=1500)
+    om = oracle.train_sgns(walks, NV, 64, 6, table_size=20011, arith=0)
+    got = {}
+    for cap in (-1, 3, 0):
+        c = dge.make_config(64, 6, NV, workers=1, table_size=20011, update_policy=5)
+        with dge.tuning(table_runs=cap):
+            dm = dge.SgnsModel.fit(walks, c, 0)
+            runs, exc = dm.table_runs()
+            assert (runs == 0) if cap == 0 else (runs == 3 if cap == 3 else runs > 3), (cap, runs, exc)
+            got[cap] = (dm.vectors()[0].copy(), dm.syn1neg().copy())
+    for cap in (-1, 3):
+        assert np.array_equal(got[cap][0], got[0][0]) and np.array_equal(got[cap][1], got[0][1]), cap
+    assert cosine_rows(got[-1][0], om.syn0).min() > 1 - 1e-4
+    # a larger table over the same vocabulary, several workers: the pair count and the trained rows agree with and without the run form
+    for cap in (-1, 0):
+        c = dge.make_config(32, 6, NV, workers=16, table_size=2000003, update_policy=5)
+        with dge.tuning(table_runs=cap):
+            dm = dge.SgnsModel.fit(walks, c, 0)
+            assert dm.stats()["pairs"] == om.pairs
+            assert cosine_rows(dm.vectors()[0], oracle.train_sgns(walks, NV, 32, 6, table_size=2000003, arith=0).syn0).min() > 0.99
+
+
 def test_locked_policies_match_the_in_order_result(dge, oracle):
     """Policies 5 and 6 (layout with 16 B per lane, the centre's delta summed in LDS) against the oracle: one worker reproduces the
     sequential word2vec result to rounding, 16 workers stay within Hogwild noise."""
