@@ -62,10 +62,10 @@ int main() {
     std::vector<char*> bufs;
     for (int k = 0; k < 12; k++) {
         char* buf = nullptr;
-        CK(hipMalloc((void**)&buf, total + 65536 + 4096));
-        CK(hipMemset(buf, 0, total + 65536 + 4096)); CK(hipDeviceSynchronize());
+        CK(hipMalloc((void**)&buf, total + 2097152 + 4096));
+        CK(hipMemset(buf, 0, total + 2097152 + 4096)); CK(hipDeviceSynchronize());
         printf("allocation %2d:", k);
-        for (uint64_t off : {0, 256, 512, 768, 1024, 2048, 4096, 65536}) printf("  +%llu: %4.0f", (unsigned long long)off, run(buf + off, total, true, sink));
+        for (uint64_t off : {0, 256, 0, 65536, 0, 2097152, 0}) printf("  +%llu: %4.0f", (unsigned long long)off, run(buf + off, total, true, sink));
         printf("\n");
         bufs.push_back(buf);
     }
