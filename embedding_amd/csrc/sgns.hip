@@ -983,6 +983,10 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         p.next_walk = m->d_counters + 2;
         DGE_HIP(hipMemsetAsync(p.next_walk, 0, sizeof(unsigned long long), st));
     }
+    // A launch whose length is one busy row's chain of pairs — forced policy 5 or 6 on a vocabulary with such a row — is bound by a pair's latency, not by
+    // requests, and the 11 dependent LDS reads of the table's run form are slower than a table look-up that hits the caches (15.4-15.9 s against 12.8 s
+    // on the community graph of scripts/quality_scale.py): there the table stays.
+    if (m->hot_rows_serial > 0 && workers > 1) p.n_runs = 0;
     EventPair ev;
     if ((rc = timing_begin(m, ev, 0))) return rc;
     switch (m->stride / 64) {

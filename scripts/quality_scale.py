@@ -89,7 +89,11 @@ if HS:
         m.close()
     sys.exit(0)
 
-for pol in ((2, 7, 0) if ZIPF else (0, 2, 5, 6, 1, 3)):
+import os
+POLICIES = tuple(int(x) for x in os.environ["DGE_QUALITY_POLICIES"].split(",")) if os.environ.get("DGE_QUALITY_POLICIES") else ((2, 7, 0) if ZIPF else (0, 2, 5, 6, 1, 3))
+for kv in filter(None, os.environ.get("DGE_QUALITY_TUNE", "").split(",")):      # e.g. DGE_QUALITY_TUNE=table_runs=0
+    k, v = kv.split("="); E._native.check(E.lib.dge_set_tuning(E.engine.TUNING_KNOBS[k], int(v)))
+for pol in POLICIES:
     cfg = E.make_config(D, L, NV, negative=K, workers=0, update_policy=pol)
     m = E.SgnsModel.create(cfg, counts, 0)
     t = time.time(); m.train(corpus); st = m.stats(); dt = time.time() - t
