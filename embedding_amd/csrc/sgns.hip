@@ -31,7 +31,7 @@
 #include "sgns_model.h"
 
 
-std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
@@ -614,7 +614,7 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         {
             double s2 = 0.0;
             for (int64_t i = 0; i < V; i++) { double q = pow((double)m->h_counts[(size_t)i], power) / twp; s2 += q * q; }
-            m->neg_collision = s2;
+            m->neg_collision = s2; m->neg_norm = twp;
             m->row_share_max = std::max((double)m->h_counts[0] / (double)std::max<int64_t>(tw, 1), pow((double)m->h_counts[0], power) / twp);
             // Head of the vocabulary for the mixed policy (7).  A try-lock fails when another worker holds the row: per pair
             // ~5 syn1neg rows drawn with q_i (unigram^0.75) and one syn0 row that occurs with p_i (unigram), held for the whole
@@ -811,6 +811,29 @@ static int timing_end(dge_model* m, EventPair& ev, int rc_so_far) {
     return DGE_OK;
 }
 
+// Head of the vocabulary inside ONE BLOCK of an n-rank block schedule (dge_model_set_partition).  A block's live rows are the V / n rows of its
+// partition, and a row of the partition takes n times its share of the block's accesses (negatives drawn from the whole table are moved to the
+// partition's row nearest below: n rows' worth of draws; contexts: the pairs whose context lies in the partition), so over the locked rows the
+// expected failures per try-lock are W * 5 * n^2 * sum_{partition}(q_i^2 + p_i^2) ~ W * 5 * n * sum_{all}(q_i^2 + p_i^2): the rule of
+// dge_model_create with the bound divided by n.  And a context row whose own pairs — serialised by its lock — are more than half of what one worker
+// trains in the launch (W * n * p_i > 0.5) goes to the atomics side as well.  Rows [0, head) take atomics, the rest stay under the commit locks.
+static int64_t block_head(dge_model* m, int n, int64_t W) {
+    if (m->block_head_n == n && m->block_head_workers == W) return m->block_head_rows;
+    const double power = 0.75, twp = m->neg_norm, tw = (double)std::max<int64_t>(m->total_words, 1);
+    double tail = 0.0; int64_t H = m->V;
+    const double bound = 0.1 / (5.0 * (double)W * (double)std::max(n, 1));
+    while (H > 0) {
+        const double c = (double)m->h_counts[(size_t)(H - 1)];
+        const double q = pow(c, power) / twp, pp = c / tw;
+        if (tail + q * q + pp * pp >= bound) break;
+        tail += q * q + pp * pp; H--;
+    }
+    int64_t Hs = 0;
+    while (Hs < m->V && (double)W * (double)n * (double)m->h_counts[(size_t)Hs] / tw > 0.5) Hs++;
+    m->block_head_n = n; m->block_head_workers = W; m->block_head_rows = std::max(H, Hs);
+    return m->block_head_rows;
+}
+
 static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32_t L, int64_t walk_index_base, int32_t epoch,
                       int64_t words_before, double words_scale, int64_t total_walks, uint64_t corpus_gen) {
     if (n_rows == 0 || m->V == 0) return DGE_OK;
@@ -919,7 +942,13 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     if (part) {
         // One block of the multi-GPU schedule: the live rows are V/part_n per table, so lock attempts collide part_n times
         // as often as on the whole table (measured on cfg3 with bench.py --sim-ranks, profiles/r01_block_schedule_sim.txt).
-        p.hot_rows = 0;                         // (the head/tail split of policy 7 is not used inside a block)
+        p.hot_rows = 0;
+        // A skewed vocabulary keeps the head / tail split inside a block (round 4; until then such a block ran with float atomics on every row): the
+        // block's own head — block_head, the one-GPU rule with the block's collision rate — by atomics through the workgroup's atomics wave, the tail
+        // under the commit locks.  Two resident workgroups of 12 workers a compute unit (k_sgns_train_locked<HOTMIX, PART>).
+        const int64_t w_mixed = (int64_t)m->n_cus * 2 * 12;
+        const int64_t head_b = (m->cfg.update_policy == 0 || m->cfg.update_policy == 7) && workers > 1 && m->V / m->part_n >= 32768 ? block_head(m, m->part_n, w_mixed) : 0;
+        const int64_t head_knob = g_dge_tuning[DGE_TUNE_HOT_ROWS];
         if (pol == 0) pol = 20;
         else if (m->cfg.update_policy == 0) {
             const double per_worker = 5.0 * m->neg_collision * (double)m->part_n;
@@ -932,12 +961,20 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
                 // per rank against 3.7e8 with the syn0 locks and 3.6e8 with atomics everywhere.
                 pol = 27; p.hot_rows = 0; p.syn0_free = 1;
                 if (m->cfg.workers == 0) { workers = std::min<int64_t>(workers, (int64_t)m->n_cus * 2 * 16); p.n_workers = workers; }
+            } else if (m->V / m->part_n >= 32768 && head_b <= m->V / 4) {
+                // a skewed vocabulary (cfg5, cfg3 with Zipf destinations): the block's head by atomics, its tail under the locks
+                pol = 27; p.hot_rows = (int32_t)head_b; p.syn0_free = 0;
+                if (m->cfg.workers == 0) { workers = std::min<int64_t>(workers, (int64_t)m->n_cus * 2 * 16); p.n_workers = workers; }
             } else pol = 22;
         }
         else if (pol == 2) pol = 22;
         else if (pol == 5) pol = 25;
-        else if (pol == 7) { pol = 27; p.hot_rows = 0; p.syn0_free = 1; }      // locks on syn1neg only (see the auto rule above)
+        else if (pol == 7) { pol = 27; p.hot_rows = (int32_t)head_b; p.syn0_free = 1; }      // locks on syn1neg's tail only (the pair's syn0 row by atomics)
         else DGE_FAIL(DGE_ERR_ARG, "the block schedule runs under update_policy 0 (auto), 2, 3, 5 or 7, not %d", m->cfg.update_policy);
+        if (pol == 27) {
+            if (head_knob >= 0) p.hot_rows = (int32_t)std::min<int64_t>(head_knob, m->V);                                       // ablation knobs
+            if (g_dge_tuning[DGE_TUNE_BLOCK_SYN0_FREE] >= 0) p.syn0_free = g_dge_tuning[DGE_TUNE_BLOCK_SYN0_FREE] > 0 ? 1 : 0;
+        }
     }
     size_t shmem = 0;
     if (hs) {

@@ -26,6 +26,9 @@ struct dge_model {
     double neg_collision = 1.0;                 // sum of squared negative-sampling probabilities: P(two draws hit one row)
     int64_t hot_rows_auto = 0;                  // head rows that policy 7 keeps out of the lock protocol (see dge_model_create)
     int64_t hot_rows_serial = 0;                // head rows whose own pairs, serialised by the row's lock, would outlast a launch
+    double neg_norm = 1.0;                      // sum of count^0.75 over the vocabulary (the unigram table's normaliser)
+    // the same head for one block of an n-rank block schedule (computed on first use, kept per n: block_head in sgns.hip)
+    int32_t block_head_n = 0; int64_t block_head_workers = 0; int64_t block_head_rows = 0;
     int n_cus = 256;
     float *d_syn0 = nullptr, *d_syn1neg = nullptr, *d_snap = nullptr;
     int placed_seen[3] = {0, 0, 0}; double placed_best[3] = {0, 0, 0}, placed_worst[3] = {0, 0, 0};   // table_alloc's report for syn0, syn1neg, syn1: candidates probed, their best and worst rate (GB/s)

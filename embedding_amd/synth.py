@@ -34,7 +34,10 @@ def flow_graph_numpy(R, T, mean_degree, seed=SEED, sigma=1.0, weight_mean=20.0, 
 def flow_graph_torch(R, T, mean_degree, device, seed=SEED, sigma=1.0, weight_mean=20.0, dst="uniform"):
     """Device generator (bench configs: 5 M .. 100 M edges never touch the host).  Returns torch tensors.
     dst = "uniform": destination regions drawn uniformly (the configurations as SURVEY.md §8d specifies them: a flat vocabulary);
-    dst = "zipf": region of rank r drawn with P ~ 1/(r+1) — popular regions, what real trip data looks like: a skewed vocabulary."""
+    dst = "zipf": region of rank r drawn with P ~ 1/(r+1) — popular regions, what real trip data looks like: a skewed vocabulary;
+    dst = "community" / "community_zipf": regions form communities of 64 and 80 % of a vertex's flow stays inside its own; the flow that
+    leaves goes to a uniform / a Zipf-popular region.  A graph WITH structure: what the link-prediction parity checks (held-out walk steps,
+    tests/helpers.py: link_auc_device) need — on uniform destinations nothing generalises and every schedule scores 0.5."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -50,8 +53,19 @@ def flow_graph_torch(R, T, mean_degree, device, seed=SEED, sigma=1.0, weight_mea
         del ur
     elif dst == "uniform":
         dst_region = torch.randint(0, R, (E,), generator=g, device=device, dtype=torch.int32)
+    elif dst in ("community", "community_zipf"):
+        inside = torch.rand(E, generator=g, device=device) < 0.8
+        local = (torch.div(src % R, 64, rounding_mode="floor") * 64 + torch.randint(0, 64, (E,), generator=g, device=device, dtype=torch.int32)).clamp_(max=R - 1)
+        if dst == "community_zipf":
+            ur = torch.rand(E, generator=g, device=device, dtype=torch.float32)
+            anyw = (torch.exp(ur * float(np.log(R + 1.0))) - 1.0).to(torch.int64).clamp_(0, R - 1).to(torch.int32)
+            del ur
+        else:
+            anyw = torch.randint(0, R, (E,), generator=g, device=device, dtype=torch.int32)
+        dst_region = torch.where(inside, local.to(torch.int32), anyw)
+        del inside, local, anyw
     else:
-        raise ValueError("dst must be 'uniform' or 'zipf'")
+        raise ValueError("dst must be 'uniform', 'zipf', 'community' or 'community_zipf'")
     if T > 1:
         layer = torch.div(src, R, rounding_mode="floor")
         dst = ((layer + 1) % T) * R + dst_region

@@ -333,7 +333,8 @@ enum {
     DGE_TUNE_ACC_ROWS = 10,       /* update_policy 7: the hottest rows [0, value) add their syn1neg updates up in LDS (one set of atomics per DGE_TUNE_ACC_DRAIN updates; the kernel caps the value at what its LDS holds, 8 .. 16); default 0 = none: measured it buys 2-4 % and, from 16 updates a flush on, shifts the trained scores */
     DGE_TUNE_ACC_DRAIN = 11,      /* updates of such a row between two flushes (default 16) */
     DGE_TUNE_TABLE_RUNS = 12,     /* the negative-sampling table's run form (dge_model_table_runs): 0 = not built / not used (the lock kernels read the table), N > 0 = built from at most N runs of the vocabulary's tail (tests: the head rows in front stay on the table); default: up to 2 046 runs */
-    DGE_TUNE_COUNT = 13
+    DGE_TUNE_BLOCK_SYN0_FREE = 13, /* block schedule, mixed lock kernel: 1 = the pair's syn0 row is never locked (agent-scope read, atomics), 0 = it is locked unless it is a head row; default: the library's rule */
+    DGE_TUNE_COUNT = 14
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
 int  dge_get_tuning(int32_t knob, int64_t* value);   /* -1 = the library's own rule */

@@ -803,6 +803,15 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 
 int orc_train_sgns(const int32_t* walks, int64_t n_walks, int32_t max_len,
                    const orc_train_config* cfg, orc_model** out) {
+    return orc_train_sgns_from(walks, n_walks, max_len, cfg, NULL, NULL, NULL, out);
+}
+
+/* The same trainer continuing from a given state: `counts` ([n_vertices] token counts of the WHOLE corpus the vocabulary, the
+ * unigram table and total_words come from, instead of the counts of `walks`) and the tables a run has reached so far (rows in the
+ * vocabulary's order).  Used by the statistical parity tests: the device trains a long corpus, hands its tables over, and both
+ * sides then train the same further slice of walks — sequentially here, at full concurrency there. */
+int orc_train_sgns_from(const int32_t* walks, int64_t n_walks, int32_t max_len, const orc_train_config* cfg,
+                        const int64_t* counts, const float* syn0_init, const float* syn1neg_init, orc_model** out) {
     if (!walks || !cfg || !out || cfg->dim <= 0 || cfg->window <= 0 || cfg->negative < 0 ||
         cfg->n_vertices <= 0 || cfg->table_size <= 0 || max_len <= 0) return 1;
     init_exp_table();
@@ -817,6 +826,7 @@ int orc_train_sgns(const int32_t* walks, int64_t n_walks, int32_t max_len,
         if (t >= NV) { free(cnt); free(m); return 2; }
         if (t >= 0) cnt[t]++;
     }
+    if (counts) memcpy(cnt, counts, (size_t)NV * sizeof(int64_t));
     int64_t V = 0;
     for (int32_t v = 0; v < NV; v++) if (cnt[v] >= cfg->min_count && cnt[v] > 0) V++;
     vc_item* items = (vc_item*)malloc((size_t)(V ? V : 1) * sizeof(vc_item));
@@ -848,6 +858,8 @@ int orc_train_sgns(const int32_t* walks, int64_t n_walks, int32_t max_len,
                 m->syn0[a * D + b] = (((r & 0xFFFF) / (float)65536) - 0.5f) / D;
             }
     }
+    if (syn0_init) memcpy(m->syn0, syn0_init, (size_t)(V * D) * sizeof(float));
+    if (syn1neg_init) memcpy(m->syn1neg, syn1neg_init, (size_t)(V * D) * sizeof(float));
 
     /* --- unigram^0.75 table: word2vec.c InitUnigramTable --- */
     const int64_t T = cfg->table_size;

@@ -95,7 +95,10 @@ typedef struct orc_train_config {
 typedef struct orc_model orc_model;
 int   orc_train_sgns(const int32_t* walks, int64_t n_walks, int32_t max_len,
                      const orc_train_config* cfg, orc_model** out);
-/* same, but with an externally fixed vocabulary/state (used for multi-rank tests) */
+/* same, continuing from a given state: counts [n_vertices] of the whole corpus (vocabulary, unigram table, total_words) and the
+ * tables reached so far, rows in the vocabulary's order (count desc, vertex id asc); any of the three may be NULL */
+int   orc_train_sgns_from(const int32_t* walks, int64_t n_walks, int32_t max_len, const orc_train_config* cfg,
+                          const int64_t* counts, const float* syn0_init, const float* syn1neg_init, orc_model** out);
 int64_t orc_model_vocab_size(const orc_model* m);
 int32_t orc_model_dim(const orc_model* m);
 const float*   orc_model_syn0(const orc_model* m);      /* [V x dim] */

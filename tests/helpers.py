@@ -93,3 +93,47 @@ def link_auc(syn0, syn1neg, vocab_ids, test_walks, R, seed=3):
     ok = (ra >= 0) & (rb >= 0) & (rr >= 0); ra, rb, rr = ra[ok], rb[ok], rr[ok]
     pos = (syn0[rb].astype(np.float64) * syn1neg[ra]).sum(1); neg = (syn0[rr].astype(np.float64) * syn1neg[ra]).sum(1)
     return float((pos > neg).mean() + 0.5 * (pos == neg).mean())
+
+
+# ---- device-side helpers of the full-size statistical tests (tables of a million rows never visit the host)
+def device_table(model, table, n_parts=1, part=0):
+    """Rows of partition `part` (row % n_parts == part; n_parts = 1: the whole table) of syn0 (0) / syn1neg (1) as a torch tensor
+    [rows x stride] on the model's device — through the C ABI's partition export, device to device."""
+    import torch
+    pf = model.partition_floats(n_parts)
+    buf = torch.empty(pf, dtype=torch.float32, device=model.torch_device)
+    model.export_partition(table, n_parts, part, buf)
+    stride = -(-model.cfg.dim // 64) * 64
+    return buf.view(-1, stride)
+
+
+def link_scores_device(model, vocab_ids, test_walks, R, NV, seed=3):
+    """Scores syn0[next] . syn1neg[current] of the held-out walk steps of `test_walks` (torch int64 [n x L] on the device) and of a random
+    region of the next vertex's slice instead of it -> (pos, neg) score tensors."""
+    import torch
+    dev = model.torch_device
+    s0 = device_table(model, 0); s1 = device_table(model, 1)
+    vid = torch.from_numpy(vocab_ids.astype(np.int64)).to(dev)
+    remap = -torch.ones(NV, dtype=torch.int64, device=dev); remap[vid] = torch.arange(len(vid), device=dev)
+    a = test_walks[:, :-1].reshape(-1); b = test_walks[:, 1:].reshape(-1)
+    ok = (a >= 0) & (b >= 0); a, b = a[ok], b[ok]
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    rnd = torch.div(b, R, rounding_mode="floor") * R + torch.randint(0, R, (len(b),), generator=gen, device=dev)
+    ra, rb, rr = remap[a], remap[b], remap[rnd]
+    ok = (ra >= 0) & (rb >= 0) & (rr >= 0); ra, rb, rr = ra[ok], rb[ok], rr[ok]
+    pos = torch.empty(len(ra), dtype=torch.float32, device=dev); neg = torch.empty_like(pos)
+    for i in range(0, len(ra), 1 << 20):                      # in slices: the gathered rows of 4.6 M steps would be gigabytes
+        j = slice(i, i + (1 << 20))
+        x = s1[ra[j]]
+        pos[j] = (s0[rb[j]] * x).sum(1); neg[j] = (s0[rr[j]] * x).sum(1)
+    return pos, neg
+
+
+def link_auc_device(model, vocab_ids, test_walks, R, NV, seed=3):
+    """Link-prediction AUC on held-out walk steps (helpers.link_auc, scripts/quality_scale.py) computed on the device, and the mean
+    negative-sampling loss of the same (positive, random-region) score pairs."""
+    import torch
+    pos, neg = link_scores_device(model, vocab_ids, test_walks, R, NV, seed)
+    auc = float((pos > neg).float().mean() + 0.5 * (pos == neg).float().mean())
+    loss = float(torch.nn.functional.softplus(-pos.double()).mean() + torch.nn.functional.softplus(neg.double()).mean())
+    return auc, loss

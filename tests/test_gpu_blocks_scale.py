@@ -1,0 +1,81 @@
+"""GPU: BASELINE.json configs[3] — the 1 M-node / 100 M-edge graph vertex-sharded over 8 ranks — under the block schedule of
+embedding_amd/distributed.py AT FULL SIZE, all 8 ranks' episodes of one global batch run on this one device (8 models; the ring transfer
+becomes a device-to-device copy: helpers.simulate_block_schedule).  Eight GPUs are not available to the suite; every kernel launch, item
+store, partition export / import and learning-rate position of the 8-rank run is.  Reference call site: w2v.fit(), J/DeepWalk.java:79;
+the schedule itself is new (the reference is single-host: SURVEY.md §8e)."""
+import numpy as np
+import pytest
+
+from helpers import device_table, link_auc_device, simulate_block_schedule, simulate_gather_syn0
+
+pytestmark = pytest.mark.gpu
+
+N = 8
+
+
+@pytest.mark.parametrize("dst,expect_one,expect_block", [("community", 5, 8), ("community_zipf", 7, 7)])
+def test_cfg3_full_size_eight_rank_block_schedule(dge, dst, expect_one, expect_block):
+    """41 667 regions x 24 slices = 1 000 008 vertices, ~1e8 edges (communities of 64 regions so that held-out steps are predictable;
+    `community_zipf`: the flow that leaves a community goes to Zipf-popular regions — a skewed vocabulary), D = 128, K = 5, L = W = 24, the
+    vocabulary of the 10 M-walk epoch corpus; one global batch = 8 x 1 000 008 walks, as `bench.py --gpus 8` steps.
+    Asserted: the pairs of all ranks and episodes add up to the one-GPU launch's pair count over the same walks (every pair trained exactly
+    once); rank g moved syn0 rows of partition g only, and all of them that occur in the batch; all ranks end with the same syn1neg; the auto
+    rule resolved to what DESIGN.md §7 says (flat: owner-computes; skewed: the block's head by atomics, its tail under commit locks); and the
+    8-rank embedding predicts held-out walk steps as well as the one-GPU embedding trained on the same walks (AUC within 0.005)."""
+    import torch
+    from embedding_amd import synth
+    R, T, L, D, K = 41667, 24, 24, 128, 5
+    NV = R * T
+    dev = "cuda:0"
+    G = synth.flow_graph_torch(R, T, 100, dev, dst=dst)
+    assert 0.9e8 < G["n_edges"] < 1.1e8
+    g = dge.DeviceGraph(0); g.add_edges_device(G["src"], G["dst"], G["w"]); g.set_sources(G["sources"]); del G
+    torch.cuda.empty_cache()
+    g.build_alias(False)
+    epoch = 10 * NV
+    corpus = g.sample_walks_device(epoch, L, seed=20171106)
+    counts = torch.zeros(NV, dtype=torch.int64, device=dev); corpus.count_tokens(NV, counts)
+    B = N * (epoch // 10)                                                  # the global batch of an 8-rank step
+    test = torch.from_numpy(g.sample_walks(100_000, L, seed=99, rng_mode=1)).to(dev).to(torch.int64)
+    cfg = dge.make_config(D, L, NV, negative=K, workers=0, epochs=1, seed=1)
+
+    one = dge.SgnsModel.create(cfg, counts, 0)
+    vid = one.vectors()[1]
+    V = len(vid)
+    assert V > 900_000
+    init0 = device_table(one, 0).clone()
+    one.train(corpus, 0, B, walk_index_base=0, total_walks=epoch)
+    st1, sch1 = one.stats(), one.schedule()
+    assert sch1["update_policy"] == expect_one, sch1
+    auc1, loss1 = link_auc_device(one, vid, test, R, NV)
+    one.close(); del one
+    torch.cuda.empty_cache()
+
+    ms = [dge.SgnsModel.create(cfg, counts, 0) for _ in range(N)]
+    simulate_block_schedule(ms, lambda m: m.train(corpus, 0, B, walk_index_base=0, total_walks=epoch))
+    sts = [m.stats() for m in ms]
+    assert sum(s["pairs"] for s in sts) == st1["pairs"] > 2.9e9, (sum(s["pairs"] for s in sts), st1["pairs"])
+    assert sum(s["words"] for s in sts) == N * st1["words"]               # every rank counts the batch's words once (its diagonal block)
+    sch = ms[0].schedule()
+    assert sch["update_policy"] == expect_block, sch
+    if expect_block == 7:
+        assert 0 < sch["hot_rows"] <= V // 4, sch                          # the block's own head, derived from the counts
+    # which rows of the batch's walks exist: tokens of the batch, as vocabulary rows
+    sub = torch.zeros(NV, dtype=torch.int64, device=dev); corpus.count_tokens(NV, sub, 0, B)
+    in_batch = (sub[torch.from_numpy(vid.astype(np.int64)).to(dev)] > 0)
+    rows = torch.arange(V, device=dev)
+    for gk, m in enumerate(ms):
+        moved = (device_table(m, 0)[:V] != init0[:V]).any(1)
+        assert not bool((moved & (rows % N != gk)).any()), gk              # a rank's syn0 moves in its own partition only
+        mine = in_batch & (rows % N == gk)
+        assert float(moved[mine].float().mean()) > 0.999, gk              # and every row of it that the batch holds (as a context) moved
+    ref1 = device_table(ms[0], 1)
+    for m in ms[1:]:
+        assert torch.equal(device_table(m, 1), ref1)                      # the partitions came round: one syn1neg everywhere
+    assert bool(torch.isfinite(ref1).all())
+    simulate_gather_syn0(ms)
+    auc8, loss8 = link_auc_device(ms[0], vid, test, R, NV)
+    for m in ms:
+        m.close()
+    assert auc1 > 0.9, (auc1, auc8)
+    assert abs(auc8 - auc1) < 0.005 and abs(loss8 / loss1 - 1) < 0.02, dict(one_gpu=(auc1, loss1), eight_ranks=(auc8, loss8), schedule=sch)

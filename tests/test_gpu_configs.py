@@ -165,7 +165,23 @@ def test_cfg2_shaped_auto_schedule_resolves_to_owner_computes(dge):
     assert res[0]["auc"] > res[2]["auc"] - 0.01, res
 
 
-def test_cfg5_at_full_size(dge, oracle):
+@pytest.fixture(scope="module")
+def cfg5_full(dge):
+    """BASELINE configs[4] at full size: power-law 10 000 008 vertices / ~874 M edges, 24 slices; alias tables built (Vose)."""
+    import torch
+    from embedding_amd import synth
+    R, T = 416667, 24
+    G = synth.powerlaw_flow_graph_torch(R, T, 1_000_000_000, "cuda:0")
+    n_edges = int(G["n_edges"])
+    g = dge.DeviceGraph(0); g.add_edges_device(G["src"], G["dst"], G["w"]); sources = G["sources"]; del G
+    torch.cuda.empty_cache()
+    g.set_sources(sources); g.build_alias(False)
+    yield dict(g=g, R=R, T=T, NV=R * T, n_edges=n_edges, sources=sources)
+    g.close()
+    torch.cuda.empty_cache()
+
+
+def test_cfg5_at_full_size(dge, oracle, cfg5_full):
     """BASELINE configs[4] AT FULL SIZE on one GPU: power-law 10 000 008 vertices / ~874 M edges, 24 slices, D = 256, K = 20, the vocabulary of
     the 10 M-walk epoch corpus, one bench-sized launch (1 000 008 walks) under auto.  Checked: the auto rule resolves to the mixed policy 7 with a
     count-derived head below V/8; pairs and words identities; finite tables in which every trained row moved; and the walk half against the
@@ -174,17 +190,10 @@ def test_cfg5_at_full_size(dge, oracle):
     import ctypes as C
 
     import torch
-    from embedding_amd import synth
-    R, T, L, D, K = 416667, 24, 24, 256, 20
-    NV = R * T
-    G = synth.powerlaw_flow_graph_torch(R, T, 1_000_000_000, "cuda:0")
-    n_edges = int(G["n_edges"])
+    g, R, T, NV, n_edges, sources = (cfg5_full[k] for k in ("g", "R", "T", "NV", "n_edges", "sources"))
+    L, D, K = 24, 256, 20
     assert 8.0e8 < n_edges <= 1.0e9
-    g = dge.DeviceGraph(0); g.add_edges_device(G["src"], G["dst"], G["w"]); sources = G["sources"]; del G
-    torch.cuda.empty_cache()
-    g.set_sources(sources); g.build_alias(False)
     assert g.num_vertices == NV and g.num_edges == n_edges
-
     # ---- walk half vs the oracle
     row_ptr = np.zeros(NV + 1, np.int64); od = np.zeros(NV, np.float64)
     dge._native.check(dge.lib.dge_graph_get_csr(g._h, row_ptr.ctypes.data_as(C.c_void_p), None, None, None, None, od.ctypes.data_as(C.c_void_p), NV, 0))
@@ -232,3 +241,81 @@ def test_cfg5_at_full_size(dge, oracle):
     moved = np.abs(after - before).max(1) > 0
     assert moved[rows].mean() > 0.99 and not moved[~rows].any()                        # rows of the launch's tokens moved (as context rows); no other row did
     assert st["pairs"] / (st["kernel_ms"] * 1e-3) > 5e7                              # and it is the fast path
+    m.close(); corpus.close()
+
+
+def _eight_rank_identities(dge, g, R, T, NV, L, D, K, epoch_walks, batch_walks, n_ranks=8):
+    """One global batch of `batch_walks` walks: the one-GPU launch, then all `n_ranks` ranks' episodes of the block schedule on this device.
+    -> dict(one=(stats, schedule, auc, loss), blocks=(stats per rank, schedule, auc, loss), V)"""
+    import torch
+    from helpers import device_table, link_auc_device, simulate_block_schedule, simulate_gather_syn0
+    dev = "cuda:0"
+    corpus = g.sample_walks_device(epoch_walks, L, seed=20171106)
+    counts = torch.zeros(NV, dtype=torch.int64, device=dev); corpus.count_tokens(NV, counts)
+    test = torch.from_numpy(g.sample_walks(50_000, L, seed=99, rng_mode=1)).to(dev).to(torch.int64)
+    cfg = dge.make_config(D, L, NV, negative=K, workers=0, epochs=1, seed=1)
+    one = dge.SgnsModel.create(cfg, counts, 0)
+    vid = one.vectors()[1]; V = len(vid)
+    init0 = device_table(one, 0).clone()
+    one.train(corpus, 0, batch_walks, walk_index_base=0, total_walks=epoch_walks)
+    st1, sch1 = one.stats(), one.schedule()
+    auc1, loss1 = link_auc_device(one, vid, test, R, NV)
+    one.close(); del one
+    torch.cuda.empty_cache()
+    ms = [dge.SgnsModel.create(cfg, counts, 0) for _ in range(n_ranks)]
+    simulate_block_schedule(ms, lambda m: m.train(corpus, 0, batch_walks, walk_index_base=0, total_walks=epoch_walks))
+    sts = [m.stats() for m in ms]
+    sch = ms[0].schedule()
+    sub = torch.zeros(NV, dtype=torch.int64, device=dev); corpus.count_tokens(NV, sub, 0, batch_walks)
+    in_batch = (sub[torch.from_numpy(vid.astype(np.int64)).to(dev)] > 0)
+    rows = torch.arange(V, device=dev)
+    for gk, m in enumerate(ms):
+        moved = (device_table(m, 0)[:V] != init0[:V]).any(1)
+        assert not bool((moved & (rows % n_ranks != gk)).any()), gk              # a rank's syn0 moves in its own partition only
+        mine = in_batch & (rows % n_ranks == gk)
+        assert float(moved[mine].float().mean()) > 0.99, gk                     # (a walk whose other tokens were all dropped as rare trains nothing)
+    ref1 = device_table(ms[0], 1)
+    assert bool(torch.isfinite(ref1).all())
+    for m in ms[1:]:
+        assert torch.equal(device_table(m, 1), ref1)                              # the partitions came round: one syn1neg everywhere
+    del ref1, init0
+    simulate_gather_syn0(ms)
+    auc8, loss8 = link_auc_device(ms[0], vid, test, R, NV)
+    for m in ms:
+        m.close()
+    corpus.close()
+    torch.cuda.empty_cache()
+    return dict(one=(st1, sch1, auc1, loss1), blocks=(sts, sch, auc8, loss8), V=V)
+
+
+def test_cfg5_full_size_eight_rank_block_schedule(dge, cfg5_full):
+    """BASELINE configs[4] as it is specified — the power-law graph ON 8 RANKS — at full size: all 8 ranks' episodes of one global batch
+    (2 M walks, 7.6e8 pairs) on this device.  The pairs of all ranks and episodes add up to the one-GPU launch's count; a rank's syn0 moves in
+    its partition only, every rank ends with the same syn1neg; and the auto rule keeps the head / tail split INSIDE a block (round 4): the
+    block's own head by atomics, its tail under commit locks — not float atomics on every row."""
+    g, R, T, NV = (cfg5_full[k] for k in ("g", "R", "T", "NV"))
+    r = _eight_rank_identities(dge, g, R, T, NV, 24, 256, 20, epoch_walks=NV, batch_walks=2_000_000)
+    st1, sch1, _, _ = r["one"]; sts, sch, _, _ = r["blocks"]
+    assert sch1["update_policy"] == 7 and r["V"] >= 3_000_000
+    assert sum(s["pairs"] for s in sts) == st1["pairs"] > 6e8, (sum(s["pairs"] for s in sts), st1["pairs"])
+    assert sum(s["words"] for s in sts) == 8 * st1["words"]
+    assert sch["update_policy"] == 7 and 0 < sch["hot_rows"] <= r["V"] // 4, sch
+
+
+def test_cfg5_tenth_size_eight_rank_block_schedule_predicts_like_one_gpu(dge):
+    """configs[4] at 1/10 (1 M vertices, 100 M edges, D = 256, K = 20), one epoch of 1 M walks as ONE global batch: the 8-rank block schedule's
+    embedding predicts held-out walk steps as well as the one-GPU embedding of the same walks (AUC within 0.005), same pair count."""
+    import torch
+    from embedding_amd import synth
+    R, T = 41666, 24
+    NV = R * T
+    G = synth.powerlaw_flow_graph_torch(R, T, 100_000_000, "cuda:0")
+    g = dge.DeviceGraph(0); g.add_edges_device(G["src"], G["dst"], G["w"]); g.set_sources(G["sources"]); del G
+    torch.cuda.empty_cache()
+    g.build_alias(False)
+    r = _eight_rank_identities(dge, g, R, T, NV, 24, 256, 20, epoch_walks=1_000_000, batch_walks=1_000_000)
+    g.close()
+    st1, sch1, auc1, loss1 = r["one"]; sts, sch, auc8, loss8 = r["blocks"]
+    assert sum(s["pairs"] for s in sts) == st1["pairs"] > 3e8
+    assert sch1["update_policy"] == 7 and sch["update_policy"] == 7 and sch["hot_rows"] > 0, (sch1, sch)
+    assert auc1 > 0.6 and abs(auc8 - auc1) < 0.005, dict(one_gpu=(auc1, loss1), eight_ranks=(auc8, loss8), schedule=sch)
