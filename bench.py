@@ -311,6 +311,7 @@ def main():
         pairs_per_launch = st["pairs"] / launches
         achieved = pairs_per_launch * bytes_per_pair / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
         sched = model.schedule()
+        stamp = E.engine.build_stamp()
         kernel_name = ("k_sgns_train<HS>" if args.hs else
                        {5: "k_sgns_train_locked", 6: "k_sgns_train_locked<strict>", 7: "k_sgns_train_locked<head rows by atomics>",
                         2: "k_sgns_train<atomics>", 1: "k_sgns_train<row rmw>", 0: "k_sgns_train<in-order>",
@@ -337,8 +338,8 @@ def main():
                                        else "walk-shard x%d, RCCL all-reduce of deltas per step (comparison mode)" % N if N > 1 else "1 GPU"),
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None if (args.dim or args.negative >= 0 or NB > 1) else measured_traffic(args.workload, "hs" if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch),
-                         "traffic_source": "profiles/traffic.json: bytes per pair from the committed rocprofv3 PMC passes of this workload x the pairs of this run (not counters of this run)",
+                         "traffic": None if (args.dim or args.negative >= 0 or NB > 1) else measured_traffic(args.workload, "hs" if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch, stamp),
+                         "traffic_source": "profiles/traffic.json: bytes per pair from the committed rocprofv3 PMC passes of this workload x the pairs of this run (not counters of this run); null unless those passes were collected with the kernels of the loaded library (build stamp %s)" % json.dumps(stamp),
                          "kernel": kernel_name, "schedule": sched,
                          "ms_per_launch": ms_per_launch,
                          "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
@@ -348,7 +349,7 @@ def main():
                          "row_read_GBps": row_rates and round(row_rates[0], 1), "row_rewrite_GBps": row_rates and round(row_rates[1], 1),
                          # what the lock kernel actually runs against (profiles/r03_shape_sweep.txt): requests at the L2's memory side — reads leave as 128 bytes,
                          # writes as 64 — at ~8.5e10/s in every shape measured; from the committed PMC passes like `traffic`, not from counters of this run
-                         "fabric_requests_per_s": None if (args.dim or args.negative >= 0 or NB > 1) else measured_requests(args.workload, "hs" if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch, ms_per_launch)},
+                         "fabric_requests_per_s": None if (args.dim or args.negative >= 0 or NB > 1) else measured_requests(args.workload, "hs" if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch, ms_per_launch, stamp)},
         }
         if "expect_policy" in wl and not (args.policy or args.workers or args.hs or NB > 1) and sched["update_policy"] != wl["expect_policy"]:
             print("warning: workload %s resolved to policy %d, the committed traffic profile is for policy %d" % (args.workload, sched["update_policy"], wl["expect_policy"]), file=sys.stderr)
@@ -405,29 +406,35 @@ def rendezvous_check(args):
     return 0
 
 
-def measured_traffic(workload, policy, pairs_per_launch):       # policy: "policy5", "policy7", "hs", ...
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE / WRITE_SIZE per pair of the same workload and policy, corrected as profiles/README.md describes).
-    bench.py cannot collect counters itself; None when no profile of this configuration is committed."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
-        return None
-    try:
-        t = json.load(open(path))
-        e = t.get("%s/%s" % (workload, policy))
-        return None if e is None else e["bytes_per_pair"] * pairs_per_launch
-    except (ValueError, KeyError):
-        return None
-
-
-def measured_requests(workload, policy, pairs_per_launch, ms_per_launch):
-    """Requests per second at the L2's memory side: requests per pair from the committed PMC passes (profiles/traffic.json) x this run's pair rate."""
+def _traffic_entry(workload, policy, stamp):
+    """The committed counter profile of (workload, schedule) — or None when there is none, or when it was collected with OTHER kernels than the
+    loaded library's: every entry of profiles/traffic.json carries the source hash of the build it was measured on (`stamp`, written by
+    scripts/traffic_update.py; include/dge.h: dge_build_stamp), `stamp` here is {"kernels": ..., "sorted": ...} of the loaded library.
+    stamp=None skips the comparison (tests)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         e = json.load(open(path)).get("%s/%s" % (workload, policy))
-        return None if not e or "requests_per_pair" not in e or not ms_per_launch else e["requests_per_pair"] * pairs_per_launch / (ms_per_launch * 1e-3)
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError):
         return None
+    if not e or "bytes_per_pair" not in e:
+        return None
+    if stamp is not None and e.get("stamp") != stamp.get("sorted" if policy == "policy8" else "kernels"):
+        return None
+    return e
+
+
+def measured_traffic(workload, policy, pairs_per_launch, stamp=None):       # policy: "policy5", "policy7", "hs", ...
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE / WRITE_SIZE per pair of the same workload and policy, corrected as profiles/README.md describes).
+    bench.py cannot collect counters itself; None when no profile of this configuration AND of this build's kernels is committed."""
+    e = _traffic_entry(workload, policy, stamp)
+    return None if e is None else e["bytes_per_pair"] * pairs_per_launch
+
+
+def measured_requests(workload, policy, pairs_per_launch, ms_per_launch, stamp=None):
+    """Requests per second at the L2's memory side: requests per pair from the committed PMC passes (profiles/traffic.json) x this run's pair rate."""
+    e = _traffic_entry(workload, policy, stamp)
+    return None if not e or "requests_per_pair" not in e or not ms_per_launch else e["requests_per_pair"] * pairs_per_launch / (ms_per_launch * 1e-3)
 
 
 def cpu_baseline(walks, NV, D, L, K, seconds):

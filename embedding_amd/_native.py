@@ -35,6 +35,7 @@ _P = C.POINTER
 SIGNATURES = {
     "dge_last_error": (C.c_char_p, []),
     "dge_version": (_int, []),
+    "dge_build_stamp": (C.c_char_p, []),
     "dge_device_count": (_int, [_P(_int)]),
     "dge_graph_create": (_int, [_P(_vp), _int]),
     "dge_graph_free": (None, [_vp]),

@@ -43,6 +43,14 @@ extern "C" int dge_get_tuning(int32_t knob, int64_t* value) {
     return DGE_OK;
 }
 
+#ifndef DGE_KERNELS_HASH
+#define DGE_KERNELS_HASH "unknown"
+#endif
+#ifndef DGE_SORTED_HASH
+#define DGE_SORTED_HASH "unknown"
+#endif
+extern "C" const char* dge_build_stamp(void) { return "kernels=" DGE_KERNELS_HASH " sorted=" DGE_SORTED_HASH; }
+
 // ------------------------------------------------------------------------------------------ where the tables lie
 // Which memory a table of random rows lies in decides how fast rows can be read AND WRITTEN BACK in it: allocations of half a gigabyte fall into
 // two classes 15 % apart (a microbenchmark of random 512-byte rows read and stored back reaches 6.3 or 7.3 TB/s on them, nothing in between),

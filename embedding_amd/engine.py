@@ -392,6 +392,11 @@ class SgnsModel:
         check(lib.dge_model_import_delta(self._h, _dev_ptr(d_buf), float(scale)))
 
 
+def build_stamp():
+    """{"kernels": hash, "sorted": hash} of the trainer kernels' sources the loaded libdge.so was built from (include/dge.h: dge_build_stamp)."""
+    return dict(kv.split("=") for kv in lib.dge_build_stamp().decode().split())
+
+
 TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7, "hs_cold": 8, "hs_wave": 9, "acc_rows": 10, "acc_drain": 11, "table_runs": 12, "block_syn0_free": 13}      # include/dge.h: DGE_TUNE_*
 
 

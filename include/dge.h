@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DGE_VERSION 103   /* 103: dge_get_tuning, dge_model_tune_placement, dge_model_table_placement, dge_selftest_atomics_wave, tuning knobs 8 .. 11 (additions only) */
+#define DGE_VERSION 104   /* 104: dge_build_stamp, DGE_TUNE_BLOCK_SYN0_FREE; the block schedule keeps a head / tail split on skewed vocabularies (additions only) */
 
 enum {
     DGE_OK = 0,
@@ -48,6 +48,10 @@ typedef struct dge_model dge_model;   /* vocabulary + syn0/syn1neg tables, resid
 
 const char* dge_last_error(void);
 int  dge_version(void);
+/* "kernels=<hash> sorted=<hash>": 12 hex digits of the SHA-1 of the trainer kernels' sources this library was built from (sgns_kernels.h + dge_algos.h;
+   the same + sgns_sorted.hip).  The committed counter profiles (profiles/traffic.json) carry the stamp of the build they were collected with; bench.py
+   quotes a profile's bytes per pair only when the stamp matches the loaded library. */
+const char* dge_build_stamp(void);
 int  dge_device_count(int* n);
 
 /* ------------------------------------------------------------------------------------------------

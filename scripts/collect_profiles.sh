@@ -9,6 +9,7 @@
 #                                               (bench.py --placement-candidates, on by default) runs quarter-size probe launches of the same kernel
 #                                               before the timed region, which rocprofv3's own average includes; this average is the one the bench
 #                                               line's ms_per_launch must agree with
+#   gpurun_out/prof_<tag>/traffic.json          (with TRAFFIC_KEY set) profiles/traffic.json with this workload's entry rewritten from pmc.csv and stamped
 # Counters are collected in their own runs with --kernel-trace only (MI355X_MICROARCH.md, HBM section).
 # One process per rocprofv3: bench.py --gpus N > 1 starts further processes (a launcher hop the pool forbids under the profiler) — refused here;
 # to profile several ranks export RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT and run one rocprofv3 per rank.
@@ -32,4 +33,7 @@ cd $root
 mkdir -p $out/flat; find $out/pmc -name "*.csv" -exec cp {} $out/flat/ \;
 python3 scripts/pmc_digest.py $out/flat "$needle" > $out/pmc.csv
 rm -rf $out/stats $out/pmc $out/flat
+# TRAFFIC_KEY=cfg3/policy5 [TRAFFIC_X2="k_sgns_train_locked"]: rewrite that entry of profiles/traffic.json from the passes just made, stamped with the build's
+# kernel-source hash (scripts/traffic_update.py); the table travels back as $out/traffic.json (gpurun only merges gpurun_out/)
+if [ -n "$TRAFFIC_KEY" ]; then python3 scripts/traffic_update.py "$TRAFFIC_KEY" $out ${TRAFFIC_X2:+--x2 "$TRAFFIC_X2"} && cp profiles/traffic.json $out/traffic.json; fi
 head -3 $out/kernel_stats.csv; cat $out/kernel_timed.txt; cat $out/bench.json | cut -c1-400

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(dge):
 
 def test_struct_layouts(dge):
     assert C.sizeof(dge.TrainConfig) == 64 and C.sizeof(dge.TrainStats) == 40
-    assert dge.lib.dge_version() == 103
+    assert dge.lib.dge_version() == 104
 
 
 def test_no_device_means_loud_failure(dge):
@@ -81,13 +81,24 @@ def test_bench_workloads_and_traffic_table():
     assert {"cfg1", "cfg2", "cfg3", "cfg3_zipf", "cfg5"} <= set(bench.WORKLOADS)
     w = bench.WORKLOADS["cfg3"]
     assert w["R"] * w["T"] == 1000008 and w["dim"] == 128 and w["negative"] == 5 and w["L"] == 24      # the configuration the metric is quoted on
-    assert bench.measured_traffic("cfg3", "policy5", 1000.0) == 6627.0 * 1000.0          # profiles/r03_cfg3_pmc.csv
+    table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    e = table["cfg3/policy5"]
+    assert 6000 < e["bytes_per_pair"] < 7600                                              # the rows of a pair: 7168 algorithmic
+    assert bench.measured_traffic("cfg3", "policy5", 1000.0) == e["bytes_per_pair"] * 1000.0
     assert bench.measured_traffic("cfg5", "policy7", 1.0) > 45056 and bench.measured_traffic("cfg3", "hs", 1.0) > 0
     assert bench.measured_traffic("cfg3", "policy99", 1.0) is None
-    # requests at the L2's memory side: 85.35 a pair at cfg3 (profiles/r03_cfg3_pmc.csv) x the pair rate; None where no profile says
-    assert abs(bench.measured_requests("cfg3", "policy5", 3.8e8, 400.0) - 85.35 * 3.8e8 / 0.4) < 1e3
-    assert bench.measured_requests("cfg5", "policy7", 1.0, 1.0) is None and bench.measured_requests("cfg3", "policy5", 1.0, 0.0) is None
-    table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    # requests at the L2's memory side x the pair rate; None where no profile says
+    assert abs(bench.measured_requests("cfg3", "policy5", 3.8e8, 400.0) - e["requests_per_pair"] * 3.8e8 / 0.4) < 1e3
+    assert bench.measured_requests("cfg3", "policy5", 1.0, 0.0) is None
+    # a profile is only quoted for the kernels it was collected with: the entry's stamp against the loaded library's (dge_build_stamp)
+    import embedding_amd as E
+    stamp = E.engine.build_stamp()
+    assert set(stamp) == {"kernels", "sorted"} and all(re.fullmatch(r"[0-9a-f]{12}", v) for v in stamp.values()), stamp
+    assert bench.measured_traffic("cfg3", "policy5", 1.0, {"kernels": "0" * 12, "sorted": "0" * 12}) is None
+    for key, ent in table.items():
+        if isinstance(ent, dict) and ent.get("stamp") == stamp["sorted" if key.endswith("policy8") else "kernels"]:
+            wl_, pol_ = key.split("/")
+            assert bench.measured_traffic(wl_, pol_, 2.0, stamp) == 2.0 * ent["bytes_per_pair"]
     for name, wl in bench.WORKLOADS.items():                            # a default run of a named workload must find its counters
         if "expect_policy" in wl:
             assert "%s/policy%d" % (name, wl["expect_policy"]) in table, "profiles/traffic.json lacks %s/policy%d" % (name, wl["expect_policy"])
