@@ -77,6 +77,11 @@ def main():
                     help="round 2's whole-model form of the same (SgnsModel.create_placed: this many models side by side, the fastest kept); default 1 = off")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="dge_set_tuning knob for experiments (hot_rows, hs_drain, sorted_chunk, sorted_walks, ...)")
+    ap.add_argument("--epoch", action="store_true",
+                    help="one GPU: DeepWalk.main end to end (J/DeepWalk.java:120-140) instead of steady-state steps — edge tuples in HBM -> CSR -> alias tables "
+                         "-> the epoch's walks -> the one-shot fit (counts, vocabulary, unigram table, tables incl. their placement probes, the placement search "
+                         "where it pays, ONE epoch with the real decaying learning rate) -> the .vec text file; wall clock per stage; the CPU restatement's "
+                         "projected end-to-end time beside it.  Prints one JSON line (not the driver's metric line).")
     ap.add_argument("--rendezvous-check", action="store_true",
                     help="ranks only meet (init_process_group, all-reduce, barrier) and rank 0 prints {\"n_gpus\": N, ...}: checks the "
                          "launcher on a box without a GPU; nothing is measured")
@@ -148,6 +153,11 @@ def main():
     R, T, L, D, K = wl["R"], wl["T"], wl["L"], wl["dim"], wl["negative"]
     NV = R * T
     t0 = time.time()
+
+    if args.epoch:
+        if N != 1:
+            sys.exit("bench.py --epoch is a one-GPU measurement")
+        return run_epoch(args, wl, E, synth, local_rank, dev, stage)
 
     # ---- setup (untimed): replicate the edge store on every GPU, build alias tables
     if wl.get("powerlaw"):
@@ -361,6 +371,80 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_epoch(args, wl, E, synth, local_rank, dev, stage):
+    """DeepWalk.main (J/DeepWalk.java:120-140) end to end on one GPU, wall clock: checkInputFile's walk generation
+    (J/CrossTimeGraph.java:115-124: construct the graph, initiateAliasTables, numSamples walks) and learnEmbedding (:32-83: vocabulary, fit(), writeWordVectors).
+    The input — the (src, dst, weight) tuples the reference reads out of its flow maps — is resident in HBM when the clock starts."""
+    import tempfile
+
+    import numpy as np
+    import torch
+    R, T, L, D, K = wl["R"], wl["T"], wl["L"], wl["dim"], wl["negative"]
+    NV = R * T
+    G = synth.powerlaw_flow_graph_torch(R, T, wl["n_edges"], dev) if wl.get("powerlaw") else synth.flow_graph_torch(R, T, wl["mean_degree"], dev, dst=wl.get("dst", "uniform"))
+    n_edges = int(G["n_edges"])
+    sources = G["sources"] if T > 1 else np.arange(R, dtype=np.int32)
+    epoch_walks = wl["walks_per_vertex"] * NV
+    torch.cuda.synchronize()
+    stage("edge tuples resident: %d" % n_edges)
+    st = {}
+
+    def timed(name, fn):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize(); st[name] = time.perf_counter() - t
+        stage("%s: %.3f s" % (name, st[name]))
+        return r
+
+    g = E.DeviceGraph(local_rank)
+    timed("store_s", lambda: (g.add_edges_device(G["src"], G["dst"], G["w"]), g.set_sources(sources)))
+    del G
+    timed("alias_s", lambda: g.build_alias(exact=False))
+    corpus = timed("walks_s", lambda: g.sample_walks_device(epoch_walks, L, seed=20171106, rng_mode=1, first_index=0))
+    cfg = E.make_config(D, L, NV, negative=K, min_count=2, epochs=1, workers=args.workers, seed=1, update_policy=args.policy, use_hs=args.hs)
+    model = timed("fit_s", lambda: E.SgnsModel.fit(corpus, cfg, local_rank))
+    stats, sched, search = model.stats(), model.schedule(), model.placement_search()
+    vec = os.path.join(tempfile.gettempdir(), "bench_epoch_%d.vec" % os.getpid())
+    timed("vec_s", lambda: model.write_vec(vec))
+    vec_bytes = os.path.getsize(vec)
+    os.unlink(vec)
+    total = sum(st.values())
+    out = {"metric": "DeepWalk.main end to end, one epoch (edges trained per wall-clock second)", "value": stats["pairs"] / total, "unit": "edges/s", "n_gpus": 1,
+           "higher_is_better": True, "dtype": "f32", "data": "synthetic", "epoch_s": total, "stages_s": {k: round(v, 3) for k, v in st.items()},
+           "train_kernel_s": stats["kernel_ms"] * 1e-3, "pairs": stats["pairs"], "walks": epoch_walks, "vec_bytes": vec_bytes,
+           "steady_state_edges_per_s": stats["pairs"] / (stats["kernel_ms"] * 1e-3) if stats["kernel_ms"] else None,
+           "config": {"workload": wl["name"], "vertices": NV, "edges": n_edges, "dim": D, "negatives": K, "walk_len": L, "epochs": 1, "schedule": sched,
+                      "placement_search": search, "table_placement": model.table_placement(), "use_hs": bool(args.hs)}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_epoch_baseline(wl, n_edges, epoch_walks, stats["pairs"], g, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_epoch_baseline(wl, n_edges, epoch_walks, epoch_pairs, g, seconds):
+    """The CPU restatement end to end, PROJECTED from bounded samples (the full epoch would take the oracle ~20 minutes): edge store + alias tables and the walk
+    sampler on the same kind of graph at 1/16 of the regions (both linear in edges / walk steps; single thread, as the reference's walk half is), training
+    on a sample of the device's walks with every core of one GPU's host share (Hogwild; the reference uses 8 workers).  kind "port": not the Java path."""
+    import numpy as np
+    from embedding_amd import synth
+    from oracle import oracle as O
+    O.build()
+    Rs = max(64, wl["R"] // 16)
+    Gs = synth.flow_graph_numpy(Rs, wl["T"], wl.get("mean_degree", 100))
+    t = time.perf_counter()
+    og = O.Graph(); og.add_edges(Gs["src"], Gs["dst"], Gs["w"]); og.set_sources(Gs["sources"] if wl["T"] > 1 else np.arange(Rs, dtype=np.int32)); og.build_alias(False)
+    build_rate = len(Gs["src"]) / (time.perf_counter() - t)                       # edges per second into store + tables
+    nw = 200_000
+    t = time.perf_counter(); og.sample_walks(nw, wl["L"], seed=1, rng_mode=0); walk_rate = nw / (time.perf_counter() - t)
+    del og
+    sample = g.sample_walks(min(epoch_walks, 400_000), wl["L"], seed=20171106, rng_mode=1, first_index=0)
+    tr = cpu_baseline(sample, wl["R"] * wl["T"], wl["dim"], wl["L"], wl["negative"], seconds)
+    proj = n_edges / build_rate + epoch_walks / walk_rate + epoch_pairs / tr["value"]
+    return {"value": epoch_pairs / proj, "unit": "edges/s", "cores": tr["cores"], "kind": "port", "projected_epoch_s": proj,
+            "parts": {"store_and_alias_edges_per_s": build_rate, "walks_per_s_one_thread": walk_rate, "train_edges_per_s": tr["value"]},
+            "sample": "store + alias tables + %d walks on a %d-region x %d-slice graph of the same generator (one thread), training: %s; projected linearly to the epoch; .vec output not included"
+                      % (nw, Rs, wl["T"], tr["sample"])}
 
 
 def launch_ranks(n):

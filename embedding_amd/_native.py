@@ -80,6 +80,7 @@ SIGNATURES = {
     "dge_model_table_placement": (_int, [_vp, _i32, _vp, _vp, _vp]),
     "dge_model_table_runs": (_int, [_vp, _vp, _vp]),
     "dge_model_tune_placement": (_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "dge_model_placement_search": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "dge_model_reset_stats": (_int, [_vp]),
     "dge_model_schedule": (_int, [_vp, _P(_i32), _P(_i64), _P(_i32)]),
     "dge_write_vec": (_int, [_vp, _vp, C.c_char_p, _int]),

@@ -24,6 +24,8 @@
 #include <limits>
 #include <map>
 #include <mutex>
+#include <string>
+#include <thread>
 
 #include "dge_algos.h"
 #include "dge_internal.h"
@@ -1091,10 +1093,17 @@ extern "C" int dge_train_sgns_device(const dge_walks* w, const dge_train_config*
     if (!rc) rc = dge_model_create(w->device, cfg, d_counts, &m);
     dge_dev_free(d_counts);
     if (rc) return rc;
-    // models whose launches are long enough for it to pay get the placement search first (results are unaffected: dge_model_tune_placement)
+    // The placement search first — where it can pay (results are unaffected: dge_model_tune_placement).  A pass of the search is 2 + 4 (candidates - 1)
+    // probe launches of n_probe walks (a model that started well needs one pass), and what it can win is ~10 % of the training launches' time
+    // (profiles/r03_placement.txt): it runs when a tenth of the projected training — epochs x walks — is more than one pass.  The reference's own
+    // iterations(1) fit of cfg3 (10 M walks, 3.9 s) is below that: 1.3 - 8 s of probes would be a net loss there (round-3 verdict); 4 epochs are above.
     if (!rc && cfg->epochs > 0 && cfg->workers != 1 && m->V >= 262144 && w->n >= 262144) {
-        double before = 0, after = 0; int32_t moved = 0;
-        rc = dge_model_tune_placement(m, w, 0, std::min<int64_t>(w->n / 8, 262144), 4, &before, &after, &moved);
+        const int candidates = 4;
+        const int64_t n_probe = std::min<int64_t>(w->n / 8, 262144);
+        if (0.10 * (double)cfg->epochs * (double)w->n > (double)(2 + 4 * (candidates - 1)) * (double)n_probe) {
+            double before = 0, after = 0; int32_t moved = 0;
+            rc = dge_model_tune_placement(m, w, 0, n_probe, candidates, &before, &after, &moved);
+        }
     }
     for (int ep = 0; ep < cfg->epochs && !rc; ep++) rc = dge_model_train(m, w, 0, w->n, 0, ep, 0, 1.0, w->n);
     if (!rc) { hipError_t e = hipStreamSynchronize(m->stream); if (e != hipSuccess) { dge_set_error("training failed: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; } }
@@ -1403,7 +1412,17 @@ extern "C" int dge_model_tune_placement(dge_model* m, const dge_walks* w, int64_
     m->seen_gen = 0;                                           // (the next launch derives its rows again)
     if (rc == DGE_OK) rc = rc2;
     if (ms_before) *ms_before = first; if (ms_after) *ms_after = best; if (arrays_moved) *arrays_moved = moved;
+    m->search_runs++; m->search_ms_before = first; m->search_ms_after = best; m->search_moved = moved;
     return rc;
+}
+
+extern "C" int dge_model_placement_search(const dge_model* m, int32_t* runs, double* ms_before, double* ms_after, int32_t* arrays_moved) {
+    if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_placement_search: null model");
+    if (runs) *runs = m->search_runs;
+    if (ms_before) *ms_before = m->search_ms_before;
+    if (ms_after) *ms_after = m->search_ms_after;
+    if (arrays_moved) *arrays_moved = m->search_moved;
+    return DGE_OK;
 }
 
 extern "C" int dge_model_table_placement(const dge_model* m, int32_t table, int32_t* candidates, double* best_gb_per_s, double* worst_gb_per_s) {
@@ -1439,6 +1458,9 @@ extern "C" int dge_model_reset_stats(dge_model* m) {
     return DGE_OK;
 }
 
+// WordVectorSerializer.writeWordVectors: V lines of D decimal numbers.  At the reference's sizes (6 408 x 20) that is nothing; at cfg3's (10^6 x 128 =
+// 1.3e8 conversions, 1.5 GB of text) one thread formats for ~25 s — longer than the epoch trained.  Rows are formatted in slabs by up to 16 host threads
+// (each row into its own string, the slab written in row order): same bytes as the serial loop.
 extern "C" int dge_write_vec(dge_model* m, const char* const* names, const char* path, int header) {
     if (!m || !path) DGE_FAIL(DGE_ERR_ARG, "dge_write_vec: null argument");
     int rc = sync_tables_to_host(m, true, false);
@@ -1446,14 +1468,35 @@ extern "C" int dge_write_vec(dge_model* m, const char* const* names, const char*
     FILE* f = fopen(path, "w");
     if (!f) DGE_FAIL(DGE_ERR_IO, "dge_write_vec: cannot open %s", path);
     if (header) fprintf(f, "%lld %d\n", (long long)m->V, m->D);
-    for (int64_t r = 0; r < m->V; r++) {
-        int32_t id = m->h_vocab_ids[(size_t)r];
-        if (names && names[id]) fputs(names[id], f); else fprintf(f, "%d", id);
-        const float* v = m->h_syn0.data() + r * m->D;
-        for (int j = 0; j < m->D; j++) fprintf(f, " %.9g", (double)v[j]);
-        fputc('\n', f);
+    const int64_t V = m->V; const int D = m->D;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, 16u), V * (int64_t)D / 65536));
+    const int64_t slab = 4096 * (int64_t)n_thr;                                  // rows formatted before they are written
+    std::vector<std::string> out((size_t)n_thr);
+    bool ok = true;
+    for (int64_t r0 = 0; r0 < V && ok; r0 += slab) {
+        const int64_t r1 = std::min(V, r0 + slab);
+        auto work = [&](int t) {
+            std::string& sbuf = out[(size_t)t]; sbuf.clear();
+            const int64_t a = r0 + (r1 - r0) * t / n_thr, b = r0 + (r1 - r0) * (t + 1) / n_thr;
+            char num[40];
+            for (int64_t r = a; r < b; r++) {
+                const int32_t id = m->h_vocab_ids[(size_t)r];
+                if (names && names[id]) sbuf += names[id]; else { snprintf(num, sizeof(num), "%d", id); sbuf += num; }
+                const float* v = m->h_syn0.data() + r * D;
+                for (int j = 0; j < D; j++) { const int n = snprintf(num, sizeof(num), " %.9g", (double)v[j]); sbuf.append(num, (size_t)n); }
+                sbuf += '\n';
+            }
+        };
+        if (n_thr == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; t++) th.emplace_back(work, t);
+            for (auto& x : th) x.join();
+        }
+        for (int t = 0; t < n_thr && ok; t++) ok = out[(size_t)t].empty() || fwrite(out[(size_t)t].data(), 1, out[(size_t)t].size(), f) == out[(size_t)t].size();
     }
-    if (fclose(f) != 0) DGE_FAIL(DGE_ERR_IO, "dge_write_vec: write to %s failed", path);
+    if (fclose(f) != 0 || !ok) DGE_FAIL(DGE_ERR_IO, "dge_write_vec: write to %s failed", path);
     return DGE_OK;
 }
 

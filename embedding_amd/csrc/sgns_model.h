@@ -63,6 +63,7 @@ struct dge_model {
     double kernel_ms = 0, walk_ms = 0;
     int64_t launches = 0;
     int last_policy = -1; int64_t last_workers = 0; int32_t last_hot_rows = 0;   // what the latest launch ran with
+    int32_t search_runs = 0, search_moved = 0; double search_ms_before = 0, search_ms_after = 0;      // dge_model_tune_placement's latest report
     int32_t part_n = 1, part_ctx = 0, part_tgt = 0;                              // block schedule (dge_model_set_partition)
     const int32_t* seen_rows = nullptr; int64_t seen_n = 0; int32_t seen_L = 0; uint64_t seen_gen = 0;   // what d_sen/d_len/d_wb were derived from
     dge_sorted_work* sorted = nullptr;                                           // update_policy 8 (allocated on first use)

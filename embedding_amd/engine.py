@@ -345,6 +345,13 @@ class SgnsModel:
         check(lib.dge_model_tune_placement(self._h, corpus._h, int(row0), int(n_rows), int(candidates), C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
 
+    def placement_search(self):
+        """{"runs", "probe_ms_before", "probe_ms_after", "arrays_moved"} of the placement search on this model (runs == 0: it never ran — the one-shot
+        fit skips it where it cannot pay)."""
+        n, a, b, mv = C.c_int32(0), C.c_double(0), C.c_double(0), C.c_int32(0)
+        check(lib.dge_model_placement_search(self._h, C.byref(n), C.byref(a), C.byref(b), C.byref(mv)))
+        return {"runs": n.value, "probe_ms_before": a.value, "probe_ms_after": b.value, "arrays_moved": mv.value}
+
     def stats(self):
         s = TrainStats()
         check(lib.dge_model_stats(self._h, C.byref(s)))

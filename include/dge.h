@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DGE_VERSION 104   /* 104: dge_build_stamp, DGE_TUNE_BLOCK_SYN0_FREE; the block schedule keeps a head / tail split on skewed vocabularies (additions only) */
+#define DGE_VERSION 104   /* 104: dge_build_stamp, dge_model_placement_search, DGE_TUNE_BLOCK_SYN0_FREE; the block schedule keeps a head / tail split on skewed vocabularies (additions only) */
 
 enum {
     DGE_OK = 0,
@@ -252,6 +252,9 @@ int  dge_model_table_runs(const dge_model* m, int32_t* n_runs, int32_t* n_except
    through in passes until a pass moves nothing (at most six): 2 + 4 (candidates - 1) probe launches per pass, transiently 2 x the tables' memory.  ms_before / ms_after: probe launch before and after (may be NULL). */
 int  dge_model_tune_placement(dge_model* m, const dge_walks* w, int64_t row0, int64_t n_rows, int32_t candidates, double* ms_before, double* ms_after,
                               int32_t* arrays_moved);
+/* Whether the search has run on this model (the one-shot dge_train_sgns_device runs it only where it can pay: when a tenth of the projected training,
+   epochs x walks, exceeds one pass of probes) and its latest report: probe launch before / after (ms), arrays moved. */
+int  dge_model_placement_search(const dge_model* m, int32_t* runs, double* ms_before, double* ms_after, int32_t* arrays_moved);
 /* what the latest training launch resolved `update_policy` 0 / `workers` 0 to: the policy that ran (0 = in-order plain),
  * the concurrent workers, and for policy 7 the head rows kept out of the lock protocol */
 int  dge_model_schedule(const dge_model* m, int32_t* update_policy, int64_t* workers, int32_t* hot_rows);

@@ -46,7 +46,7 @@ def cosine_rows(a, b):
     return num / np.maximum(den, 1e-300)
 
 
-def simulate_block_schedule(models, train_fn):
+def simulate_block_schedule(models, train_fn, serial=False):
     """The multi-GPU block schedule (embedding_amd/distributed.py: block_schedule_step) with all ranks on ONE device:
     models[g] plays rank g; the all-gather between episodes becomes direct export/import between the models."""
     import torch
@@ -57,6 +57,8 @@ def simulate_block_schedule(models, train_fn):
         for g, m in enumerate(models):
             m.set_partition(N, g, (g + e) % N)
             train_fn(m)
+            if serial:
+                m.stats()                   # drains this model's stream: the ranks' launches of an episode run one after the other, as they would on N devices of their own
         for g, m in enumerate(models):
             m.export_partition(1, N, (g + e) % N, bufs[g])
         for g, m in enumerate(models):

@@ -52,7 +52,7 @@ def test_cfg3_full_size_eight_rank_block_schedule(dge, dst, expect_one, expect_b
     torch.cuda.empty_cache()
 
     ms = [dge.SgnsModel.create(cfg, counts, 0) for _ in range(N)]
-    simulate_block_schedule(ms, lambda m: m.train(corpus, 0, B, walk_index_base=0, total_walks=epoch))
+    simulate_block_schedule(ms, lambda m: m.train(corpus, 0, B, walk_index_base=0, total_walks=epoch), serial=True)
     sts = [m.stats() for m in ms]
     assert sum(s["pairs"] for s in sts) == st1["pairs"] > 2.9e9, (sum(s["pairs"] for s in sts), st1["pairs"])
     assert sum(s["words"] for s in sts) == N * st1["words"]               # every rank counts the batch's words once (its diagonal block)

@@ -263,7 +263,7 @@ def _eight_rank_identities(dge, g, R, T, NV, L, D, K, epoch_walks, batch_walks, 
     one.close(); del one
     torch.cuda.empty_cache()
     ms = [dge.SgnsModel.create(cfg, counts, 0) for _ in range(n_ranks)]
-    simulate_block_schedule(ms, lambda m: m.train(corpus, 0, batch_walks, walk_index_base=0, total_walks=epoch_walks))
+    simulate_block_schedule(ms, lambda m: m.train(corpus, 0, batch_walks, walk_index_base=0, total_walks=epoch_walks), serial=True)
     sts = [m.stats() for m in ms]
     sch = ms[0].schedule()
     sub = torch.zeros(NV, dtype=torch.int64, device=dev); corpus.count_tokens(NV, sub, 0, batch_walks)

@@ -5,7 +5,7 @@ Hogwild schedule, trains pairs in another order than the sequential loop.  Eleme
 (tests/test_gpu_sgns.py, tests/test_gpu_fuzz.py).  Here the full-concurrency launch is measured against the ORACLE on a cfg3-shaped graph
 (24 slices, D = 128, K = 5, L = W = 24, >= 262 144 vocabulary rows so that auto resolves to the lock kernels):
 
-  1. the device trains a long corpus (2.4 M walks, 9e8 pairs) — the embedding leaves word2vec's slow start and predicts held-out walk steps;
+  1. the device trains a long corpus (3 - 4 M walks, 1.1 - 1.5e9 pairs) — the embedding leaves word2vec's slow start and predicts held-out walk steps;
   2. its tables are handed to the oracle (oracle.train_sgns(..., counts, syn0_init, syn1neg_init): orc_train_sgns_from);
   3. BOTH sides then train the same further slice of walks (30 000 walks, 1.1e7 pairs) from that state with the same vocabulary, unigram
      table, learning-rate positions and random streams: the oracle sequentially in word2vec order (the definition), the oracle with the
@@ -24,7 +24,7 @@ from helpers import cosine_rows, link_auc
 pytestmark = pytest.mark.gpu
 
 T, L, D, K = 24, 24, 128, 5
-N_LONG, N_SLICE = 2_400_000, 30_000
+N_SLICE = 30_000
 
 
 def _host_loss(syn0, syn1neg, vocab_ids, test_walks, R, seed=3):
@@ -56,7 +56,8 @@ def runs(dge, oracle):
     out = {}
     pool = cf.ThreadPoolExecutor(max_workers=2)
     pending = {}
-    for name, R, dst in (("flat", 11500, "community"), ("zipf", 14500, "community_zipf")):
+    # flat: 480 000 vertices — auto takes the lock kernel (5) from ~350 000 flat rows on (below, the owner-computes schedule); ~200 tokens per vertex in the long corpus
+    for name, R, dst, N_LONG in (("flat", 20000, "community", 4_000_000), ("zipf", 14500, "community_zipf", 2_900_000)):
         NV = R * T
         G = synth.flow_graph_torch(R, T, 30, dev, dst=dst)
         g = dge.DeviceGraph(0); g.add_edges_device(G["src"], G["dst"], G["w"]); g.set_sources(G["sources"]); del G
@@ -81,7 +82,7 @@ def runs(dge, oracle):
         s0_d = m.vectors()[0]; s1_d = m.syn1neg()
         m.close(); corpus.close(); g.close()
         torch.cuda.empty_cache()
-        out[name] = dict(R=R, NV=NV, vid=vid, test=test, before=(s0_0, s1_0), dev=(s0_d, s1_d), st=st, sch=sch, sch_long=sch_long, kw=kw, sl=sl, V=len(vid))
+        out[name] = dict(R=R, NV=NV, n_long=N_LONG, vid=vid, test=test, before=(s0_0, s1_0), dev=(s0_d, s1_d), st=st, sch=sch, sch_long=sch_long, kw=kw, sl=sl, V=len(vid))
     for name, o in out.items():
         o["cpu8"] = oracle.train_sgns(o["sl"], o["NV"], D, L, threads=8, **o["kw"])
     for name, o in out.items():

@@ -720,19 +720,25 @@ def test_placement_search_leaves_the_model_as_it_was(dge, oracle):
             assert a.stats()["pairs"] == b.stats()["pairs"]
 
 
-def test_one_shot_fit_runs_the_placement_search_on_large_models(dge):
-    """dge_train_sgns_device (w2v.fit()) calls the placement search itself when vocabulary and corpus are large enough for it to pay; the
-    search's probe launches must leave no trace: the pair and word counts are those of create + train on the same corpus."""
+def test_one_shot_fit_runs_the_placement_search_where_it_can_pay(dge):
+    """dge_train_sgns_device (w2v.fit()) calls the placement search itself when vocabulary and corpus are large AND the projected training is long
+    enough for a pass of probes to pay (a tenth of epochs x walks against 14 probe launches): 20 epochs here; the reference's own iterations(1)
+    fit skips it.  The probes must leave no trace: pair and word counts are those of create + train on the same corpus."""
     import torch
     NV, L, n = 300_000, 8, 300_000
     g = torch.Generator(device="cuda:0"); g.manual_seed(7)
     walks = torch.randint(0, NV, (n, L), generator=g, device="cuda:0", dtype=torch.int32).cpu().numpy()
     corpus = dge.WalkCorpus.from_host(walks, 0)
-    cfg = dge.make_config(64, L, NV, workers=0, min_count=1, table_size=1_000_003)
-    a = dge.SgnsModel.fit(corpus, cfg, 0)
     counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0"); corpus.count_tokens(NV, counts)
-    b = dge.SgnsModel.create(cfg, counts, 0); b.train(corpus)
-    sa, sb = a.stats(), b.stats()
-    assert len(a.vectors()[1]) >= 262144                                   # large enough for the search to have run
-    assert sa["pairs"] == sb["pairs"] and sa["words"] == sb["words"] == int(counts.sum().item()) and sa["launches"] == sb["launches"] == 1
-    assert np.isfinite(a.vectors()[0]).all() and a.schedule()["update_policy"] == b.schedule()["update_policy"]
+    for epochs, searched in ((20, True), (1, False)):
+        cfg = dge.make_config(64, L, NV, workers=0, min_count=1, table_size=1_000_003, epochs=epochs)
+        a = dge.SgnsModel.fit(corpus, cfg, 0)
+        b = dge.SgnsModel.create(cfg, counts, 0)
+        for ep in range(epochs):
+            b.train(corpus, epoch=ep)
+        sa, sb = a.stats(), b.stats()
+        assert len(a.vectors()[1]) >= 262144
+        assert (a.placement_search()["runs"] == 1) == searched and b.placement_search()["runs"] == 0, (epochs, a.placement_search())
+        assert sa["pairs"] == sb["pairs"] and sa["words"] == sb["words"] == epochs * int(counts.sum().item()) and sa["launches"] == sb["launches"] == epochs
+        assert np.isfinite(a.vectors()[0]).all() and a.schedule()["update_policy"] == b.schedule()["update_policy"]
+        a.close(); b.close()

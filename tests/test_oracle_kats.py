@@ -411,3 +411,25 @@ def test_update_arithmetic_second_reading_in_numpy_float32(oracle):
         assert np.array_equal(syn1neg.view(np.int32), m1.syn1neg.view(np.int32)), use_hs
         if use_hs and V > 1:
             assert np.array_equal(syn1[:V - 1].view(np.int32), m1.syn1.view(np.int32))
+
+
+def test_oracle_continues_from_a_given_state(oracle):
+    """orc_train_sgns_from (the warm start of tests/test_gpu_quality.py): with the whole corpus' counts, the learning-rate position and the tables a
+    run has reached, training the second half of a corpus continues the run bit for bit — sequentially, and under the hierarchical softmax's
+    negatives-only tables as well."""
+    rng = np.random.default_rng(0)
+    w = rng.integers(0, 50, (200, 6)).astype(np.int32)
+    w[rng.random(w.shape) < 0.05] = -1
+    for arith in (0, 1):
+        kw = dict(negative=5, table_size=1009, arith=arith, seed=3)
+        whole = oracle.train_sgns(w, 50, 16, 6, **kw)
+        cnt = np.bincount(w[w >= 0], minlength=50).astype(np.int64)
+        h1 = oracle.train_sgns(w[:100], 50, 16, 6, counts=cnt, total_walks=200, total_words=whole.total_words, **kw)
+        assert np.array_equal(h1.vocab_ids, whole.vocab_ids) and np.array_equal(h1.table(1009), whole.table(1009))     # the corpus' vocabulary, not the half's
+        words_before = int(np.isin(w[:100], whole.vocab_ids).sum())
+        h2 = oracle.train_sgns(w[100:], 50, 16, 6, counts=cnt, total_walks=200, total_words=whole.total_words, walk_index_base=100,
+                               words_before=words_before, syn0_init=h1.syn0, syn1neg_init=h1.syn1neg, **kw)
+        assert h1.pairs + h2.pairs == whole.pairs
+        assert np.array_equal(h2.syn0.view(np.int32), whole.syn0.view(np.int32)) and np.array_equal(h2.syn1neg.view(np.int32), whole.syn1neg.view(np.int32))
+    with pytest.raises(ValueError):
+        oracle.train_sgns(w, 50, 16, 6, counts=np.zeros(7, np.int64))
