@@ -33,7 +33,7 @@
 #include "sgns_model.h"
 
 
-std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
@@ -1004,6 +1004,19 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     }
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
+    const bool big_tables = (uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull || g_dge_tuning[DGE_TUNE_FORCE_SEGMENTS] > 0;
+    if (pol == 12 && workers > 1 && m->stride <= 128 && L <= 64 && !big_tables && g_dge_tuning[DGE_TUNE_HS_CENTRE] != 0) {
+        // Hierarchical softmax, a wave per centre (k_sgns_train_hsw, round 4): the centre's path nodes stay in the registers of a wave's four groups for all
+        // its contexts and their gathered updates leave once per centre.  `workers` = walks in flight = waves that train: two resident workgroups of three
+        // such waves (and one atomics wave) a compute unit; never more than an eighth of the vocabulary (a wave works on four context rows at a time).
+        pol = 13;
+        if (m->cfg.workers == 0 && !(g_dge_tuning[DGE_TUNE_WORKERS] > 0)) workers = std::max<int64_t>(1, std::min<int64_t>((int64_t)m->n_cus * 2 * 3, std::max<int64_t>(1, m->V / 8)));
+        workers = std::max<int64_t>(1, std::min<int64_t>(workers, n_rows));
+        p.n_workers = workers;
+        blocks = (unsigned)((workers + 2) / 3);
+        // an LDS accumulator now takes one addition per CENTRE (16 pairs' worth on cfg3): drained every 4 additions instead of every 64
+        p.hs_drain = g_dge_tuning[DGE_TUNE_HS_DRAIN] >= 1 ? (int32_t)g_dge_tuning[DGE_TUNE_HS_DRAIN] : 4;
+    }
     // (not on small vocabularies, where the worker count is capped at half the rows and every pair is a latency chain: the reference's own
     //  801 x 8 tract graph with hierarchical softmax runs 407 ms per 6.5e7 pairs on its 3 204 workers, 552 ms on 2 400 workers and a wave)
     if (pol == 12 && workers > 1 && (g_dge_tuning[DGE_TUNE_HS_WAVE] > 0 || (g_dge_tuning[DGE_TUNE_HS_WAVE] < 0 && m->V >= 65536))) {
@@ -1046,7 +1059,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     }
     if ((rc = timing_end(m, ev, DGE_OK))) return rc;
     m->launches++;
-    m->last_policy = pol >= 20 ? pol - 20 : (pol >= 10 ? pol - 10 : pol); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
+    m->last_policy = pol >= 20 ? pol - 20 : (pol == 13 ? 2 : (pol >= 10 ? pol - 10 : pol)); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
     DGE_HIP(hipGetLastError());
     return DGE_OK;
 }

@@ -1348,6 +1348,242 @@ k_sgns_train_locked(TrainParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ hierarchical softmax, a wave per centre (round 4)
+// k_sgns_train<.., HS> trains pair after pair: every (centre, context) pair climbs the centre's whole Huffman path, ~20 inner nodes of 512 bytes each read
+// AND updated per pair, the updates as memory-side float atomics — 10 KB of atomic traffic a pair at 1.13 TB/s: the bound of that kernel (0.49 of the
+// roofline on cfg3, profiles/r01_cfg3_hs_pmc.csv).  But the path belongs to the CENTRE: all contexts of a centre (L = W = 24: 16 on average) meet the same
+// nodes.  Here a WAVE takes a walk centre by centre, its four 16-lane groups share the centre's path (group g holds nodes g, g + 4, g + 8, ... in
+// registers, HSW_NQ of them each: the row as it moves and the update it has gathered), the centre's contexts are trained four at a time (one per group for
+// the negative-sampling half; for the tree half every group applies all four contexts to ITS nodes, context after context, and the four partial
+// "neu" sums meet through cross-group shuffles), and a node's gathered update leaves ONCE PER CENTRE: into the workgroup's LDS accumulators near the
+// root (hot_add), as a plain read-modify-write at the cold end of the tree, through the atomics wave in between.  Per pair the tree half then costs one
+// sixteenth of its reads and of its atomics.  Within the wave the node rows see every update in word2vec's order (context after context); what other
+// waves do to a node meanwhile is seen at the next centre: Hogwild staleness of one centre's pairs.  The negative-sampling half (positive target in
+// registers per group, K negatives by atomics through the atomics wave, the context row by atomics) is that of k_sgns_train<.., 2, .., HS>, draw for draw.
+// Rows move 16 bytes per lane.  Walks of up to 64 tokens, rows of up to 128 floats, more than one worker; everything else runs k_sgns_train.
+#define HSW_NQ 6                 /* path nodes a group holds in registers: 4 x 6 = the 24 nodes nearest the root; deeper ones (rare, cold) go pair by pair */
+template <int DCH>
+__device__ __forceinline__ void hot_addA(float* s_hot, int* s_cnt, int slot, int drain, const TableView& t, int32_t row, int lane, const Row<DCH>& x) {
+    float* a = s_hot + slot * (DCH * 64) + 4 * lane;
+#pragma unroll
+    for (int c = 0; c < DCH; c++) {
+        atomicAdd(a + c * 64 + 0, x.v[c].x); atomicAdd(a + c * 64 + 1, x.v[c].y); atomicAdd(a + c * 64 + 2, x.v[c].z); atomicAdd(a + c * 64 + 3, x.v[c].w);
+    }
+    int n = 0;
+    if (lane == 0) n = atomicAdd(&s_cnt[slot], 1) + 1;
+    n = __shfl(n, 0, 16);
+    if (n % drain == 0) {
+        float* gp = t.base + (size_t)row * (t.row_bytes / 4) + 4 * lane;
+#pragma unroll
+        for (int c = 0; c < DCH; c++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if ((uint32_t)(c * 64 + 4 * lane + m) >= t.valid) continue;
+                const float v = atomicExch(a + c * 64 + m, 0.f);
+                if (v != 0.f) atomicAdd(gp + c * 64 + m, v);
+            }
+    }
+}
+template <int DCH>
+__device__ __forceinline__ void row_add(Row<DCH>& y, const Row<DCH>& x) {
+#pragma unroll
+    for (int c = 0; c < DCH; c++) { y.v[c].x += x.v[c].x; y.v[c].y += x.v[c].y; y.v[c].z += x.v[c].z; y.v[c].w += x.v[c].w; }
+}
+template <int DCH>
+__global__ void __launch_bounds__(256, 2)
+k_sgns_train_hsw(TrainParams p) {
+    __shared__ float s_exp[EXP_TABLE_SIZE];
+    __shared__ __attribute__((aligned(16))) float s_mb[LK_MB_WORKERS * 2 * LkBox<DCH>::FLOATS];
+    __shared__ int s_mb_flag[LK_MB_WORKERS * 2];
+    __shared__ int s_mb_done;
+    for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
+    if (threadIdx.x < LK_MB_WORKERS * 2) s_mb_flag[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_mb_done = 0;
+    float* s_hot = s_dyn;
+    int* s_hot_cnt = (int*)(s_dyn + (size_t)p.hs_n_hot * DCH * 64);
+    for (int i = threadIdx.x; i < p.hs_n_hot * (DCH * 64 + 1); i += blockDim.x) s_dyn[i] = 0.f;   // +0.0f == int 0
+    __syncthreads();
+
+    const int lane = threadIdx.x & 15, grp = (threadIdx.x >> 4) & 3, wl = threadIdx.x & 63;
+    const int wk = threadIdx.x >> 4;                       // this group's message boxes (groups 0 .. 11 train, the fourth wave issues the atomics)
+    const int wv = threadIdx.x >> 6;
+    TableView syn0 = make_view(p.syn0, p.V, p.stride), syn1neg = make_view(p.syn1neg, p.V, p.stride), syn1 = make_view(p.syn1, p.V, p.stride);
+    syn0.valid = syn1neg.valid = syn1.valid = (uint32_t)p.D;
+    const int64_t wave = (int64_t)blockIdx.x * 3 + wv;     // p.n_workers = waves that train
+    if (wv == 3) {
+        const int64_t waves_here = min((int64_t)3, p.n_workers - (int64_t)blockIdx.x * 3);
+        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(waves_here, (int64_t)0) * 4, syn0, syn1neg, syn1);
+    }
+    unsigned n_posts = 0;
+    const int L = p.L, W = p.W, K = p.K;
+    // lane j turns a state into the state j + 1 draws on; (mK, cK): K draws on
+    uint64_t mA = 1, cA = 0;
+    for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
+    uint64_t mK = 1, cK = 0;
+    for (int j = 0; j < K; j++) { mK *= DGE_W2V_MULT; cK = cK * DGE_W2V_MULT + 11; }
+    unsigned long long my_pairs = 0, my_words = 0;
+
+    int64_t w_next = (wv == 3 || wave >= p.n_workers) ? p.n_rows : wave;
+    while (w_next < p.n_rows) {
+        const int64_t w = w_next;
+        if (p.next_walk) {
+            unsigned long long t = 0;
+            if (wl == 0) t = atomicAdd(p.next_walk, 1ull);
+            w_next = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t)) + p.n_workers;
+        } else w_next = w + p.n_workers;
+        const int len = (int)p.len[w];
+        if (len < 2) { my_words += (unsigned long long)max(len, 0); continue; }
+        my_words += (unsigned long long)len;
+        const int32_t tok = wl < len ? p.sen[w * L + wl] : -1;            // lane l of the wave holds token l (L <= 64)
+        const int64_t wbw = p.wb[w];
+        const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
+        float alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
+        if (alpha < p.min_alpha) alpha = p.min_alpha;
+        const int64_t gbase = (p.gidx_base + w) * (int64_t)L;
+
+        for (int i = 0; i < len; i++) {
+            // ---- open centre i: DL4J's window draw, the Huffman path, this group's nodes of it
+            const int32_t word = __builtin_amdgcn_readlane(tok, i);
+            uint64_t s = dge_mix64(p.seed + (uint64_t)(gbase + i));
+            s = s * DGE_W2V_MULT + 11;
+            const int radius = W - (int)dge_fast_mod(s, (uint64_t)W, p.W_magic);
+            const int lo = max(0, i - radius), hi = min(len - 1, i + radius);
+            const int n_ctx = hi - lo;                                    // positions lo .. hi without i
+            if (n_ctx <= 0) continue;
+            const int64_t hs_o = p.hs_off[word];
+            const int P = (int)(p.hs_off[word + 1] - hs_o);
+            const uint64_t hs_bits = p.hs_codes[word];
+            int32_t node[HSW_NQ];
+            Row<DCH> S[HSW_NQ], dS[HSW_NQ];
+#pragma unroll
+            for (int q = 0; q < HSW_NQ; q++) {
+                const int k = 4 * q + grp;
+                node[q] = k < P ? p.hs_points[hs_o + k] : -1;
+                rowA_load<DCH, 16, false>(S[q], syn1, node[q] >= 0 ? node[q] : p.filler_row, lane);
+                row_zero(dS[q]);
+            }
+            Row<DCH> h, dh;                                               // the positive target syn1neg[word]: a copy per group, its gathered update
+            rowA_load<DCH, 16, false>(h, syn1neg, word, lane);
+            row_zero(dh);
+            bool dh_dirty = false;
+
+            for (int base = 0; base < n_ctx; base += 4) {
+                const int n_here = min(4, n_ctx - base);
+                const bool active = grp < n_here;
+                int c = lo + base + grp;
+                if (c >= i) c++;
+                const int32_t last = __shfl(tok, active ? c : 0, 64);
+                Row<DCH> l1, neu;
+                rowA_load<DCH, 16, false>(l1, syn0, active ? last : p.filler_row, lane);
+                row_zero(neu);
+                // ---- negative-sampling half, this group's context: positive target first (word2vec order), then the K negatives of the pair's draws
+                if (active) {
+                    const float f = row_dot(l1, h);
+                    const float g = sgns_g(f, 1.0f, alpha, s_exp);
+                    row_axpy(neu, g, h); row_axpy(h, g, l1); row_axpy(dh, g, l1);
+                    dh_dirty = true;
+                }
+                uint64_t sg = s;                                          // the centre's stream at this pair: grp pairs of K draws on
+                for (int z = 0; z < grp; z++) sg = sg * mK + cK;
+                for (int kd = 0; kd < K; kd += 16) {
+                    const int kc = min(16, K - kd);
+                    const uint64_t sl = sg * mA + cA;
+                    int32_t t = -1;
+                    if (active && lane < kc) {
+                        t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                        if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                        if (t == word) t = -1;
+                    }
+                    sg = shfl16_u64(sl, kc - 1);
+                    float mb_g = 0.f;
+                    for (int b0 = 0; b0 < kc; b0 += NEG_BATCH) {
+                        int32_t tg[NEG_BATCH];
+                        Row<DCH> rr[NEG_BATCH];
+#pragma unroll
+                        for (int q = 0; q < NEG_BATCH; q++) { const int32_t v = __shfl(t, (b0 + q) & 15, 16); tg[q] = (b0 + q < kc) ? v : -1; }
+#pragma unroll
+                        for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16, false>(rr[q], syn1neg, tg[q] >= 0 ? tg[q] : p.filler_row, lane);
+#pragma unroll
+                        for (int q = 0; q < NEG_BATCH; q++)
+                            if (tg[q] >= 0) {
+                                const float f = row_dot(l1, rr[q]);
+                                const float g = sgns_g(f, 0.0f, alpha, s_exp);
+                                row_axpy(neu, g, rr[q]);
+                                if (lane == b0 + q) mb_g = g;
+                            }
+                    }
+                    if ((unsigned)(__ballot(t >= 0) >> (threadIdx.x & 48)) & 0xFFFFu) lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, t, mb_g, l1, lane);
+                }
+                for (int z = 0; z < n_here; z++) s = s * mK + cK;         // the centre's stream behind this round's pairs
+                // ---- tree half: every group applies the round's contexts, one after the other, to ITS nodes of the path
+                for (int j = 0; j < n_here; j++) {
+                    Row<DCH> lj, part;
+#pragma unroll
+                    for (int cc = 0; cc < DCH; cc++) {
+                        lj.v[cc].x = __shfl(l1.v[cc].x, j * 16 + lane, 64); lj.v[cc].y = __shfl(l1.v[cc].y, j * 16 + lane, 64);
+                        lj.v[cc].z = __shfl(l1.v[cc].z, j * 16 + lane, 64); lj.v[cc].w = __shfl(l1.v[cc].w, j * 16 + lane, 64);
+                    }
+                    row_zero(part);
+#pragma unroll
+                    for (int q = 0; q < HSW_NQ; q++)
+                        if (node[q] >= 0) {
+                            const float f = row_dot(lj, S[q]);
+                            if (f > -(float)MAX_EXP && f < (float)MAX_EXP) {      // word2vec.c: outside the table the step is skipped
+                                const int idx = (int)((f + (float)MAX_EXP) * (float)(EXP_TABLE_SIZE / MAX_EXP / 2));
+                                const float code = (float)((hs_bits >> (4 * q + grp)) & 1ULL);
+                                const float g = (1.0f - code - s_exp[idx]) * alpha;
+                                row_axpy(part, g, S[q]); row_axpy(S[q], g, lj); row_axpy(dS[q], g, lj);
+                            }
+                        }
+                    for (int k = 4 * HSW_NQ + grp; k < P; k += 4) {        // beyond the 24 nodes in registers: the deepest, coldest nodes of a long path, pair by pair
+                        const int32_t nd = p.hs_points[hs_o + k];
+                        Row<DCH> r;
+                        rowA_load<DCH, 16, false>(r, syn1, nd, lane);
+                        const float f = row_dot(lj, r);
+                        if (f > -(float)MAX_EXP && f < (float)MAX_EXP) {
+                            const int idx = (int)((f + (float)MAX_EXP) * (float)(EXP_TABLE_SIZE / MAX_EXP / 2));
+                            const float g = (1.0f - (float)((hs_bits >> k) & 1ULL) - s_exp[idx]) * alpha;
+                            row_axpy(part, g, r); row_axpy(r, g, lj);
+                            rowA_store<DCH, 16, false>(r, syn1, nd, lane);
+                        }
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < DCH; cc++) {                      // the four groups' shares of context j's neu
+                        part.v[cc].x += __shfl_xor(part.v[cc].x, 16, 64); part.v[cc].y += __shfl_xor(part.v[cc].y, 16, 64);
+                        part.v[cc].z += __shfl_xor(part.v[cc].z, 16, 64); part.v[cc].w += __shfl_xor(part.v[cc].w, 16, 64);
+                        part.v[cc].x += __shfl_xor(part.v[cc].x, 32, 64); part.v[cc].y += __shfl_xor(part.v[cc].y, 32, 64);
+                        part.v[cc].z += __shfl_xor(part.v[cc].z, 32, 64); part.v[cc].w += __shfl_xor(part.v[cc].w, 32, 64);
+                    }
+                    if (grp == j) row_add(neu, part);
+                }
+                if (active) lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 2, lane == 0 ? last : -1, 1.0f, neu, lane);      // syn0[last] += neu
+            }
+            my_pairs += (unsigned long long)n_ctx;
+            // ---- close the centre: what it gathered leaves once
+            if (dh_dirty) lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, lane == 0 ? word : -1, 1.0f, dh, lane);
+#pragma unroll
+            for (int q = 0; q < HSW_NQ; q++)
+                if (node[q] >= 0) {
+                    if (node[q] >= p.hs_hot0) hot_addA<DCH>(s_hot, s_hot_cnt, node[q] - p.hs_hot0, p.hs_drain, syn1, node[q], lane, dS[q]);
+                    else if (node[q] < p.hs_cold) {
+                        Row<DCH> r;
+                        rowA_load<DCH, 16, false>(r, syn1, node[q], lane);
+                        row_add(r, dS[q]);
+                        rowA_store<DCH, 16, false>(r, syn1, node[q], lane);
+                    } else lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 3, lane == 0 ? node[q] : -1, 1.0f, dS[q], lane);
+                }
+        }
+    }
+    if (wv != 3) {
+        if (wl == 0) {
+            if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
+            if (my_words) atomicAdd(&p.counters[1], my_words);
+        }
+        if (lane == 0 && wave < p.n_workers) __hip_atomic_fetch_add(&s_mb_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // (behind this group's last post)
+    }
+    hot_drain_block(s_hot, p.hs_n_hot * DCH * 64, p.syn1 + (size_t)p.hs_hot0 * (DCH * 64));
+}
+
 template <int DCH, bool BIG>
 static inline void launch_train_b(const TrainParams& p, int pol, unsigned blocks, unsigned threads, size_t shmem, hipStream_t st) {
     switch (pol) {
@@ -1355,6 +1591,7 @@ static inline void launch_train_b(const TrainParams& p, int pol, unsigned blocks
         case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 10: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;    // + hierarchical softmax
         case 12: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, true, false>), dim3(blocks), dim3(threads), shmem, st, p); break;
+        case 13: if constexpr (DCH <= 2 && !BIG) hipLaunchKernelGGL((k_sgns_train_hsw<DCH>), dim3(blocks), dim3(threads), shmem, st, p); break;   // hierarchical softmax, a wave per centre
         case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 7: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;

@@ -79,8 +79,8 @@ if BLOCKS:
     sys.exit(0)
 
 if HS:
-    for name, knobs in (("every inner node under atomics, issued by the workers", {"hs_cold": 0, "hs_wave": 0}), ("cold end of the tree by plain read-modify-write, atomics by the workers", {"hs_wave": 0}),
-                        ("cold end plain, atomics through the atomics wave (default)", {})):
+    for name, knobs in (("pair by pair, cold end plain, atomics through the atomics wave (round 3)", {"hs_centre": 0}),
+                        ("a wave per centre (round 4, default)", {}), ("a wave per centre, LDS accumulators drained every 16 centre additions", {"hs_drain": 16})):
         with E.tuning(**knobs):
             m = E.SgnsModel.create(E.make_config(D, L, NV, negative=K, workers=0, use_hs=True), counts, 0)
             m.train(corpus); st = m.stats()

@@ -56,7 +56,10 @@ def simulate_block_schedule(models, train_fn, serial=False):
     for e in range(N):
         for g, m in enumerate(models):
             m.set_partition(N, g, (g + e) % N)
-            train_fn(m)
+            if train_fn.__code__.co_argcount >= 2:
+                train_fn(m, e)              # (the episode number: learning-rate position by progress)
+            else:
+                train_fn(m)
             if serial:
                 m.stats()                   # drains this model's stream: the ranks' launches of an episode run one after the other, as they would on N devices of their own
         for g, m in enumerate(models):

@@ -96,10 +96,13 @@ def test_full_concurrency_launch_against_the_sequential_oracle(runs, name, polic
     o = runs[name]
     seq, cpu8 = o["seq"], o["cpu8"]
     (b0, b1), (d0, d1) = o["before"], o["dev"]
-    assert o["V"] >= 262144 and o["sch_long"]["update_policy"] == policy, (o["V"], o["sch_long"])
-    assert o["sch"]["update_policy"] == policy and o["sch"]["workers"] >= 9000, o["sch"]          # the headline kernel, device-filling
-    if policy == 7:
-        assert 0 < o["sch"]["hot_rows"] < o["V"] // 8
+    # the lock kernel, device-filling.  On the flat graph auto may keep a handful of busy rows out of the lock protocol (policy 7 with < 64 head rows: a row
+    # whose own pairs, serialised by its lock, would outlast the launch — DESIGN.md section 5.5); on the Zipf graph the head is thousands of rows
+    assert o["V"] >= 262144 and o["sch"] == o["sch_long"] and o["sch"]["workers"] >= 9000, (o["V"], o["sch"], o["sch_long"])
+    if policy == 5:
+        assert o["sch"]["update_policy"] == 5 or (o["sch"]["update_policy"] == 7 and o["sch"]["hot_rows"] < 64), o["sch"]
+    else:
+        assert o["sch"]["update_policy"] == 7 and 1000 < o["sch"]["hot_rows"] < o["V"] // 8, o["sch"]
     assert np.array_equal(seq.vocab_ids, o["vid"]) and o["st"]["pairs"] == seq.pairs == cpu8.pairs > 1.0e7
     assert np.isfinite(d0).all() and np.isfinite(d1).all()
     R, vid, test = o["R"], o["vid"], o["test"]

@@ -514,7 +514,15 @@ def test_hierarchical_softmax_long_paths_and_word2vec_order(dge, oracle):
     assert cosine_rows(dm.vectors()[0], o0.syn0).min() > 1 - 1e-4
 
 
-def test_hierarchical_softmax_hogwild_and_exchange(dge, oracle):
+@pytest.fixture(params=[0, 1], ids=["pair_by_pair", "wave_per_centre"])
+def hs_kernel(request, dge):
+    """Both Hogwild kernels of the hierarchical softmax: k_sgns_train<.., HS> (pair by pair) and k_sgns_train_hsw (a wave per centre, round 4: the
+    default where it applies)."""
+    with dge.tuning(hs_centre=request.param):
+        yield request.param
+
+
+def test_hierarchical_softmax_hogwild_and_exchange(dge, oracle, hs_kernel):
     """Device-filling schedule (memory-side atomics on all three tables, the inner nodes nearest the root combined in LDS):
     it stays closer to the in-order result than the CPU's own 8-thread Hogwild does; few workers track it almost exactly.
     The delta exchange carries syn1 as the third table; policies that cannot run HS are refused."""
@@ -553,7 +561,7 @@ def test_hierarchical_softmax_hogwild_and_exchange(dge, oracle):
         dge.SgnsModel.fit(walks[:100], dge.make_config(32, 6, NV), 0).syn1()
 
 
-def test_hierarchical_softmax_lds_combining_conserves_updates(dge, oracle, monkeypatch):
+def test_hierarchical_softmax_lds_combining_conserves_updates(dge, oracle, monkeypatch, hs_kernel):
     """The root-side LDS accumulators (hot_add): (1) in isolation no addition is lost or doubled, whatever the drain
     period — including "never", where only the block-wide drain at kernel end moves data; (2) in the trainer at a
     vanishing learning rate, where the model is nearly linear in its updates and the syn1 rows are sums over pairs that
@@ -578,6 +586,42 @@ def test_hierarchical_softmax_lds_combining_conserves_updates(dge, oracle, monke
         # the sign of f ~ 0, shows there — hence the wider bound when the root is never refreshed during the run)
         assert cosine_rows(a[busy], b[busy]).min() > 0.998, drain
         assert np.abs(na[busy] / nb[busy] - 1).max() < tol, drain
+
+
+@pytest.mark.parametrize("dim,negative,window", [(20, 5, 8), (128, 5, 24), (64, 20, 5), (100, 0, 24)])
+def test_hierarchical_softmax_wave_per_centre_linear_regime(dge, oracle, dim, negative, window):
+    """k_sgns_train_hsw (a wave per centre; the centre's path nodes in the registers of its four groups, their gathered updates leaving once per centre)
+    with Huffman paths that reach beyond the 24 nodes a wave holds (geometric counts: the rare words sit ~35 levels deep, the deeper nodes go pair by
+    pair), ragged walks of up to 24 tokens, 20 negatives (two draw rounds a pair).  At a vanishing learning rate every row is a sum over the pairs that
+    touch it and barely depends on the order: the Hogwild tables must reproduce the in-order oracle's — every (pair, node) term exactly once, with the
+    right code bit, learning rate and draws."""
+    import torch
+    rng = np.random.default_rng(dim * 131 + negative)
+    NV, n, L = 300, 6000, 24
+    ids = rng.integers(0, NV, (n, L)).astype(np.int32)
+    lens = rng.integers(2, L + 1, n); ids[np.arange(L)[None, :] >= lens[:, None]] = -1
+    counts = rng.integers(1, 5, NV).astype(np.int64)
+    counts[:27] = 2 ** (36 - np.arange(27, dtype=np.int64))                         # a chain of 27 levels above a bushy tail
+    kw = dict(negative=negative, min_count=1, epochs=1, seed=3, table_size=100_003, alpha=1e-6, min_alpha=1e-6)
+    om = oracle.train_sgns(ids, NV, dim, window, threads=1, arith=1, use_hs=True, counts=counts, **kw)
+    longest = max(len(om.code(r)[0]) for r in range(om.V))
+    assert 28 < longest <= 40 and om.V == NV, longest                               # longer than the register-resident part of a path
+    init = oracle.train_sgns(ids[:1], NV, dim, window, threads=1, arith=1, use_hs=True, counts=counts, **dict(kw, alpha=0.0, min_alpha=0.0))
+    corpus = dge.WalkCorpus.from_host(ids, 0)
+    d_counts = torch.from_numpy(counts).to("cuda:0")
+    for centre in (1, 0):
+        with dge.tuning(hs_centre=centre):
+            dm = dge.SgnsModel.create(dge.make_config(dim, window, NV, workers=0, use_hs=True, **kw), d_counts, 0)
+            dm.train(corpus)
+        assert dm.stats()["pairs"] == om.pairs and np.array_equal(dm.vectors()[1], om.vocab_ids)
+        for name, dev_t, orc_t, ini in (("syn0", dm.vectors()[0], om.syn0, init.syn0), ("syn1neg", dm.syn1neg(), om.syn1neg, init.syn1neg), ("syn1", dm.syn1(), om.syn1, init.syn1)):
+            da, db = (dev_t - ini).astype(np.float64), (orc_t - ini).astype(np.float64)
+            nb = np.linalg.norm(db, axis=1)
+            busy = nb > np.percentile(nb[nb > 0], 20)                               # rows with more than a couple of terms (LUT step noise averages out)
+            cos = cosine_rows(da[busy], db[busy])
+            assert cos.min() > 0.99 and np.median(cos) > 0.9999, (name, centre, float(cos.min()), float(np.median(cos)))
+            assert np.abs(np.linalg.norm(da[busy], axis=1) / nb[busy] - 1).max() < 0.05, (name, centre)
+            assert not np.abs(da[nb == 0]).any(), (name, centre)                    # rows the oracle never touched stay untouched
 
 
 # ------------------------------------------------------------------------------------------ multi-GPU block schedule
