@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <charconv>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -1497,7 +1498,8 @@ extern "C" int dge_write_vec(dge_model* m, const char* const* names, const char*
                 const int32_t id = m->h_vocab_ids[(size_t)r];
                 if (names && names[id]) sbuf += names[id]; else { snprintf(num, sizeof(num), "%d", id); sbuf += num; }
                 const float* v = m->h_syn0.data() + r * D;
-                for (int j = 0; j < D; j++) { const int n = snprintf(num, sizeof(num), " %.9g", (double)v[j]); sbuf.append(num, (size_t)n); }
+                // (std::to_chars(double, general, 9) is specified to give printf's "%.9g" — same bytes, half the time)
+                for (int j = 0; j < D; j++) { num[0] = ' '; const auto res = std::to_chars(num + 1, num + sizeof(num), (double)v[j], std::chars_format::general, 9); sbuf.append(num, (size_t)(res.ptr - num)); }
                 sbuf += '\n';
             }
         };

@@ -602,7 +602,7 @@ def test_hierarchical_softmax_wave_per_centre_linear_regime(dge, oracle, dim, ne
     lens = rng.integers(2, L + 1, n); ids[np.arange(L)[None, :] >= lens[:, None]] = -1
     counts = rng.integers(1, 5, NV).astype(np.int64)
     counts[:27] = 2 ** (36 - np.arange(27, dtype=np.int64))                         # a chain of 27 levels above a bushy tail
-    kw = dict(negative=negative, min_count=1, epochs=1, seed=3, table_size=100_003, alpha=1e-6, min_alpha=1e-6)
+    kw = dict(negative=negative, min_count=1, epochs=1, seed=3, table_size=100_003, alpha=1e-5, min_alpha=1e-5)
     om = oracle.train_sgns(ids, NV, dim, window, threads=1, arith=1, use_hs=True, counts=counts, **kw)
     longest = max(len(om.code(r)[0]) for r in range(om.V))
     assert 28 < longest <= 40 and om.V == NV, longest                               # longer than the register-resident part of a path
@@ -619,7 +619,8 @@ def test_hierarchical_softmax_wave_per_centre_linear_regime(dge, oracle, dim, ne
             nb = np.linalg.norm(db, axis=1)
             busy = nb > np.percentile(nb[nb > 0], 20)                               # rows with more than a couple of terms (LUT step noise averages out)
             cos = cosine_rows(da[busy], db[busy])
-            assert cos.min() > 0.99 and np.median(cos) > 0.9999, (name, centre, float(cos.min()), float(np.median(cos)))
+            # (not 1.0: a row is its initial value plus thousands of additions ~1e4 times smaller — float32 rounds each, in another order here)
+            assert cos.min() > 0.99 and np.median(cos) > 0.9995, (name, centre, float(cos.min()), float(np.median(cos)))
             assert np.abs(np.linalg.norm(da[busy], axis=1) / nb[busy] - 1).max() < 0.05, (name, centre)
             assert not np.abs(da[nb == 0]).any(), (name, centre)                    # rows the oracle never touched stay untouched
 
