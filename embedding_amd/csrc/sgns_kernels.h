@@ -622,7 +622,11 @@ k_sgns_train(TrainParams p) {
     // through two bit masks over the walk's tokens, so a block costs what its own pairs cost.  Every pair draws from
     // its own stream (seeded from the centre's stream and the context position): the draws of a pair do not depend on
     // which other pairs of the centre this block trains.
-    uint64_t ctx_mask = 0, tgt_mask = 0, pair_mask = 0, s_centre = 0;
+    // PART with HS: EVERY centre is visited in every block — for the inner nodes of its path that lie in partition part_tgt (inner-node rows are split by
+    // node % n like vocabulary rows; the syn1 partition travels the ring with the syn1neg partition of the same number); the negative-sampling terms of a
+    // pair stay with the block of its centre's partition (is_tgt)
+    uint64_t ctx_mask = 0, tgt_mask = 0, cen_mask = 0, pair_mask = 0, s_centre = 0;
+    bool is_tgt = true;
     int nx_len = 0; int64_t nx_wb = 0; int32_t nx0 = -1, nx1 = -1, nx2 = -1, nx3 = -1;
 
     // ---- per-worker state: walk w, centre i, next context c (contexts are c..c_hi without i)
@@ -655,7 +659,7 @@ k_sgns_train(TrainParams p) {
         bool new_centre = false, alive = true;
         while (c > c_hi) {
             DGE_CLOSE_CENTRE();
-            if (PART) i = first_bit_from(tgt_mask, i + 1, len); else i++;
+            if (PART) i = first_bit_from(cen_mask, i + 1, len); else i++;
             while (i >= len) {                             // next walk of this worker (empty walks are skipped)
                 w = w_next;
                 if (w >= p.n_rows) { alive = false; break; }
@@ -682,7 +686,8 @@ k_sgns_train(TrainParams p) {
                     if (PART) {
                         ctx_mask = part_token_mask(tk0, tk1, tk2, tk3, p.part_n, p.part_ctx);
                         tgt_mask = part_token_mask(tk0, tk1, tk2, tk3, p.part_n, p.part_tgt);
-                        i = first_bit_from(tgt_mask, 0, len);
+                        cen_mask = HS ? (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) : tgt_mask;
+                        i = first_bit_from(cen_mask, 0, len);
                     }
                     // learning rate from the exact number of in-vocabulary tokens that precede this walk
                     const int64_t wbw = PART ? wb_next : p.wb[w];
@@ -704,6 +709,7 @@ k_sgns_train(TrainParams p) {
             if (c == i) c++;
             new_centre = true;
             if (PART) {
+                is_tgt = !HS || ((tgt_mask >> i) & 1ull) != 0;
                 s_centre = s;
                 pair_mask = ctx_mask & ~(1ull << i) & (c < 64 ? (~0ull << c) : 0ull);
                 if (c_hi < 63) pair_mask &= (1ull << (c_hi + 1)) - 1ull;
@@ -719,7 +725,7 @@ k_sgns_train(TrainParams p) {
         Row<DCH> l1, neu;
         DGE_SOLO_WAIT();
         row_load<DCH, P::LOAD_AUX, BIG>(l1, syn0, last, lane);
-        if (new_centre) {
+        if (new_centre && (!PART || is_tgt)) {
             row_load<DCH, P::LOAD_AUX, BIG>(h, syn1neg, word, lane);
             if (P::ATOMIC) row_zero(dh);
         }
@@ -731,7 +737,8 @@ k_sgns_train(TrainParams p) {
             // sequential result.
             for (int kd = 0; kd < hs_n; kd += 16) {
                 const int kc = min(16, hs_n - kd);
-                const int32_t t = lane < kc ? p.hs_points[hs_o + kd + lane] : -1;
+                int32_t t = lane < kc ? p.hs_points[hs_o + kd + lane] : -1;
+                if (PART && t >= 0 && t % p.part_n != p.part_tgt) t = -1;          // another block's inner node
                 float mb_g = 0.f; bool mb_mine = false;      // atomics wave: this lane's node of the round takes atomics, with this step
                 for (int base = 0; base < kc; base += NEG_BATCH) {
                     int32_t tg[NEG_BATCH];
@@ -741,6 +748,7 @@ k_sgns_train(TrainParams p) {
                         int32_t v = __shfl(t, (base + q) & 15, 16);
                         tg[q] = (base + q < kc) ? v : -1;
                     }
+                    if (PART) { bool any = false; _Pragma("unroll") for (int q = 0; q < NEG_BATCH; q++) any |= tg[q] >= 0; if (!any) continue; }
 #pragma unroll
                     for (int q = 0; q < NEG_BATCH; q++) row_load<DCH, P::LOAD_AUX, BIG>(rr[q], syn1, tg[q] >= 0 ? tg[q] : (BIG ? 0 : p.filler_row), lane);
 #pragma unroll
@@ -772,7 +780,7 @@ k_sgns_train(TrainParams p) {
                 if (use_mb && ((unsigned)(__ballot(mb_mine) >> (threadIdx.x & 48)) & 0xFFFFu)) lk_post4<DCH>(s_mb, s_mb_flag, wk, n_posts, 3, mb_mine ? t : -1, mb_g, l1, lane);
             }
         }
-        {   // d == 0: target = word, label 1 (word2vec order: positive first)
+        if (!PART || is_tgt) {   // d == 0: target = word, label 1 (word2vec order: positive first)
             float f = row_dot(l1, h);
             float g = sgns_g(f, 1.0f, alpha, s_exp);
             row_axpy(neu, g, h);
@@ -780,7 +788,7 @@ k_sgns_train(TrainParams p) {
             if (P::ATOMIC) row_axpy(dh, g, l1);
             h_dirty = true;
         }
-        for (int kd = 0; kd < K; kd += 16) {
+        for (int kd = 0; kd < K && (!PART || is_tgt); kd += 16) {
             const int kc = min(16, K - kd);
             // lane j draws negative kd+j
             const uint64_t sl = s * mA + cA;
@@ -846,7 +854,7 @@ k_sgns_train(TrainParams p) {
             }
             row_store<DCH, P::STORE_AUX, BIG>(l1, syn0, last, lane);
         }
-        my_pairs++;
+        if (!PART || is_tgt) my_pairs++;
         if (PART) {
             pair_mask &= pair_mask - 1ull;
             c = first_bit_from(pair_mask, 0, c_hi + 1);
@@ -1535,16 +1543,23 @@ k_sgns_train_hsw(TrainParams p) {
                                 row_axpy(part, g, S[q]); row_axpy(S[q], g, lj); row_axpy(dS[q], g, lj);
                             }
                         }
-                    for (int k = 4 * HSW_NQ + grp; k < P; k += 4) {        // beyond the 24 nodes in registers: the deepest, coldest nodes of a long path, pair by pair
-                        const int32_t nd = p.hs_points[hs_o + k];
-                        Row<DCH> r;
+                    for (int k = 4 * HSW_NQ + grp; k < P; k += 4) {        // beyond the 24 nodes in registers: the deepest nodes of a long path, pair by pair —
+                        const int32_t nd = p.hs_points[hs_o + k];          // cold ones as a rule, but a chain-like tree (very skewed counts) has busy nodes down there too:
+                        Row<DCH> r;                                        // each node is updated the way its class is updated everywhere else
                         rowA_load<DCH, 16, false>(r, syn1, nd, lane);
                         const float f = row_dot(lj, r);
                         if (f > -(float)MAX_EXP && f < (float)MAX_EXP) {
                             const int idx = (int)((f + (float)MAX_EXP) * (float)(EXP_TABLE_SIZE / MAX_EXP / 2));
                             const float g = (1.0f - (float)((hs_bits >> k) & 1ULL) - s_exp[idx]) * alpha;
-                            row_axpy(part, g, r); row_axpy(r, g, lj);
-                            rowA_store<DCH, 16, false>(r, syn1, nd, lane);
+                            row_axpy(part, g, r);
+                            if (nd >= p.hs_hot0) {
+                                Row<DCH> gl;
+                                row_zero(gl); row_axpy(gl, g, lj);
+                                hot_addA<DCH>(s_hot, s_hot_cnt, nd - p.hs_hot0, p.hs_drain, syn1, nd, lane, gl);
+                            } else if (nd < p.hs_cold) {
+                                row_axpy(r, g, lj);
+                                rowA_store<DCH, 16, false>(r, syn1, nd, lane);
+                            } else rowA_atomic_axpy<DCH>(syn1, nd, lane, g, lj);
                         }
                     }
 #pragma unroll
@@ -1598,6 +1613,8 @@ static inline void launch_train_b(const TrainParams& p, int pol, unsigned blocks
         // block schedule of the multi-GPU path (dge_model_set_partition): in-order, atomics, commit locks
         case 20: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 22: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 30: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, true, true>), dim3(blocks), dim3(threads), 0, st, p); break;      // ... with the hierarchical softmax
+        case 32: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, true, true>), dim3(blocks), dim3(threads), shmem, st, p); break;
         case 25: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 27: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true, true>), dim3(blocks), dim3(threads), 0, st, p); break;
         default: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;

@@ -600,7 +600,11 @@ static int64_t train_walk(const orc_train_config* cfg, orc_model* m, const int32
     for (int i = 0; i < len; i++) {
         int32_t word = sen[i];
         if (word < 0) continue;
-        if (PN > 1 && word % PN != part_tgt) continue;       /* another block's centre */
+        /* block schedule: the negative-sampling terms of a pair belong to the block of its centre's partition; with the hierarchical softmax every
+           centre is visited in every block for the inner nodes of ITS path that lie in partition part_tgt (inner-node rows are split by node % n like
+           the vocabulary rows, and the syn1 partition travels the ring with the syn1neg partition of the same number) */
+        const int is_tgt = PN <= 1 || word % PN == part_tgt;
+        if (!is_tgt && !cfg->use_hs) continue;               /* another block's centre */
         uint64_t s = orc_mix64(cfg->seed + (uint64_t)(gidx_base + i));
         s = s * W2V_MULT + 11;
         int b = (int)(s % (uint64_t)W);
@@ -619,6 +623,7 @@ static int64_t train_walk(const orc_train_config* cfg, orc_model* m, const int32
             for (int k = 0; k < D; k++) neu1e[k] = 0;
             if (cfg->use_hs)                       /* word2vec.c: HIERARCHICAL SOFTMAX, before the negative sampling */
                 for (int d = 0; d < m->codelen[word]; d++) {
+                    if (PN > 1 && m->points[(int64_t)word * MAX_CODE_LENGTH + d] % PN != part_tgt) continue;      /* another block's inner node */
                     float* l2 = m->syn1 + (int64_t)m->points[(int64_t)word * MAX_CODE_LENGTH + d] * D;
                     float f = cfg->arith ? dot_lane16(l1, l2, D) : dot_seq(l1, l2, D);
                     if (f <= -MAX_EXP) continue;
@@ -633,7 +638,7 @@ static int64_t train_walk(const orc_train_config* cfg, orc_model* m, const int32
                         for (int k = 0; k < D; k++) l2[k] += g * l1[k];
                     }
                 }
-            for (int d = 0; d < K + 1; d++) {
+            for (int d = 0; d < K + 1 && is_tgt; d++) {
                 int64_t target; float label;
                 if (d == 0) { target = word; label = 1; }
                 else {
@@ -659,7 +664,7 @@ static int64_t train_walk(const orc_train_config* cfg, orc_model* m, const int32
                 }
             }
             for (int k = 0; k < D; k++) l1[k] += neu1e[k];
-            pairs++;
+            pairs += is_tgt;
         }
     }
     return pairs;
