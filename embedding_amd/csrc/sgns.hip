@@ -887,7 +887,6 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     if (g_dge_tuning[DGE_TUNE_SEGMENT_SHIFT] >= 0) p.big_seg_shift = (int32_t)g_dge_tuning[DGE_TUNE_SEGMENT_SHIFT];   // tests: several segments on a small table
     const bool part = m->part_n > 1;
     const bool hs = m->cfg.use_hs != 0;
-    if (part && hs) DGE_FAIL(DGE_ERR_STATE, "the block schedule (dge_model_set_partition) cannot carry the hierarchical-softmax term: a Huffman path crosses every partition");
 
     // auto: where the Hogwild kernels are bound by contention on a FLAT vocabulary — one too small for row locks (they fall back to
     // atomics: cfg2), a block of a schedule of 3 and more ranks (V/N live rows per table) — the owner-computes schedule is the faster
@@ -960,7 +959,10 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         const int64_t w_mixed = (int64_t)m->n_cus * 2 * 12;
         const int64_t head_b = (m->cfg.update_policy == 0 || m->cfg.update_policy == 7) && workers > 1 && m->V / m->part_n >= 32768 ? block_head(m, m->part_n, w_mixed) : 0;
         const int64_t head_knob = g_dge_tuning[DGE_TUNE_HOT_ROWS];
-        if (pol == 0) pol = 20;
+        // with the hierarchical softmax (round 4): the in-order schedule or memory-side atomics, as on one GPU — inner-node rows are split by node % n like the
+        // vocabulary rows, every block visits every centre for the path nodes of its target partition (k_sgns_train<.., HS, PART>)
+        if (hs) pol = pol == 0 ? 20 : 22;
+        else if (pol == 0) pol = 20;
         else if (m->cfg.update_policy == 0) {
             const double per_worker = 5.0 * m->neg_collision * (double)m->part_n;
             const int64_t w_max = per_worker > 0 ? (int64_t)(0.37 / per_worker) / 256 * 256 : workers;
@@ -989,8 +991,8 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     }
     size_t shmem = 0;
     if (hs) {
-        pol = pol == 0 ? 10 : 12;               // dge_model_create admitted policies 0/2/3 only
-        if (pol == 12 && workers > 1) {         // (one worker: the sequential schedule — no LDS accumulators, no cold class, every node by atomics it waits for)
+        pol = pol == 0 ? 10 : (pol == 20 ? 30 : (pol == 22 ? 32 : 12));      // dge_model_create admitted policies 0/2/3 only; 30 / 32: one block of the multi-GPU schedule
+        if ((pol == 12 || pol == 32) && workers > 1) {         // (one worker: the sequential schedule — no LDS accumulators, no cold class, every node by atomics it waits for)
             // LDS accumulators for the inner nodes nearest the root: 30 KB a block (3 blocks a CU stay resident beside the atomics wave's boxes)
             const int64_t row_b = (int64_t)m->stride * 4 + 4;
             p.hs_n_hot = (int32_t)std::min<int64_t>(std::max<int64_t>(m->V - 1, 0), 30720 / row_b);
@@ -1020,7 +1022,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     }
     // (not on small vocabularies, where the worker count is capped at half the rows and every pair is a latency chain: the reference's own
     //  801 x 8 tract graph with hierarchical softmax runs 407 ms per 6.5e7 pairs on its 3 204 workers, 552 ms on 2 400 workers and a wave)
-    if (pol == 12 && workers > 1 && (g_dge_tuning[DGE_TUNE_HS_WAVE] > 0 || (g_dge_tuning[DGE_TUNE_HS_WAVE] < 0 && m->V >= 65536))) {
+    if ((pol == 12 || pol == 32) && workers > 1 && (g_dge_tuning[DGE_TUNE_HS_WAVE] > 0 || (g_dge_tuning[DGE_TUNE_HS_WAVE] < 0 && m->V >= 65536))) {
         // hierarchical softmax under atomics: every workgroup's fourth wave issues the atomics of its 12 workers (k_sgns_train, lk_atomics_wave)
         p.hs_wave = 1;
         // (three workgroups a compute unit stay resident next to their LDS accumulators and message boxes: DGE_HS_WAVES)
@@ -1060,7 +1062,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     }
     if ((rc = timing_end(m, ev, DGE_OK))) return rc;
     m->launches++;
-    m->last_policy = pol >= 20 ? pol - 20 : (pol == 13 ? 2 : (pol >= 10 ? pol - 10 : pol)); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
+    m->last_policy = pol >= 30 ? pol - 30 : (pol >= 20 ? pol - 20 : (pol == 13 ? 2 : (pol >= 10 ? pol - 10 : pol))); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
     DGE_HIP(hipGetLastError());
     return DGE_OK;
 }
@@ -1552,10 +1554,11 @@ extern "C" int dge_model_partition_floats(const dge_model* m, int32_t n_parts, i
 }
 
 static int partition_copy(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf, bool pack) {
-    if (!m || !d_buf || n_parts <= 0 || part < 0 || part >= n_parts || (table != 0 && table != 1)) DGE_FAIL(DGE_ERR_ARG, "dge_model_%s_partition: bad argument", pack ? "export" : "import");
+    if (!m || !d_buf || n_parts <= 0 || part < 0 || part >= n_parts || table < 0 || table > 2) DGE_FAIL(DGE_ERR_ARG, "dge_model_%s_partition: bad argument", pack ? "export" : "import");
+    if (table == 2 && !m->d_syn1) DGE_FAIL(DGE_ERR_STATE, "dge_model_%s_partition: table 2 (syn1) exists with use_hs only", pack ? "export" : "import");
     DGE_HIP(hipSetDevice(m->device));
     if (!pack) DGE_HIP(hipDeviceSynchronize());          // d_buf comes from the caller's collective, on the caller's stream
-    float* tab = table == 0 ? m->d_syn0 : m->d_syn1neg;
+    float* tab = table == 0 ? m->d_syn0 : (table == 1 ? m->d_syn1neg : m->d_syn1);
     const int64_t rows = (m->V + n_parts - 1) / n_parts;
     if (rows > 0) {
         if (pack) hipLaunchKernelGGL(k_partition_pack, dim3(2048), dim3(256), 0, m->stream, tab, d_buf, m->V, m->stride, n_parts, part, rows);
@@ -1740,21 +1743,25 @@ extern "C" int dge_model_ring_pass(dge_model* m, dge_comm* c, int32_t episode) {
     int64_t pf = 0;
     int rc = dge_model_partition_floats(m, c->nranks, &pf);
     if (rc) return rc;
-    if ((rc = comm_buffers(m, c, 2 * pf))) return rc;
-    float* mine = c->d_buf; float* next = c->d_buf + pf;
-    if ((rc = dge_model_export_partition(m, 1, c->nranks, (c->rank + episode) % c->nranks, mine))) return rc;
+    const int n_tab = m->d_syn1 ? 2 : 1;                   // with the hierarchical softmax the syn1 partition of the same number travels along
+    if ((rc = comm_buffers(m, c, 2 * pf * n_tab))) return rc;
+    float* mine = c->d_buf; float* next = c->d_buf + pf * n_tab;
+    for (int t = 0; t < n_tab; t++)
+        if ((rc = dge_model_export_partition(m, 1 + t, c->nranks, (c->rank + episode) % c->nranks, mine + t * pf))) return rc;
     const int dst = (c->rank + c->nranks - 1) % c->nranks, src = (c->rank + 1) % c->nranks;
     int n = g_rccl.GroupStart();
-    if (!n) n = g_rccl.Send(mine, (size_t)pf, ncclFloat32, dst, c->nccl, m->stream);
-    if (!n) n = g_rccl.Recv(next, (size_t)pf, ncclFloat32, src, c->nccl, m->stream);
+    if (!n) n = g_rccl.Send(mine, (size_t)(pf * n_tab), ncclFloat32, dst, c->nccl, m->stream);
+    if (!n) n = g_rccl.Recv(next, (size_t)(pf * n_tab), ncclFloat32, src, c->nccl, m->stream);
     const int n2 = g_rccl.GroupEnd();
     if (n || n2) return rccl_fail(n ? n : n2, "ncclSend/ncclRecv");
     DGE_HIP(hipStreamSynchronize(m->stream));
-    return dge_model_import_partition(m, 1, c->nranks, (c->rank + 1 + episode) % c->nranks, next);
+    for (int t = 0; t < n_tab; t++)
+        if ((rc = dge_model_import_partition(m, 1 + t, c->nranks, (c->rank + 1 + episode) % c->nranks, next + t * pf))) return rc;
+    return DGE_OK;
 }
 
 extern "C" int dge_model_gather_table(dge_model* m, dge_comm* c, int table) {
-    if (!m || !c || (table != 0 && table != 1)) DGE_FAIL(DGE_ERR_ARG, "dge_model_gather_table: bad argument");
+    if (!m || !c || table < 0 || table > 2 || (table == 2 && !m->d_syn1)) DGE_FAIL(DGE_ERR_ARG, "dge_model_gather_table: bad argument");
     if (c->device != m->device) DGE_FAIL(DGE_ERR_ARG, "dge_model_gather_table: communicator and model live on different devices");
     DGE_HIP(hipSetDevice(m->device));
     int64_t pf = 0;

@@ -178,19 +178,21 @@ def block_schedule_step(model, train_fn, world, rank, part_buf=None, recv_buf=No
         recv_buf = torch.empty(pf, dtype=torch.float32, device=dev)
     if not isinstance(transport, RingTransport):
         transport = RingTransport.choose(world, rank, d, device=part_buf.device, requested=transport)
+    tables = (1, 2) if getattr(getattr(model, "cfg", None), "use_hs", 0) else (1,)     # with the hierarchical softmax the syn1 partition of the same number travels along
     for e in range(world):
         tgt = (rank + e) % world
         model.set_partition(world, rank, tgt)
         train_fn()
-        model.export_partition(1, world, tgt, part_buf)            # what this rank just trained ...
-        _ring_pass(part_buf, recv_buf, world, rank, d, transport)  # ... goes to rank-1; rank+1's arrives:
-        model.import_partition(1, world, (rank + 1 + e) % world, recv_buf)     # the partition of the NEXT episode
+        for table in tables:
+            model.export_partition(table, world, tgt, part_buf)        # what this rank just trained ...
+            _ring_pass(part_buf, recv_buf, world, rank, d, transport)  # ... goes to rank-1; rank+1's arrives:
+            model.import_partition(table, world, (rank + 1 + e) % world, recv_buf)     # the partition of the NEXT episode
     model.set_partition(1)
     return part_buf, recv_buf
 
 
 def gather_table(model, table, world, rank, part_buf=None, gather_buf=None, dist_mod=None):
-    """After training: every rank holds the current partition `rank` of `table` (0 = syn0, 1 = syn1neg); collect the others."""
+    """After training: every rank holds the current partition `rank` of `table` (0 = syn0, 1 = syn1neg, 2 = syn1 under use_hs); collect the others."""
     if world <= 1:
         return
     import torch
@@ -245,6 +247,8 @@ def fit_distributed(graph, n_walks, walk_len, cfg, world, rank, walk_seed, batch
             words_before += model.stats()["words"]
     gather_table(model, 0, world, rank, dist_mod=dist_mod)
     gather_table(model, 1, world, rank, dist_mod=dist_mod)
+    if getattr(cfg, "use_hs", 0):
+        gather_table(model, 2, world, rank, dist_mod=dist_mod)
     corpus.close()
     return model
 

@@ -273,11 +273,14 @@ void dge_model_free(dge_model* m);
  * walks: the blocks of one episode are row-disjoint, after N episodes every pair was trained once.
  * After an episode a rank hands the syn1neg partition it trained to rank g-1, which trains it next (export -> point-to-point
  * transfer -> import: a ring); syn0 partitions never leave their rank until the final gather.  n_parts <= 1 switches the filter off.
- * Policies under a partition: 0 (auto), 2, 3, 5, 8, and 7 = row locks on syn1neg only, the pair's syn0 row by atomics. */
+ * Policies under a partition: 0 (auto), 2, 3, 5, 8, and 7 = row locks on syn1neg's tail only, the pair's syn0 row by atomics.  Auto keeps the head / tail
+ * split of policy 7 inside a block on skewed vocabularies (the block's own head, derived from the counts with the block's collision rate).
+ * With use_hs (policies 0 / 2 / 3): inner-node rows are split by node % n_parts too; a block visits EVERY centre for the inner nodes of its path that lie in
+ * tgt_part, the negative-sampling terms of a pair stay with the block of its centre's partition; syn1 partition p travels with syn1neg partition p. */
 int  dge_model_set_partition(dge_model* m, int32_t n_parts, int32_t ctx_part, int32_t tgt_part);
 /* floats of one packed partition buffer: ceil(V / n_parts) rows x row stride (same for every partition) */
 int  dge_model_partition_floats(const dge_model* m, int32_t n_parts, int64_t* n_floats);
-/* table: 0 = syn0, 1 = syn1neg; d_buf is device memory of dge_model_partition_floats floats */
+/* table: 0 = syn0, 1 = syn1neg, 2 = syn1 (use_hs); d_buf is device memory of dge_model_partition_floats floats */
 int  dge_model_export_partition(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf);
 int  dge_model_import_partition(dge_model* m, int table, int32_t n_parts, int32_t part, const float* d_buf);
 
@@ -303,7 +306,7 @@ void dge_comm_free(dge_comm* c);
 int  dge_model_allreduce_deltas(dge_model* m, dge_comm* c);
 /* block schedule with RCCL called from the library (N = nranks).  dge_model_ring_pass: after episode `episode` rank g hands the
  * syn1neg partition it just trained, (g + episode) % N, to rank g-1 and takes (g + 1 + episode) % N — the one it trains next — from
- * rank g+1 (ncclSend / ncclRecv).  dge_model_gather_table: every rank publishes partition `rank` of `table` (0 = syn0, 1 = syn1neg)
+ * rank g+1 (ncclSend / ncclRecv; with use_hs the syn1 partition of the same number in the same transfer).  dge_model_gather_table: every rank publishes partition `rank` of `table` (0 = syn0, 1 = syn1neg, 2 = syn1)
  * and takes the others (all-gather): the end of training.  NOT YET RUN ON MORE THAN ONE GPU (README.md: verification status). */
 int  dge_model_ring_pass(dge_model* m, dge_comm* c, int32_t episode);
 int  dge_model_gather_table(dge_model* m, dge_comm* c, int table);

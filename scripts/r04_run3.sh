@@ -6,7 +6,8 @@ O=gpurun_out/r04_run3; mkdir -p $O
 cd "$(dirname "$0")/.."
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; }
 run() { name=$1; shift; echo "== $name"; date; timeout -k 10 $1 python -m pytest "${@:2}" -x -q -s -m gpu --durations=5 > $O/$name.log 2>&1; rc=$?; echo "rc $rc" >> $O/$name.log; grep -E "passed|failed|error|rc |quality|Memory access|Error" $O/$name.log | tail -8; return $rc; }
-run hs_tests 600 tests/test_gpu_sgns.py -k "hierarchical" || exit 1
+run hs_tests 600 tests/test_gpu_sgns.py -k "hierarchical or block_schedule" || exit 1
+run hs_dist 300 tests/test_gpu_distributed.py -k "oracles_block_run"
 line() { python -c "
 import json,sys
 for l in sys.stdin:

@@ -62,12 +62,13 @@ def simulate_block_schedule(models, train_fn, serial=False):
                 train_fn(m)
             if serial:
                 m.stats()                   # drains this model's stream: the ranks' launches of an episode run one after the other, as they would on N devices of their own
-        for g, m in enumerate(models):
-            m.export_partition(1, N, (g + e) % N, bufs[g])
-        for g, m in enumerate(models):
-            for r in range(N):
-                if r != g:
-                    m.import_partition(1, N, (r + e) % N, bufs[r])
+        for table in ((1, 2) if getattr(getattr(models[0], "cfg", None), "use_hs", 0) else (1,)):      # syn1 partitions travel with the syn1neg partitions (use_hs)
+            for g, m in enumerate(models):
+                m.export_partition(table, N, (g + e) % N, bufs[g])
+            for g, m in enumerate(models):
+                for r in range(N):
+                    if r != g:
+                        m.import_partition(table, N, (r + e) % N, bufs[r])
     for g, m in enumerate(models):
         m.set_partition(1)
 

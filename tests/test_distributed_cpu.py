@@ -29,9 +29,11 @@ class FakeBlockModel:
     every syn1neg row of the target partition, and records the block — a row touched by two ranks in one episode, or a
     block trained twice, shows up as a count != the expected one."""
 
-    def __init__(self, V, stride):
+    def __init__(self, V, stride, hs=False):
+        import types
         self.V, self.stride = V, stride
-        self.tab = [np.zeros((V, stride), np.float32), np.zeros((V, stride), np.float32)]
+        self.tab = [np.zeros((V, stride), np.float32) for _ in range(3 if hs else 2)]      # syn0, syn1neg (, syn1: its partitions travel with syn1neg's)
+        self.cfg = types.SimpleNamespace(use_hs=int(hs))
         self.part = (1, 0, 0)
         self.blocks = []
 
@@ -45,7 +47,8 @@ class FakeBlockModel:
         n, ctx, tgt = self.part
         self.blocks.append((ctx, tgt))
         self.tab[0][ctx::n] += 1
-        self.tab[1][tgt::n] += 1
+        for t in self.tab[1:]:
+            t[tgt::n] += 1
 
     def export_partition(self, table, n, part, buf):
         rows = self.tab[table][part::n]
@@ -57,31 +60,34 @@ class FakeBlockModel:
         self.tab[table][part::n] = buf.numpy().reshape(-1, self.stride)[:rows]
 
 
-def _block_worker(rank, world, port, out_dir, transport=None):
+def _block_worker(rank, world, port, out_dir, transport=None, hs=False):
     import torch.distributed as dist
     from embedding_amd.distributed import block_schedule_step, gather_table
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    m = FakeBlockModel(11, 4)                      # 11 rows: partitions of unequal size (padding in the packed buffers)
+    m = FakeBlockModel(11, 4, hs)                  # 11 rows: partitions of unequal size (padding in the packed buffers)
     bufs = (None, None)
     for _ in range(2):                             # two global batches
         bufs = block_schedule_step(m, m.train, world, rank, *bufs, transport=transport)
     held = m.tab[1][rank::world].copy()            # ring invariant: after a whole batch, partition `rank` of syn1neg is home again
     gather_table(m, 0, world, rank)
     gather_table(m, 1, world, rank)
+    if hs:
+        gather_table(m, 2, world, rank)
+        assert np.array_equal(m.tab[2], m.tab[1])  # the inner-node partitions went round with the syn1neg partitions
     assert np.array_equal(m.tab[1][rank::world], held)
     np.savez(os.path.join(out_dir, "b%d.npz" % rank), syn0=m.tab[0], syn1neg=m.tab[1], blocks=np.array(m.blocks), part=np.array(m.part))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,transport", [(2, None), (3, None), (3, "allgather")])
-def test_block_schedule_gloo(tmp_path, world, transport):
+@pytest.mark.parametrize("world,transport,hs", [(2, None, False), (3, None, False), (3, "allgather", False), (3, None, True)])
+def test_block_schedule_gloo(tmp_path, world, transport, hs):
     """Every (context partition, centre partition) block is trained exactly once per batch, by exactly one rank; the blocks
-    of one episode are row-disjoint; all ranks end with identical tables."""
+    of one episode are row-disjoint; all ranks end with identical tables (hs: the inner-node table's partitions travel along)."""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_block_worker, args=(world, port, str(tmp_path), transport), nprocs=world, join=True)
+    mp.spawn(_block_worker, args=(world, port, str(tmp_path), transport, hs), nprocs=world, join=True)
     r = [np.load(str(tmp_path / ("b%d.npz" % i))) for i in range(world)]
     seen = []
     for i in range(world):

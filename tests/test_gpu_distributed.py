@@ -21,36 +21,39 @@ def _graph(dge):
     return g
 
 
-def _rank(rank, world, port, out_dir, batch_walks, workers):
+def _rank(rank, world, port, out_dir, batch_walks, workers, hs=False):
     import torch.distributed as dist
     import embedding_amd as dge
     from embedding_amd.distributed import fit_distributed
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = _graph(dge)
-    cfg = dge.make_config(DIM, T, R * T, workers=workers, table_size=20011)
+    cfg = dge.make_config(DIM, T, R * T, workers=workers, table_size=20011, use_hs=hs)
     m = fit_distributed(g, N_WALKS, T, cfg, world, rank, walk_seed=11, batch_walks=batch_walks)
     syn0, vid = m.vectors()
-    np.savez(os.path.join(out_dir, "d%d.npz" % rank), syn0=syn0, syn1neg=m.syn1neg(), vid=vid, pairs=m.stats()["pairs"])
+    np.savez(os.path.join(out_dir, "d%d.npz" % rank), syn0=syn0, syn1neg=m.syn1neg(), vid=vid, pairs=m.stats()["pairs"], syn1=m.syn1() if hs else np.zeros(0, np.float32))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(tmp_path, batch_walks, workers):
+def _run(tmp_path, batch_walks, workers, hs=False):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_rank, args=(2, port, str(tmp_path), batch_walks, workers), nprocs=2, join=True)
+    mp.spawn(_rank, args=(2, port, str(tmp_path), batch_walks, workers, hs), nprocs=2, join=True)
     return [np.load(str(tmp_path / ("d%d.npz" % i))) for i in range(2)]
 
 
-def test_two_rank_fit_is_the_oracles_block_run(dge, oracle, tmp_path):
-    """One batch = the whole epoch, in-order workers: both ranks end bit-identical to the oracle's sequential run of the 2x2 blocks."""
-    r = _run(tmp_path, N_WALKS, 1)
+@pytest.mark.parametrize("hs", [False, True], ids=["sgns", "hs"])
+def test_two_rank_fit_is_the_oracles_block_run(dge, oracle, tmp_path, hs):
+    """One batch = the whole epoch, in-order workers: both ranks end bit-identical to the oracle's sequential run of the 2x2 blocks — with the
+    hierarchical-softmax term as well (what DeepWalk's builder default trains, J/DeepWalk.java:73-76): the syn1 partitions travel the ring with syn1neg's."""
+    r = _run(tmp_path, N_WALKS, 1, hs)
     walks = _graph(dge).sample_walks(N_WALKS, T, seed=11, rng_mode=1)
-    om = oracle.train_sgns(walks, R * T, DIM, T, table_size=20011, arith=1, part_n=2)
+    om = oracle.train_sgns(walks, R * T, DIM, T, table_size=20011, arith=1, part_n=2, use_hs=hs)
     for d in r:
         assert np.array_equal(d["vid"], om.vocab_ids)
         assert np.array_equal(bits(d["syn0"]), bits(om.syn0)) and np.array_equal(bits(d["syn1neg"]), bits(om.syn1neg))
+        assert not hs or np.array_equal(bits(d["syn1"]), bits(om.syn1))
 
 
 def test_two_rank_fit_in_batches_matches_one_process(dge, oracle, tmp_path):

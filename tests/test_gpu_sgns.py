@@ -610,7 +610,9 @@ def test_hierarchical_softmax_wave_per_centre_linear_regime(dge, oracle, dim, ne
     corpus = dge.WalkCorpus.from_host(ids, 0)
     d_counts = torch.from_numpy(counts).to("cuda:0")
     for centre in (1, 0):
-        with dge.tuning(hs_centre=centre):
+        # (hs_cold = 0: the "cold" class — plain read-modify-write for inner nodes on < 2e-5 of the paths BY THE COUNTS — assumes the corpus follows the
+        #  counts; these artificial counts do not, the bushy tail is visited all the time)
+        with dge.tuning(hs_centre=centre, hs_cold=0):
             dm = dge.SgnsModel.create(dge.make_config(dim, window, NV, workers=0, use_hs=True, **kw), d_counts, 0)
             dm.train(corpus)
         assert dm.stats()["pairs"] == om.pairs and np.array_equal(dm.vectors()[1], om.vocab_ids)
@@ -626,21 +628,21 @@ def test_hierarchical_softmax_wave_per_centre_linear_regime(dge, oracle, dim, ne
 
 
 # ------------------------------------------------------------------------------------------ multi-GPU block schedule
-@pytest.mark.parametrize("n_ranks,dim,negative", [(2, 32, 5), (3, 64, 5), (4, 20, 3), (2, 128, 20)])
-def test_block_schedule_bit_exact_with_oracle(dge, oracle, n_ranks, dim, negative):
+@pytest.mark.parametrize("n_ranks,dim,negative,hs", [(2, 32, 5, False), (3, 64, 5, False), (4, 20, 3, False), (2, 128, 20, False), (2, 32, 5, True), (3, 64, 2, True), (4, 20, 0, True)])
+def test_block_schedule_bit_exact_with_oracle(dge, oracle, n_ranks, dim, negative, hs):
     """N ranks (N models on this one GPU), in-order workers: after the N episodes and the partition exchanges every rank
     holds exactly the tables the oracle produces when it runs the same N*N blocks one after the other — the blocks of an
     episode are row-disjoint, so running them on N devices at once changes nothing.  Every pair is trained exactly once."""
     import torch
     from helpers import simulate_block_schedule, simulate_gather_syn0
     walks, NV = _walks(oracle, dge, n=400 if dim >= 128 else 800)
-    om = oracle.train_sgns(walks, NV, dim, 6, negative=negative, table_size=20011, arith=1, part_n=n_ranks)
-    o1 = oracle.train_sgns(walks, NV, dim, 6, negative=negative, table_size=20011, arith=1)
+    om = oracle.train_sgns(walks, NV, dim, 6, negative=negative, table_size=20011, arith=1, part_n=n_ranks, use_hs=hs)
+    o1 = oracle.train_sgns(walks, NV, dim, 6, negative=negative, table_size=20011, arith=1, use_hs=hs)
     assert om.pairs == o1.pairs
     corpus = dge.WalkCorpus.from_host(walks, 0)
     counts = torch.zeros(NV, dtype=torch.int64, device="cuda:0")
     corpus.count_tokens(NV, counts)
-    cfg = dge.make_config(dim, 6, NV, negative=negative, workers=1, table_size=20011)
+    cfg = dge.make_config(dim, 6, NV, negative=negative, workers=1, table_size=20011, use_hs=hs)
     ms = [dge.SgnsModel.create(cfg, counts, 0) for _ in range(n_ranks)]
     simulate_block_schedule(ms, lambda m: m.train(corpus))
     simulate_gather_syn0(ms)
@@ -648,6 +650,8 @@ def test_block_schedule_bit_exact_with_oracle(dge, oracle, n_ranks, dim, negativ
     for m in ms:
         assert np.array_equal(bits(m.vectors()[0]), bits(om.syn0))
         assert np.array_equal(bits(m.syn1neg()), bits(om.syn1neg))
+        if hs:      # with the hierarchical softmax (round 4): inner nodes split by node % n, every centre visited in every block for its path's nodes of that partition
+            assert np.array_equal(bits(m.syn1()), bits(om.syn1))
     # and the block order costs nothing statistically: as close to the plain sequential run as another pair order is
     assert float(np.median(cosine_rows(ms[0].vectors()[0], o1.syn0))) > 0.8
 
@@ -685,10 +689,15 @@ def test_block_schedule_hogwild_policies(dge, oracle):
         m.set_partition(2, 0, 1)
         with pytest.raises(dge.DgeError):
             m.train(corpus)
-    m = dge.SgnsModel.create(dge.make_config(32, 6, NV, table_size=20011, use_hs=True), counts, 0)
-    m.set_partition(2, 0, 1)
-    with pytest.raises(dge.DgeError):
-        m.train(corpus)
+    # hierarchical softmax inside the blocks, device-filling workers (atomics on all three tables): same pairs, within Hogwild noise of the oracle's block run
+    oh = oracle.train_sgns(walks, NV, 32, 6, table_size=20011, arith=1, part_n=2, use_hs=True)
+    ms = [dge.SgnsModel.create(dge.make_config(32, 6, NV, workers=0, table_size=20011, use_hs=True), counts, 0) for _ in range(2)]
+    simulate_block_schedule(ms, lambda m: m.train(corpus))
+    simulate_gather_syn0(ms)
+    assert sum(m.stats()["pairs"] for m in ms) == oh.pairs and ms[0].schedule()["update_policy"] == 2
+    assert np.array_equal(bits(ms[0].syn1()), bits(ms[1].syn1())) and np.isfinite(ms[0].syn1()).all()
+    assert float(np.median(cosine_rows(ms[0].vectors()[0], oh.syn0))) > 0.75
+    m = ms[0]
     with pytest.raises(dge.DgeError):
         m.set_partition(2, 2, 0)
 
