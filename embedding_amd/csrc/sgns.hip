@@ -1008,7 +1008,10 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     unsigned threads = workers == 1 ? 64u : 256u;
     unsigned blocks = (unsigned)((workers * 16 + threads - 1) / threads);
     const bool big_tables = (uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull || g_dge_tuning[DGE_TUNE_FORCE_SEGMENTS] > 0;
-    if (pol == 12 && workers > 1 && m->stride <= 128 && L <= 64 && !big_tables && g_dge_tuning[DGE_TUNE_HS_CENTRE] != 0) {
+    // (from 65 536 vocabulary rows on, like the atomics wave below: on the reference's own 6 408-row tract vocabulary the walks in flight are capped by the
+    //  vocabulary — 801 waves — and the pair-by-pair kernel's 3 204 groups are faster: 1.64e8 against 1.22e8 edges/s; DGE_TUNE_HS_CENTRE = 1 forces it)
+    if (pol == 12 && workers > 1 && m->stride <= 128 && L <= 64 && !big_tables &&
+        (g_dge_tuning[DGE_TUNE_HS_CENTRE] > 0 || (g_dge_tuning[DGE_TUNE_HS_CENTRE] < 0 && m->V >= 65536))) {
         // Hierarchical softmax, a wave per centre (k_sgns_train_hsw, round 4): the centre's path nodes stay in the registers of a wave's four groups for all
         // its contexts and their gathered updates leave once per centre.  `workers` = walks in flight = waves that train: two resident workgroups of three
         // such waves (and one atomics wave) a compute unit; never more than an eighth of the vocabulary (a wave works on four context rows at a time).

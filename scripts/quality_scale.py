@@ -79,8 +79,11 @@ if BLOCKS:
     sys.exit(0)
 
 if HS:
-    for name, knobs in (("pair by pair, cold end plain, atomics through the atomics wave (round 3)", {"hs_centre": 0}),
-                        ("a wave per centre (round 4, default)", {}), ("a wave per centre, LDS accumulators drained every 16 centre additions", {"hs_drain": 16})):
+    import os
+    variants = [("pair by pair, cold end plain, atomics through the atomics wave (round 3)", {"hs_centre": 0}), ("a wave per centre (round 4, default)", {})]
+    if os.environ.get("DGE_HS_DRAINS"):          # e.g. DGE_HS_DRAINS=6,8: only the wave-per-centre kernel with these drain periods of the LDS accumulators
+        variants = [("a wave per centre, LDS accumulators drained every %s centre additions" % d, {"hs_drain": int(d)}) for d in os.environ["DGE_HS_DRAINS"].split(",")]
+    for name, knobs in variants:
         with E.tuning(**knobs):
             m = E.SgnsModel.create(E.make_config(D, L, NV, negative=K, workers=0, use_hs=True), counts, 0)
             m.train(corpus); st = m.stats()

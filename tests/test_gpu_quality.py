@@ -11,6 +11,9 @@ Hogwild schedule, trains pairs in another order than the sequential loop.  Eleme
      table, learning-rate positions and random streams: the oracle sequentially in word2vec order (the definition), the oracle with the
      reference's own 8 Hogwild workers (J/DeepWalk.java:75), the device with ~12 000 concurrent workers.
 
+On the Zipf graph the slice is trained a second time with 1/33 of the workers — the slice is 1/33 of a bench launch, so the same ~100 walks per worker —
+and the strict comparisons apply to that run (with device-filling workers a third of this short slice is in flight at once: reported, weaker bounds).
+
 Compared: the pair count (identical); per row, the direction of the slice's update (row after - row before) against the sequential update;
 link-prediction AUC and mean negative-sampling loss on held-out walk steps.  The device must be as close to the sequential result as the
 CPU's 8-thread Hogwild is.  (SGNS half of the oracle: a restatement of word2vec.c / DL4J, parity unpinned — DESIGN.md §3.)"""
@@ -19,7 +22,7 @@ import concurrent.futures as cf
 import numpy as np
 import pytest
 
-from helpers import cosine_rows, link_auc
+from helpers import cosine_rows, device_table, link_auc
 
 pytestmark = pytest.mark.gpu
 
@@ -76,13 +79,26 @@ def runs(dge, oracle):
         kw = dict(negative=K, min_count=2, epochs=1, seed=1, table_size=10_000_000, arith=0, counts=counts.cpu().numpy(), syn0_init=s0_0, syn1neg_init=s1_0,
                   walk_index_base=N_LONG, total_walks=n_tot, total_words=4 * tw, words_before=st_long["words"])
         pending[name] = pool.submit(oracle.train_sgns, sl, NV, D, L, threads=1, **kw)
+        keep = [device_table(m, t).clone() for t in (0, 1)]                # the state the slice starts from (the second device run below starts from it again)
         m.reset_stats()
         m.train(corpus, N_LONG, N_SLICE, walk_index_base=N_LONG, words_before=st_long["words"], total_walks=n_tot)
         st, sch = m.stats(), m.schedule()
         s0_d = m.vectors()[0]; s1_d = m.syn1neg()
+        # The slice is 1/33 of a bench launch (30 000 of 1 000 008 walks).  Device-filling workers (~12 000) then hold a THIRD of the slice in flight at any
+        # moment (3 walks each), a bench launch 1 %.  On the flat graph that changes nothing measurable; on the Zipf graph the head rows take a third of
+        # the slice's updates from one stale value.  So the slice is also trained with 1/33 of the workers — the same ~100 walks per worker as a launch:
+        prop = None
+        if name == "zipf":
+            for t in (0, 1):
+                m.import_partition(t, 1, 0, keep[t].view(-1))
+            m.reset_stats()
+            with dge.tuning(workers=max(16, sch["workers"] * N_SLICE // 1_000_008 // 16 * 16)):
+                m.train(corpus, N_LONG, N_SLICE, walk_index_base=N_LONG, words_before=st_long["words"], total_walks=n_tot)
+            prop = dict(dev=(m.vectors()[0], m.syn1neg()), st=m.stats(), sch=m.schedule())
+        del keep
         m.close(); corpus.close(); g.close()
         torch.cuda.empty_cache()
-        out[name] = dict(R=R, NV=NV, n_long=N_LONG, vid=vid, test=test, before=(s0_0, s1_0), dev=(s0_d, s1_d), st=st, sch=sch, sch_long=sch_long, kw=kw, sl=sl, V=len(vid))
+        out[name] = dict(R=R, NV=NV, n_long=N_LONG, vid=vid, test=test, before=(s0_0, s1_0), dev=(s0_d, s1_d), st=st, sch=sch, sch_long=sch_long, kw=kw, sl=sl, V=len(vid), prop=prop)
     for name, o in out.items():
         o["cpu8"] = oracle.train_sgns(o["sl"], o["NV"], D, L, threads=8, **o["kw"])
     for name, o in out.items():
@@ -107,18 +123,25 @@ def test_full_concurrency_launch_against_the_sequential_oracle(runs, name, polic
     assert np.isfinite(d0).all() and np.isfinite(d1).all()
     R, vid, test = o["R"], o["vid"], o["test"]
     res = {}
-    for tag, (s0, s1) in (("before", (b0, b1)), ("seq", (seq.syn0, seq.syn1neg)), ("cpu8", (cpu8.syn0, cpu8.syn1neg)), ("dev", (d0, d1))):
+    legs = [("before", (b0, b1)), ("seq", (seq.syn0, seq.syn1neg)), ("cpu8", (cpu8.syn0, cpu8.syn1neg)), ("dev", (d0, d1))]
+    if o["prop"]:
+        assert o["prop"]["st"]["pairs"] == seq.pairs and o["prop"]["sch"]["update_policy"] == policy and 64 <= o["prop"]["sch"]["workers"] < 1000, o["prop"]["sch"]
+        legs.append(("dev_prop", o["prop"]["dev"]))
+    for tag, (s0, s1) in legs:
         res[tag] = dict(auc=link_auc(s0, s1, vid, test, R), loss=_host_loss(s0, s1, vid, test, R))
-    for tag, (s0, s1) in (("cpu8", (cpu8.syn0, cpu8.syn1neg)), ("dev", (d0, d1))):
+    for tag, (s0, s1) in legs[2:]:
         c0 = _delta_cosine(s0, b0, seq.syn0); c1 = _delta_cosine(s1, b1, seq.syn1neg)
         res[tag].update(cos0_med=float(np.median(c0)), cos0_p05=float(np.percentile(c0, 5)), cos1_med=float(np.median(c1)), cos1_p05=float(np.percentile(c1, 5)))
     print("\n[quality %s] %s" % (name, res), flush=True)
-    # the embedding is a trained one (not word2vec's slow start), and the slice moved it
+    # the embedding is a trained one (not word2vec's slow start)
     assert res["before"]["auc"] > 0.85, res
-    # statistical parity with the sequential definition
-    assert abs(res["dev"]["auc"] - res["seq"]["auc"]) < 0.005, res
-    assert abs(res["dev"]["loss"] / res["seq"]["loss"] - 1) < 0.01, res
+    # the device-filling launch: finite, every pair, and the slice did not hurt (on the Zipf graph a third of the slice is in flight at once: see `runs`)
+    assert res["dev"]["auc"] > res["before"]["auc"] - 0.002 and res["dev"]["loss"] < res["before"]["loss"] * 1.01, res
+    strict = "dev_prop" if o["prop"] else "dev"
+    # statistical parity with the sequential definition ...
+    assert abs(res[strict]["auc"] - res["seq"]["auc"]) < 0.005, res
+    assert abs(res[strict]["loss"] / res["seq"]["loss"] - 1) < 0.01, res
     # ... as close to it as the reference's own 8 Hogwild workers are: per-row update directions
-    assert res["dev"]["cos0_med"] > res["cpu8"]["cos0_med"] - 0.02 and res["dev"]["cos1_med"] > res["cpu8"]["cos1_med"] - 0.02, res
-    assert res["dev"]["cos0_p05"] > res["cpu8"]["cos0_p05"] - 0.05 and res["dev"]["cos1_p05"] > res["cpu8"]["cos1_p05"] - 0.05, res
-    assert res["dev"]["auc"] >= res["cpu8"]["auc"] - 0.002, res
+    assert res[strict]["cos0_med"] > res["cpu8"]["cos0_med"] - 0.02 and res[strict]["cos1_med"] > res["cpu8"]["cos1_med"] - 0.02, res
+    assert res[strict]["cos0_p05"] > res["cpu8"]["cos0_p05"] - 0.05 and res[strict]["cos1_p05"] > res["cpu8"]["cos1_p05"] - 0.05, res
+    assert res[strict]["auc"] >= res["cpu8"]["auc"] - 0.002, res
