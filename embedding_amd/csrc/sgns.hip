@@ -1472,7 +1472,10 @@ extern "C" int dge_model_reset_stats(dge_model* m) {
     if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_reset_stats: null model");
     int rc = drain_events(m);
     if (rc) return rc;
-    DGE_HIP(hipMemset(m->d_counters, 0, 2 * sizeof(unsigned long long)));
+    // on the model's own stream (a non-blocking one: a null-stream memset is not ordered against it — a short launch right behind reset_stats lost a tenth of
+    // its pair count to the memset landing late: tests/test_gpu_quality.py, round 4)
+    DGE_HIP(hipMemsetAsync(m->d_counters, 0, 2 * sizeof(unsigned long long), m->stream));
+    DGE_HIP(hipStreamSynchronize(m->stream));
     m->kernel_ms = 0; m->walk_ms = 0; m->launches = 0;
     return DGE_OK;
 }
