@@ -920,6 +920,11 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || m->cfg.update_policy == 7 || auto_locked || auto_mixed) ? ((m->cfg.update_policy == 7 || auto_mixed) ? (m->stride <= 128 ? DGE_HOTMIX_WAVES : 2) : (m->stride == 64 ? 4 : DGE_LOCKED_WAVES)) : 4;   // (rows of one chunk leave room for a 4th wave per SIMD in the lock kernel; a 5th under atomics gains nothing: cfg2 7.6e8 either way)   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)m->n_cus * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
+        // ... nor so many that ONE row has dozens of its updates in flight at once: every one of them is computed from the same stale row, and their
+        // sum — along the direction the contexts share — is a gradient step M times too long.  A vocabulary whose busiest row takes 9 % of the tokens
+        // (Zipf(1) over 50 000 words: text without sub-sampling, not a flow graph) went to NaN within one launch of 16 384 workers
+        // (scripts/policy_sweep.py, round 4); cfg3 with Zipf destinations and cfg5 keep 34 and 18 in flight and train to the atomics-free AUC.
+        workers = std::min(workers, std::max<int64_t>(64, (int64_t)(48.0 / std::max(m->row_share_max, 1e-12))));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
     } else workers = m->cfg.workers;
     if (m->cfg.workers == 0 && g_dge_tuning[DGE_TUNE_WORKERS] > 0) workers = std::min<int64_t>(g_dge_tuning[DGE_TUNE_WORKERS], (n_rows + 15) / 16 * 16);     // ablation knob
@@ -1016,7 +1021,8 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // its contexts and their gathered updates leave once per centre.  `workers` = walks in flight = waves that train: two resident workgroups of three
         // such waves (and one atomics wave) a compute unit; never more than an eighth of the vocabulary (a wave works on four context rows at a time).
         pol = 13;
-        if (m->cfg.workers == 0 && !(g_dge_tuning[DGE_TUNE_WORKERS] > 0)) workers = std::max<int64_t>(1, std::min<int64_t>((int64_t)m->n_cus * 2 * 3, std::max<int64_t>(1, m->V / 8)));
+        if (m->cfg.workers == 0 && !(g_dge_tuning[DGE_TUNE_WORKERS] > 0))
+            workers = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)m->n_cus * 2 * 3, std::max<int64_t>(1, m->V / 8)), std::max<int64_t>(16, (int64_t)(12.0 / std::max(m->row_share_max, 1e-12)))));
         workers = std::max<int64_t>(1, std::min<int64_t>(workers, n_rows));
         p.n_workers = workers;
         blocks = (unsigned)((workers + 2) / 3);
