@@ -603,7 +603,7 @@ static void launch_commit_any(int dch, const SortedParams& q, const int64_t* seg
 // the link-prediction AUC equals the atomics schedule's up to ~120 items per row and mini-batch, slips by 0.001 per ~70 items beyond and
 // collapses between 320 and 390 (8 ranks: 73 ms per episode at 128 items per row, 69 at 256 — not worth the margin) —
 // and the HOTTEST row counts, not the average one: on a Zipf-popular graph a head row took > 1e5 terms of a 96-per-row mini-batch and
-// the tables went to NaN within an epoch.  Hence: 128 items per live row, at most 2048 for the hottest row, and no mini-batch below 1e6
+// the tables went to NaN within an epoch.  Hence: 128 items per live row, at most 2048 for the hottest row, and no mini-batch below 5e5
 // items (the two sorts and ~16 launches per mini-batch need that much to pay): 0 = this vocabulary is too skewed or too small.
 int64_t dge_sorted_batch_items(const dge_model* m, int part_n) {
     const int n = std::max(part_n, 1);
@@ -611,7 +611,9 @@ int64_t dge_sorted_batch_items(const dge_model* m, int part_n) {
     const double hottest = std::min(1.0, m->row_share_max * (double)n);      // its share of one block's terms
     int64_t items = std::min<int64_t>(96ll << 20, 128 * live_rows);
     items = std::min<int64_t>(items, (int64_t)(2048.0 / std::max(hottest, 1e-12)));
-    return items >= (1 << 20) ? items : 0;
+    // (from half a million items on — round 4: a 50 000-row vocabulary with rank^-0.5 popularity lands at 0.9 M and ran 3.4e8 edges/s at D = 256 under this
+    //  schedule against 2.1e8 under the atomics the rule used to leave it with: scripts/policy_sweep.py)
+    return items >= (1 << 19) ? items : 0;
 }
 
 struct CastI64 { __host__ __device__ int64_t operator()(int32_t x) const { return (int64_t)x; } };

@@ -40,7 +40,7 @@ def rate(cfg, counts, corpus, n):
 
 
 worst = 1e9
-print("%9s %4s %4s | %-28s | %s" % ("V", "s", "D", "auto ran as", "edges/s: auto, then forced 2 / 5 / 7 / 8 (- = skipped after the probe, x = refused)"))
+print("%9s %4s %4s | %-28s | %s" % ("V", "s", "D", "auto ran as", "edges/s: auto, then forced 2 / 5 / 7 / 8 (- = skipped after the probe, x = refused, nan = diverged)"))
 for V in Vs:
     for s in Ss:
         corpus = corpus_for(V, s, N_WALKS, 7)
@@ -57,14 +57,15 @@ for V in Vs:
                     if pr * 4 < best:
                         res[pol] = None; continue
                     res[pol], _, ok = rate(cfg(pol), counts, corpus, N_WALKS)
-                    assert ok
+                    if not ok:
+                        res[pol] = "nan"; continue          # a FORCED policy outside its regime (owner-computes on a Zipf head: DESIGN.md section 5.7) may diverge
                     best = max(best, res[pol])
                 except E.DgeError:
                     res[pol] = "x"
             forced = [v for k, v in res.items() if k and isinstance(v, float)]
             ratio = res[0] / max(forced) if forced else 1.0
             worst = min(worst, ratio)
-            fmt = lambda v: "   -    " if v is None else ("   x    " if v == "x" else "%.2e" % v)
+            fmt = lambda v: "   -    " if v is None else ("   x    " if v == "x" else ("  nan   " if v == "nan" else "%.2e" % v))
             print("%9d %4.1f %4d | %-28s | %s  %s  -> auto / best forced = %.2f" % (V, s, D, "policy %d, %d workers, head %d" % (sch0["update_policy"], sch0["workers"], sch0["hot_rows"]),
                                                                                  fmt(res[0]), " / ".join(fmt(res[p]) for p in (2, 5, 7, 8)), ratio), flush=True)
         corpus.close()
