@@ -845,6 +845,24 @@ static int64_t block_head(dge_model* m, int n, int64_t W) {
     return m->block_head_rows;
 }
 
+// What update_policy 0 resolves to for a device-filling launch over the whole vocabulary on one GPU — 5 (commit locks), 7 (locks, the head by atomics) or 2
+// (atomics); the owner-computes schedule (8) is taken instead of 2 where it applies (train_rows).  The rule's constants were fitted on the four bench graphs
+// and then checked — and moved — against a sweep of vocabulary size x popularity exponent x row width (scripts/policy_sweep.py, profiles/r04_policy_sweep.txt):
+//   * the commit locks are the fast schedule while a try-lock rarely fails: expected failures per attempt ~ workers * 5 * sum q_i^2 < 0.4 on a vocabulary of
+//     >= 131 072 rows (round 3: 0.25 and 262 144 — a flat 200 000-row vocabulary runs 1.46e9 edges/s under locks against 1.19e9 owner-computes);
+//   * a skewed vocabulary keeps the locks for its tail when the head that has to leave them is at most a quarter of the rows (round 3: an eighth — rank^-0.5
+//     popularity over 300 000 rows: 9.5e8 against 7.3e8 owner-computes);
+//   * when the busiest row's share caps the workers below a quarter of the device (train_rows: at most 48 of a row's updates in flight), the lock protocol has
+//     nothing to win over atomics (rank^-1 over 300 000 words: 1.37e8 against 5.9e7).
+static int auto_policy(const dge_model* m, bool hs) {
+    if (hs) return 2;
+    const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
+    if ((int64_t)(48.0 / std::max(m->row_share_max, 1e-12)) < 4096) return 2;
+    if (m->V >= 131072 && fail < 0.4) return m->hot_rows_serial > 0 ? 7 : 5;
+    if (m->V >= 131072 && m->hot_rows_auto <= m->V / 4) return 7;
+    return 2;
+}
+
 static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32_t L, int64_t walk_index_base, int32_t epoch,
                       int64_t words_before, double words_scale, int64_t total_walks, uint64_t corpus_gen) {
     if (n_rows == 0 || m->V == 0) return DGE_OK;
@@ -895,8 +913,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     // thousands of terms at once with no feedback between them, and the embedding diverges (dge_sorted_batch_items).
     bool sorted_auto = false;
     if (m->cfg.update_policy == 0 && m->cfg.workers == 0 && !hs && (uint64_t)m->V * (uint64_t)m->stride * 4ull < 0xFFFFFFFFull) {
-        const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
-        const bool locks_work = m->V >= 262144 && (fail < 0.25 || m->hot_rows_auto <= m->V / 8);   // -> commit locks, all rows (5) or the tail (7)
+        const bool locks_work = auto_policy(m, hs) != 2;                                            // -> commit locks, all rows (5) or the tail (7)
         if (part) sorted_auto = m->part_n >= 2 && dge_sorted_batch_items(m, m->part_n) > 0;         // (per rank on cfg3, owner-computes vs locks, round 3 with the items made once per batch: N = 2 7.5e8 vs 7.2e8, N = 4 7.8e8 vs 7.4e8, N = 8 7.5e8 vs 4.8e8)
         else sorted_auto = !locks_work && dge_sorted_batch_items(m, 1) > 0;                         // (what used to fall back to atomics)
     }
@@ -915,8 +932,8 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // fill the device: 4 blocks of 16 workers per CU, but never more concurrent walks than half the vocabulary
         // (Hogwild's premise is sparse collisions: measured, a 2.3k-row table keeps 0.99 cosine to the in-order
         // result up to ~1k workers and loses it beyond; the reference ran 8 workers on <= 6.4k rows)
-        const bool auto_locked = !hs && m->cfg.update_policy == 0 && m->V >= 262144 && (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision < 0.25;
-        const bool auto_mixed = !hs && m->cfg.update_policy == 0 && m->V >= 262144 && ((!auto_locked && m->hot_rows_auto <= m->V / 8) || (auto_locked && m->hot_rows_serial > 0));
+        const int auto_pol = m->cfg.update_policy == 0 ? auto_policy(m, hs) : 0;
+        const bool auto_locked = auto_pol == 5, auto_mixed = auto_pol == 7;
         const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || m->cfg.update_policy == 7 || auto_locked || auto_mixed) ? ((m->cfg.update_policy == 7 || auto_mixed) ? (m->stride <= 128 ? DGE_HOTMIX_WAVES : 2) : (m->stride == 64 ? 4 : DGE_LOCKED_WAVES)) : 4;   // (rows of one chunk leave room for a 4th wave per SIMD in the lock kernel; a 5th under atomics gains nothing: cfg2 7.6e8 either way)   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)m->n_cus * blocks_per_cu * 16;
         workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
@@ -937,10 +954,9 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // probabilities).  cfg3 (uniform-ish, 1M rows, 12k workers): 0.07 -> locked, 8.9e8 edges/s.  A Zipf-popular
         // vocabulary (cfg5) gives >> 1: the same kernel spins on its hot rows (measured 5e5 edges/s) while memory-side
         // atomics are indifferent to the skew (5.9e7 = their byte rate) -> atomics.
-        const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
         // In between (a skewed head over a long tail — cfg5, and what real trip data looks like) the head rows alone are
-        // taken out of the lock protocol: policy 7.
-        pol = workers == 1 ? 100 : ((!hs && m->V >= 262144 && fail < 0.25) ? (m->hot_rows_serial > 0 ? 7 : 5) : ((!hs && m->V >= 262144 && m->hot_rows_auto <= m->V / 8) ? 7 : 2));
+        // taken out of the lock protocol: policy 7.  (auto_policy above)
+        pol = workers == 1 ? 100 : auto_policy(m, hs);
     }
     if (pol == 7) {
         const double fail_all = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;

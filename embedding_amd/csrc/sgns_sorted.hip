@@ -611,9 +611,10 @@ int64_t dge_sorted_batch_items(const dge_model* m, int part_n) {
     const double hottest = std::min(1.0, m->row_share_max * (double)n);      // its share of one block's terms
     int64_t items = std::min<int64_t>(96ll << 20, 128 * live_rows);
     items = std::min<int64_t>(items, (int64_t)(2048.0 / std::max(hottest, 1e-12)));
-    // (from half a million items on — round 4: a 50 000-row vocabulary with rank^-0.5 popularity lands at 0.9 M and ran 3.4e8 edges/s at D = 256 under this
+    // (wide rows: from half a million items on — round 4: a 50 000-row vocabulary with rank^-0.5 popularity lands at 0.9 M and ran 3.4e8 edges/s at D = 256 under this
     //  schedule against 2.1e8 under the atomics the rule used to leave it with: scripts/policy_sweep.py)
-    return items >= (1 << 19) ? items : 0;
+    //  — on rows of more than 128 floats: with D = 64 the same vocabulary runs 7.9e8 under atomics against 4.2e8 here; the sorts do not shrink with the row)
+    return items >= (m->stride > 128 ? (1 << 19) : (1 << 20)) ? items : 0;
 }
 
 struct CastI64 { __host__ __device__ int64_t operator()(int32_t x) const { return (int64_t)x; } };

@@ -153,12 +153,15 @@ typedef struct dge_train_config {
     int64_t table_size;      /* unigram^0.75 table length; 0 -> 100000000 (word2vec.c) */
     int32_t n_vertices;      /* vertex-id space of the corpus */
     int32_t update_policy;   /* how concurrent workers update the tables (MI355X has 8 L2s that are not coherent):
-                                0 = auto: 5 when the vocabulary has >= 262144 rows and its negative-sampling
+                                0 = auto: 5 when the vocabulary has >= 131072 rows and its negative-sampling
                                     distribution is flat enough for lock attempts to succeed (expected failure
-                                    rate < 0.25) and no single row is busy enough to serialise its pairs behind its lock
-                                    (workers x p_row <= 0.5); otherwise (a skewed vocabulary, a small one, a block of a schedule of
-                                    >= 2 ranks) 8 when the tables are below 4 GiB and there are >= 32768 live rows; else 7 / 2 as
-                                    before (a head of at most V/8 rows carries the skew / everything by atomics);
+                                    rate < 0.4) and no single row is busy enough to serialise its pairs behind its lock
+                                    (workers x p_row <= 0.5: such rows alone leave the locks, 7); 7 when a head of at most V/4 rows carries
+                                    the skew; otherwise (a small vocabulary, a head too large, a block of a schedule of
+                                    >= 2 ranks on a flat vocabulary) 8 when the tables are below 4 GiB and a synchronous mini-batch of >= 1e6 items
+                                    (5e5 on rows of > 128 floats) keeps the busiest row below 2048 terms; else 2.  A vocabulary whose busiest row
+                                    caps the workers below a quarter of the device (at most 48 of a row's updates in flight) runs under 2.
+                                    The constants come from scripts/policy_sweep.py (profiles/r04_policy_sweep.txt);
                                 1 = agent-scope row read-modify-write, write-through (last writer of a row wins);
                                 2 = agent-scope loads + memory-side float atomics (no update is lost);
                                 3 = plain cached accesses (debug only: every XCD trains a private stale copy);
