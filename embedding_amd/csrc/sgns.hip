@@ -119,8 +119,11 @@ static int table_alloc(float** out, size_t floats, int device, hipStream_t st, i
     if (seen) *seen = 0;
     // small tables live in the caches: nothing to choose (and the probe needs rows to draw from)
     size_t free_b = 0, total_b = 0;
-    // (and tables of 4 GiB and more are left to hipMalloc: the runtime aborted inside the probing of a 4.5 GB virtual-memory allocation)
-    if (bytes < ((size_t)64 << 20) || bytes >= 0xFFFFFFFFull || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return dge_dev_alloc(out, floats);
+    // (and tables of 2 GiB and more are left to hipMalloc.  Round 3: the runtime aborted inside the probing of a 4.5 GB virtual-memory allocation.  Round 4: creating
+    //  nine models of 2 x 3.4 GB in one process — ~100 virtual-memory allocations of 3.4 GB made, probed and released — ended twice in four runs inside this function,
+    //  once as "Memory access fault by GPU node" under the probe kernel, once as an abort() of the runtime (tests/test_gpu_configs.py, full-size cfg5 on 8 ranks).
+    //  The placement classes were measured on half-gigabyte tables; above 2 GiB the choice is not worth a process.)
+    if (bytes < ((size_t)64 << 20) || bytes >= ((size_t)2 << 30) || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return dge_dev_alloc(out, floats);
     const int n_max = (int)std::max<size_t>(1, std::min<size_t>(TABLE_CANDIDATES, free_b / 4 / bytes));      // candidates may take a quarter of the free memory
     dge_tmp<float> sink;
     int rc = sink.alloc(4);
@@ -1516,12 +1519,17 @@ extern "C" int dge_write_vec(dge_model* m, const char* const* names, const char*
     const unsigned hw = std::thread::hardware_concurrency();
     const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, 16u), V * (int64_t)D / 65536));
     const int64_t slab = 4096 * (int64_t)n_thr;                                  // rows formatted before they are written
-    std::vector<std::string> out((size_t)n_thr);
+    // two sets of slab buffers: while slab k is being written (one thread, in row order), slab k + 1 is being formatted — the text file of cfg3 is 1.67 GB,
+    // and writing it takes as long as formatting it
+    std::vector<std::string> out[2] = {std::vector<std::string>((size_t)n_thr), std::vector<std::string>((size_t)n_thr)};
     bool ok = true;
-    for (int64_t r0 = 0; r0 < V && ok; r0 += slab) {
+    std::thread writer;
+    int cur = 0;
+    for (int64_t r0 = 0; r0 < V; r0 += slab, cur ^= 1) {
         const int64_t r1 = std::min(V, r0 + slab);
-        auto work = [&](int t) {
-            std::string& sbuf = out[(size_t)t]; sbuf.clear();
+        std::vector<std::string>& ob = out[cur];
+        auto work = [&, r0, r1](int t) {
+            std::string& sbuf = ob[(size_t)t]; sbuf.clear();
             const int64_t a = r0 + (r1 - r0) * t / n_thr, b = r0 + (r1 - r0) * (t + 1) / n_thr;
             char num[40];
             for (int64_t r = a; r < b; r++) {
@@ -1539,8 +1547,13 @@ extern "C" int dge_write_vec(dge_model* m, const char* const* names, const char*
             for (int t = 0; t < n_thr; t++) th.emplace_back(work, t);
             for (auto& x : th) x.join();
         }
-        for (int t = 0; t < n_thr && ok; t++) ok = out[(size_t)t].empty() || fwrite(out[(size_t)t].data(), 1, out[(size_t)t].size(), f) == out[(size_t)t].size();
+        if (writer.joinable()) writer.join();                                   // the previous slab is on its way to the file: now this one
+        if (!ok) break;
+        writer = std::thread([&ok, &ob, f, n_thr]() {
+            for (int t = 0; t < n_thr && ok; t++) ok = ob[(size_t)t].empty() || fwrite(ob[(size_t)t].data(), 1, ob[(size_t)t].size(), f) == ob[(size_t)t].size();
+        });
     }
+    if (writer.joinable()) writer.join();
     if (fclose(f) != 0 || !ok) DGE_FAIL(DGE_ERR_IO, "dge_write_vec: write to %s failed", path);
     return DGE_OK;
 }

@@ -237,10 +237,10 @@ int  dge_model_stats(const dge_model* m, dge_train_stats* out);
 int  dge_model_row_rates(dge_model* m, double* read_gb_per_s, double* rewrite_gb_per_s, double* lock_exchanges_per_s, double* table_lookups_per_s);
 int  dge_model_reset_stats(dge_model* m);
 /* Where the tables lie.  Allocations of hundreds of megabytes fall into discrete classes of memory, up to 15 % apart in how fast random rows can be read
-   and written back in them (profiles/r03_placement.txt, last block); dge_model_create therefore takes every table of 64 MB ... 4 GiB (syn1neg first) from
+   and written back in them (profiles/r03_placement.txt, last block); dge_model_create therefore takes every table of 64 MB ... 2 GiB (syn1neg first) from
    the best of up to 32 candidates — hipMalloc and virtual-memory allocations in turn, all held until the choice — under a 2-ms read-modify-write probe, and
    stops as soon as one candidate is 14 % above the slowest seen.  This reports, for table 0 (syn0), 1 (syn1neg) or 2 (syn1), how many candidates were
-   probed and the best (= the one kept) and worst probe rate in GB/s (0 candidates: the table was small or of 4 GiB and more, or the probe could not run). */
+   probed and the best (= the one kept) and worst probe rate in GB/s (0 candidates: the table was small or of 2 GiB and more, or the probe could not run). */
 int  dge_model_table_placement(const dge_model* m, int32_t table, int32_t* candidates, double* best_gb_per_s, double* worst_gb_per_s);
 /* The negative-sampling table's run form.  Rows are ordered by count; the rows of equal count form runs (up to 2 046 of them, counted from the vocabulary's tail; the head rows in front keep the table), the
    slot -> row map of word2vec's unigram^0.75 table is that many straight segments, and the lock kernels compute a negative's row from the run arrays in

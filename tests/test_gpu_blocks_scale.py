@@ -87,6 +87,7 @@ def test_cfg3_full_size_eight_rank_block_schedule(dge, dst, expect_one, expect_b
     auc8, loss8 = link_auc_device(ms[0], vid, test, R, NV)
     for m in ms:
         m.close()
+    print("\n[blocks %s] one GPU AUC %.4f loss %.4f | 8 ranks AUC %.4f loss %.4f | %s" % (dst, auc1, loss1, auc8, loss8, sch), flush=True)
     assert auc1 > 0.9, (auc1, auc8)
     # (measured, profiles/r04_blocks_quality.txt and this test: flat 0.9563 against 0.9590; Zipf destinations 0.9408 against 0.9459)
     assert abs(auc8 - auc1) < (0.005 if expect_block == 8 else 0.008) and abs(loss8 / loss1 - 1) < 0.06, dict(one_gpu=(auc1, loss1), eight_ranks=(auc8, loss8), schedule=sch)

@@ -327,4 +327,5 @@ def test_cfg5_tenth_size_eight_rank_block_schedule_predicts_like_one_gpu(dge):
     st1, sch1, auc1, loss1 = r["one"]; sts, sch, auc8, loss8 = r["blocks"]
     assert sum(s["pairs"] for s in sts) == st1["pairs"] > 3e8
     assert sch1["update_policy"] == 7 and sch["update_policy"] == 7 and sch["hot_rows"] > 0, (sch1, sch)
+    print("\n[blocks cfg5/10] one GPU AUC %.4f loss %.4f | 8 ranks AUC %.4f loss %.4f | %s" % (auc1, loss1, auc8, loss8, sch), flush=True)
     assert auc1 > 0.6 and abs(auc8 - auc1) < 0.008, dict(one_gpu=(auc1, loss1), eight_ranks=(auc8, loss8), schedule=sch)

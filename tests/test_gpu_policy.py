@@ -54,4 +54,5 @@ def test_auto_policy_is_fast_and_finite_off_the_bench_graphs(dge, V, s, D, expec
         r, _, fin = _rate(dge, cfg(pol), counts, corpus, N_WALKS)
         if fin:
             best[pol] = r
+    print("\n[policy V=%d s=%.1f D=%d] auto %.3e (%s) | forced %s" % (V, s, D, auto, sch, {k: "%.3e" % v for k, v in best.items()}), flush=True)
     assert auto >= 0.8 * max(best.values()), (auto, best, sch)
