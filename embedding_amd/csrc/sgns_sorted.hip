@@ -7,8 +7,10 @@
 // HBM rate; on a 25 MB table that is half the rows — exclusive access cannot be had, and the memory-side atomic rate (1.3 TB/s) is a
 // sixth of the plain rate.  Those tables fit the 256 MB Infinity Cache, so the remedy is to stop WRITING rows per update at all:
 //
-//   1. every (context row, target row, label) term of the batch becomes a 12-byte ITEM (k_sorted_emit) — the same pairs, window draws
-//      and negative draws as the other kernels make;
+//   1. every (context row, target row, label) term of the batch becomes an 8-byte ITEM (k_sorted_emit) — the same pairs, window draws
+//      and negative draws as the other kernels make.  (Round 4: one packed 64-bit word, key | other row | label, sorted on the key's bits only —
+//      a radix pass over 8-byte keys runs 1.3 - 1.4x a pass over (4-byte key, 8-byte value) pairs, scripts/micro/sort_keys64.hip; the learning
+//      rate left the item: a synchronous mini-batch trains at the rate of its first walk);
 //   2. the items are sorted by TARGET row (stable radix sort); a worker that owns a run of items of one row keeps that row in
 //      registers, reads the other side (syn0[context], read-only in this phase) through the caches, applies the row's updates one
 //      after the other exactly as the sequential loop would, and stores the row once (phase A).  The step g of every item is kept;
@@ -40,11 +42,10 @@ struct dge_sorted_work {
     int32_t* cnt = nullptr; int64_t* off = nullptr;
     void* scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
     // Two buffer sets: while mini-batch k runs its phases on the model's stream (bound by the caches), mini-batch k+1 is emitted and
-    // sorted by target row on a second stream (bound by table look-up latency and by HBM): set k % 2 holds (key0, val0) = emitted items,
-    // later phase A's output; (key1, val1) = the sorted items of whichever phase runs
+    // sorted by target row on a second stream (bound by table look-up latency and by HBM): set k % 2 holds it0 = emitted items,
+    // later phase A's output; it1 = the sorted items of whichever phase runs
     int64_t cap_items = 0;                       // item slots of every array
-    int32_t *key0[2] = {nullptr, nullptr}, *key1[2] = {nullptr, nullptr};
-    uint64_t *val0[2] = {nullptr, nullptr}, *val1[2] = {nullptr, nullptr};
+    uint64_t *it0[2] = {nullptr, nullptr}, *it1[2] = {nullptr, nullptr};
     void* sort_tmp[2] = {nullptr, nullptr}; size_t sort_tmp_bytes = 0;        // [0]: second stream (sort by target), [1]: model's stream (sort by context)
     hipStream_t aux = nullptr;
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -57,16 +58,14 @@ struct dge_sorted_work {
     // k_block_emit) instead of once per episode: bucket t holds, in walk order, the items of the pairs whose centre row is in partition t.
     int32_t* st_cnt = nullptr; int64_t* st_off = nullptr; int64_t st_cap_cells = 0;      // pairs per (bucket, walk) cell [n x walks], exclusive prefix
     void* st_scan_tmp = nullptr; size_t st_scan_bytes = 0;
-    int32_t* st_key = nullptr; uint64_t* st_val = nullptr; int64_t st_cap_items = 0;
+    uint64_t* st_it = nullptr; int64_t st_cap_items = 0;
     unsigned long long* st_words = nullptr;      // in-vocabulary tokens of the batch
     std::vector<int64_t> st_bucket0;             // first pair of every bucket (+ end)
     bool st_valid = false;
-    struct Key { const int32_t* sen; int64_t n_rows; uint64_t gen; int32_t L, W, K, part_n, part_ctx; int64_t gidx_base, words_done_base, all_words, V, T; double words_scale;
-                 float alpha0, min_alpha; uint64_t seed;
+    struct Key { const int32_t* sen; int64_t n_rows; uint64_t gen; int32_t L, W, K, part_n, part_ctx; int64_t gidx_base, V, T; uint64_t seed;      // (items carry no learning rate)
                  bool operator==(const Key& o) const {
                      return sen == o.sen && n_rows == o.n_rows && gen == o.gen && L == o.L && W == o.W && K == o.K && part_n == o.part_n && part_ctx == o.part_ctx &&
-                            gidx_base == o.gidx_base && words_done_base == o.words_done_base && all_words == o.all_words && V == o.V && T == o.T &&
-                            words_scale == o.words_scale && alpha0 == o.alpha0 && min_alpha == o.min_alpha && seed == o.seed;
+                            gidx_base == o.gidx_base && V == o.V && T == o.T && seed == o.seed;
                  } } st_key_of{};
 };
 
@@ -75,12 +74,12 @@ void dge_sorted_release(dge_model* m) {
     if (!s) return;
     if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
     for (int x = 0; x < 2; x++) {
-        dge_dev_free(s->key0[x]); dge_dev_free(s->key1[x]); dge_dev_free(s->val0[x]); dge_dev_free(s->val1[x]); dge_dev_free(s->sort_tmp[x]);
+        dge_dev_free(s->it0[x]); dge_dev_free(s->it1[x]); dge_dev_free(s->sort_tmp[x]);
         if (s->ev_ready[x]) (void)hipEventDestroy(s->ev_ready[x]);
         if (s->ev_done[x]) (void)hipEventDestroy(s->ev_done[x]);
     }
     dge_dev_free(s->cnt); dge_dev_free(s->off); dge_dev_free(s->scan_tmp); dge_dev_free(s->seg); dge_dev_free(s->scratch); dge_dev_free(s->d_marks); dge_dev_free(s->shadow);
-    dge_dev_free(s->st_cnt); dge_dev_free(s->st_off); dge_dev_free(s->st_scan_tmp); dge_dev_free(s->st_key); dge_dev_free(s->st_val); dge_dev_free(s->st_words);
+    dge_dev_free(s->st_cnt); dge_dev_free(s->st_off); dge_dev_free(s->st_scan_tmp); dge_dev_free(s->st_it); dge_dev_free(s->st_words);
     delete s;
     m->sorted = nullptr;
 }
@@ -90,8 +89,12 @@ struct SortedParams {
     const int32_t* cnt; const int64_t* off;      // pairs per (walk, centre) unit, exclusive prefix
     int64_t unit0, unit1;                        // units of this mini-batch
     int64_t pair0;                               // off[unit0]
-    int32_t* key_out; uint64_t* val_out;         // emit / phase A output
-    const int32_t* key_in; const uint64_t* val_in;
+    // An item is ONE 64-bit word.  Sorted by target (emit -> phase A): key << ks1 | other row << 1 | label (1 = a negative); sorted by context (phase A ->
+    // phase B): key << ks2 | target row << 11 | step code (label << 10 | the sigmoid table's index, 1000 / 1001 = saturated): the step is (label - sigma) x the
+    // mini-batch's learning rate on both sides, so the code carries it exactly.  The sorts look at the key's bits only (stable: the rest rides along).
+    uint64_t* it_out; const uint64_t* it_in;
+    int32_t ks1, ks2; uint32_t omask;            // ks1 = 1 + bits of a row number, ks2 = 11 + that; omask = (1 << bits) - 1
+    int64_t mb_walk0;                            // first walk of the mini-batch: the learning rate of all its items
     const int64_t* seg;                          // seg[k] = first sorted position with key >= k; seg[Vk] = valid items
     int64_t n_slots;                             // sorted array length (valid items first, then the skipped draws with key V)
     int32_t chunk;                               // items per work unit
@@ -111,6 +114,26 @@ __device__ __forceinline__ void unit_window(const TrainParams& p, int64_t w, int
     const int radius = p.W - (int)dge_fast_mod(s, (uint64_t)p.W, p.W_magic);
     lo = max(0, i - radius);
     hi = min(len - 1, i + radius);
+}
+
+// the learning rate of a synchronous mini-batch: that of its first walk (the exact count of in-vocabulary tokens that precede it)
+__device__ __forceinline__ float mb_alpha(const TrainParams& p, int64_t w0) {
+    const int64_t wbw = p.wb[w0];
+    const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
+    float alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
+    return alpha < p.min_alpha ? p.min_alpha : alpha;
+}
+// the step of one term as a code (the sigmoid table's index, 1000: f beyond +MAX_EXP, 1001: beyond -MAX_EXP) and back: (label - sigma) * alpha, word2vec.c's expression
+__device__ __forceinline__ int step_code(float f) {
+    if (f > (float)MAX_EXP) return 1000;
+    if (f < -(float)MAX_EXP) return 1001;
+    const int idx = (int)((f + (float)MAX_EXP) * (float)(EXP_TABLE_SIZE / MAX_EXP / 2));
+    return min(max(idx, 0), EXP_TABLE_SIZE - 1);
+}
+__device__ __forceinline__ float code_step(int code, float label, float alpha, const float* s_exp) {
+    if (code == 1000) return (label - 1.0f) * alpha;
+    if (code == 1001) return (label - 0.0f) * alpha;
+    return (label - s_exp[code]) * alpha;
 }
 
 // pairs of every (walk, centre) unit; totals of pairs and words for dge_model_stats
@@ -192,17 +215,13 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
     unsigned todo = (unsigned)(__ballot(my_cnt > 0) >> sh) & 0xFFFFu;
     if (!todo) return;
     // every lane prepares ITS unit (one round of loads for the whole group), the group then walks through the units' pairs
-    int64_t my_slot = 0; uint64_t my_s = 0; int my_lo = 0, my_hi = -1; float my_alpha = 0.f; int32_t my_word = -1;
+    int64_t my_slot = 0; uint64_t my_s = 0; int my_lo = 0, my_hi = -1; int32_t my_word = -1;
     if (my_cnt > 0) {
         const int64_t u = u0 + lane;
         const int64_t w = u / p.L; const int i = (int)(u % p.L);
         const int len = (int)p.len[w];
         my_word = p.sen[w * p.L + i];
         unit_window(p, w, i, len, my_s, my_lo, my_hi);
-        const int64_t wbw = p.wb[w];
-        const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
-        my_alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
-        if (my_alpha < p.min_alpha) my_alpha = p.min_alpha;
         my_slot = (q.off[u] - q.pair0) * (int64_t)(p.K + 1);
     }
     uint64_t mA = 1, cA = 0;
@@ -223,7 +242,6 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
         const int32_t* sen = p.sen + w * p.L;
         const int32_t word = __shfl(my_word, ul, 16);
         const int lo = __shfl(my_lo, ul, 16), hi = __shfl(my_hi, ul, 16);
-        const float alpha = __shfl(my_alpha, ul, 16);
         uint64_t s = shfl16_u64(my_s, ul);
         const uint64_t s_centre = s;
         int64_t slot = (int64_t)shfl16_u64((uint64_t)my_slot, ul);
@@ -250,13 +268,11 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
                         if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                         if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
                         const int64_t at = slot + (int64_t)z_l * (K + 1) + 1 + d_l;
-                        q.key_out[at] = t == word ? q.Vk : t / q.kdiv;
-                        q.val_out[at] = ((uint64_t)(uint32_t)last_mine << 32) | (uint64_t)__float_as_uint(-alpha);      // label 0: the sign bit
+                        q.it_out[at] = ((uint64_t)(uint32_t)(t == word ? q.Vk : t / q.kdiv) << q.ks1) | ((uint64_t)(uint32_t)last_mine << 1) | 1ull;      // bit 0: a negative
                     }
                     if (lane < npair) {
                         const int64_t at = slot + (int64_t)lane * (K + 1);
-                        q.key_out[at] = word / q.kdiv;
-                        q.val_out[at] = ((uint64_t)(uint32_t)last_pos << 32) | (uint64_t)__float_as_uint(alpha);
+                        q.it_out[at] = ((uint64_t)(uint32_t)(word / q.kdiv) << q.ks1) | ((uint64_t)(uint32_t)last_pos << 1);
                     }
                     if (K > 0 && p.part_n <= 1) s = shfl16_u64(sl, npair * K - 1);
                     slot += (int64_t)npair * (K + 1);
@@ -264,8 +280,8 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
                     const int cl = __builtin_ctz(live); live &= live - 1;
                     const int32_t lastv = __shfl(tok, cl, 16);
                     if (p.part_n > 1) s = dge_mix64(s_centre + (uint64_t)(c0 + cl));
-                    const uint64_t hi32 = (uint64_t)(uint32_t)lastv << 32;
-                    if (lane == 0) { q.key_out[slot] = word / q.kdiv; q.val_out[slot] = hi32 | (uint64_t)__float_as_uint(alpha); }
+                    const uint64_t oth = (uint64_t)(uint32_t)lastv << 1;
+                    if (lane == 0) q.it_out[slot] = ((uint64_t)(uint32_t)(word / q.kdiv) << q.ks1) | oth;
                     for (int kd = 0; kd < K; kd += 16) {
                         const int kc = min(16, K - kd);
                         const uint64_t sl = s * mA + cA;
@@ -273,8 +289,7 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
                             int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
                             if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                             if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
-                            q.key_out[slot + 1 + kd + lane] = t == word ? q.Vk : t / q.kdiv;
-                            q.val_out[slot + 1 + kd + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);
+                            q.it_out[slot + 1 + kd + lane] = ((uint64_t)(uint32_t)(t == word ? q.Vk : t / q.kdiv) << q.ks1) | oth | 1ull;
                         }
                         s = shfl16_u64(sl, kc - 1);
                     }
@@ -320,7 +335,7 @@ __global__ void __launch_bounds__(256) k_block_count(TrainParams p, int32_t* cel
     if ((threadIdx.x & 63) == 0 && words) atomicAdd(words_out, (unsigned long long)words);
 }
 
-__global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t* __restrict__ cell_off, int32_t* __restrict__ key_out, uint64_t* __restrict__ val_out, int32_t Vk) {
+__global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t* __restrict__ cell_off, uint64_t* __restrict__ it_out, int32_t Vk, int32_t ks1) {
     const int lane = threadIdx.x & 15;
     const int sh = threadIdx.x & 48;
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -333,10 +348,6 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
     const int32_t tk2 = lane + 32 < len ? sen[lane + 32] : -1, tk3 = lane + 48 < len ? sen[lane + 48] : -1;
     const uint64_t ctx_mask = part_token_mask(tk0, tk1, tk2, tk3, N, p.part_ctx);
     if (!ctx_mask) return;
-    const int64_t wbw = p.wb[w];
-    const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
-    float alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
-    if (alpha < p.min_alpha) alpha = p.min_alpha;
     // lane t keeps the next free pair position of bucket t
     int64_t my_pos = lane < N ? cell_off[(int64_t)lane * p.n_rows + w] : 0;
     uint64_t mA = 1, cA = 0;
@@ -380,20 +391,18 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
                     int32_t tk = dge_fast_div32(t, N, p.N_magic);              // part_row: the row of the bucket's partition nearest below the draw
                     if ((int64_t)tk * N + bucket >= p.V) tk--;
                     const int64_t at = slot + (int64_t)z_l * (K + 1) + 1 + d_l;
-                    key_out[at] = tk == wkey ? Vk : tk;
-                    val_out[at] = ((uint64_t)(uint32_t)last_mine << 32) | (uint64_t)__float_as_uint(-alpha);      // label 0: the sign bit
+                    it_out[at] = ((uint64_t)(uint32_t)(tk == wkey ? Vk : tk) << ks1) | ((uint64_t)(uint32_t)last_mine << 1) | 1ull;      // bit 0: a negative
                 }
                 if (lane < npair) {
                     const int64_t at = slot + (int64_t)lane * (K + 1);
-                    key_out[at] = wkey;
-                    val_out[at] = ((uint64_t)(uint32_t)last_pos << 32) | (uint64_t)__float_as_uint(alpha);
+                    it_out[at] = ((uint64_t)(uint32_t)wkey << ks1) | ((uint64_t)(uint32_t)last_pos << 1);
                 }
                 slot += (int64_t)npair * (K + 1);
             } else {                                         // more negatives than lanes: one pair per trip, 16 draws at a time
                 const int c = __builtin_ctzll(pm); pm &= pm - 1ull;
                 const int32_t lastv = walk_tok(true, sen, c, tk0, tk1, tk2, tk3);
-                const uint64_t hi32 = (uint64_t)(uint32_t)lastv << 32;
-                if (lane == 0) { key_out[slot] = wkey; val_out[slot] = hi32 | (uint64_t)__float_as_uint(alpha); }
+                const uint64_t oth = (uint64_t)(uint32_t)lastv << 1;
+                if (lane == 0) it_out[slot] = ((uint64_t)(uint32_t)wkey << ks1) | oth;
                 uint64_t sp = dge_mix64(s_centre + (uint64_t)c);
                 for (int kd = 0; kd < K; kd += 16) {
                     const int kc = min(16, K - kd);
@@ -403,8 +412,7 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
                         if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                         int32_t tk = dge_fast_div32(t, N, p.N_magic);
                         if ((int64_t)tk * N + bucket >= p.V) tk--;
-                        key_out[slot + 1 + kd + lane] = tk == wkey ? Vk : tk;
-                        val_out[slot + 1 + kd + lane] = hi32 | (uint64_t)__float_as_uint(-alpha);
+                        it_out[slot + 1 + kd + lane] = ((uint64_t)(uint32_t)(tk == wkey ? Vk : tk) << ks1) | oth | 1ull;
                     }
                     sp = shfl16_u64(sl, kc - 1);
                 }
@@ -423,18 +431,18 @@ __global__ void k_block_tally(unsigned long long* counters, unsigned long long p
 }
 
 // seg[k] = first position of the sorted keys that is >= k, k = 0 .. Vk+1  (seg[Vk] = number of valid items, seg[Vk+1] = n)
-__global__ void k_sorted_segments(const int32_t* __restrict__ keys, int64_t n, int64_t V, int64_t* seg) {
+__global__ void k_sorted_segments(const uint64_t* __restrict__ items, int ks, int64_t n, int64_t V, int64_t* seg) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > V + 1) return;
     int64_t lo = 0, hi = n;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)keys[mid] < r) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)(items[mid] >> ks) < r) lo = mid + 1; else hi = mid; }
     seg[r] = lo;
 }
 
 
-// One worker (16 lanes) per chunk of sorted items.  PB == false (phase A): key = target row (owned, syn1neg), value = context row |
-// signed alpha; the row takes its updates in item order, the step g of every item goes out with (context, target) for phase B.
-// PB == true (phase B): key = context row (owned, syn0), value = target row | g; the row takes the sum of g * syn1neg[target].
+// One worker (16 lanes) per chunk of sorted items.  PB == false (phase A): key = target row (owned, syn1neg), the item carries the context row and
+// the label; the row takes its updates in item order, the step of every item goes out as a code with (context, target) for phase B.
+// PB == true (phase B): key = context row (owned, syn0), the item carries the target row and the step's code; the row takes the sum of g * syn1neg[target].
 // A row that lies wholly inside the chunk is stored directly; a segment of a row shared with a neighbouring chunk leaves its DELTA in
 // scratch slot 2*chunk (the segment starts the chunk) or 2*chunk+1 (it ends the chunk), summed up by k_sorted_fixup.
 #define SORTED_PIPE 4      /* rows of the other side in flight per worker (8 measured the same: cfg2 3.5 ms per launch either way, an 8-rank block 62.5 against 62.7 ms) */
@@ -442,10 +450,8 @@ template <int DCH, bool PB>
 __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
     const TrainParams& p = q.t;
     __shared__ float s_exp[EXP_TABLE_SIZE];
-    if (!PB) {
-        for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
-        __syncthreads();
-    }
+    for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
+    __syncthreads();
     const int lane = threadIdx.x & 15;
     const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t start = chunk * q.chunk;
@@ -453,9 +459,10 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
     const int64_t end = min(start + (int64_t)q.chunk, q.n_slots);
     const int64_t n_valid = q.seg[q.Vk];
     if (!PB)            // the slots behind the valid items (skipped draws) stay invalid for the second sort
-        for (int64_t x = max(start, n_valid) + lane; x < end; x += 16) { q.key_out[x] = q.Vk; q.val_out[x] = 0; }
+        for (int64_t x = max(start, n_valid) + lane; x < end; x += 16) q.it_out[x] = (uint64_t)(uint32_t)q.Vk << q.ks2;
     if (start >= n_valid) return;
     const int64_t stop = min(end, n_valid);
+    const float alpha = mb_alpha(p, q.mb_walk0);   // a synchronous mini-batch trains at the learning rate of its first walk
 
     const TableView own = make_view(PB ? p.syn0 : p.syn1neg, p.V, p.stride);
     const TableView oth = make_view(PB ? p.syn1neg : p.syn0, p.V, p.stride);
@@ -463,6 +470,7 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
     const TableView shd = make_view(q.shadow, q.Vk, p.stride);            // (indexed by key: only the rows of the target partition exist in it)
 
     const int32_t kpart = PB ? q.kpart_ctx : q.kpart_tgt;
+    const int ks = PB ? q.ks2 : q.ks1, osh = PB ? 11 : 1;
 #define OWN_ROW(k_) ((k_) * q.kdiv + kpart)
     int32_t cur = -1;                              // key of the open segment
     int64_t seg_start = start;
@@ -490,22 +498,24 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
     for (int64_t base = start; base < stop; base += 16) {
         // 16 items at a time: lane l holds item base + l
         const int64_t mine = base + lane;
-        int32_t k_l = -1; uint64_t v_l = 0;
+        uint64_t it_l = 0;
         // (items are read once and written once: non-temporal, not to displace table rows in the caches — an 8-rank block 61.9 against 62.4 ms per
         //  episode, cfg2 3.4 against 3.5 ms; the same hint on the item GENERATORS' stores cost 3 %: the sort that follows wants them cached)
-        if (mine < stop) { k_l = __builtin_nontemporal_load(q.key_in + mine); v_l = __builtin_nontemporal_load(q.val_in + mine); }
+        if (mine < stop) it_l = __builtin_nontemporal_load(q.it_in + mine);
+        const int32_t k_l = mine < stop ? (int32_t)(it_l >> ks) : -1;
+        const uint32_t o_l = (uint32_t)(it_l >> osh) & q.omask;             // the other side's row
+        const uint32_t c_l = PB ? (uint32_t)it_l & 0x7FFu : (uint32_t)it_l & 1u;      // phase B: the step's code; phase A: the label bit
         const int nb = (int)min((int64_t)16, stop - base);
-        float out_g = 0.f;                          // phase A: the step of the item this lane holds
+        int out_c = 0;                              // phase A: the code of the step of the item this lane holds
         for (int g0 = 0; g0 < nb; g0 += SORTED_PIPE) {
             Row<DCH> o[SORTED_PIPE];
-            int32_t key[SORTED_PIPE]; uint32_t vhi[SORTED_PIPE], vlo[SORTED_PIPE];
+            int32_t key[SORTED_PIPE]; uint32_t oc[SORTED_PIPE];
 #pragma unroll
             for (int z = 0; z < SORTED_PIPE; z++) {
                 const int src = min(g0 + z, nb - 1);
                 key[z] = __shfl(k_l, src, 16);
-                vhi[z] = (uint32_t)__shfl((int)(uint32_t)(v_l >> 32), src, 16);
-                vlo[z] = (uint32_t)__shfl((int)(uint32_t)v_l, src, 16);
-                rowA_load<DCH, 0, false>(o[z], oth, (int32_t)vhi[z], lane);
+                oc[z] = (uint32_t)__shfl((int)c_l, src, 16);
+                rowA_load<DCH, 0, false>(o[z], oth, (int32_t)(uint32_t)__shfl((int)o_l, src, 16), lane);
             }
 #pragma unroll
             for (int z = 0; z < SORTED_PIPE; z++) {
@@ -518,22 +528,20 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
                     if (!PB) rowA_load<DCH, 0, false>(h, own, OWN_ROW(cur), lane);
                 }
                 if (PB) {
-                    row_axpy(d, __uint_as_float(vlo[z]), o[z]);
+                    row_axpy(d, code_step((int)(oc[z] & 0x3FFu), (oc[z] >> 10) ? 0.0f : 1.0f, alpha, s_exp), o[z]);
                 } else {
-                    const float a = __uint_as_float(vlo[z]);
-                    const float f = row_dot(h, o[z]);
-                    const float g = sgns_g(f, (vlo[z] >> 31) ? 0.0f : 1.0f, fabsf(a), s_exp);
+                    const float label = oc[z] ? 0.0f : 1.0f;
+                    const int code = step_code(row_dot(h, o[z]));
+                    const float g = code_step(code, label, alpha, s_exp);
                     row_axpy(h, g, o[z]);
                     row_axpy(d, g, o[z]);
-                    if (lane == g0 + z) out_g = g;               // (the item's record for the second sort leaves with the other 15 of its batch, below)
+                    if (lane == g0 + z) out_c = code | (int)(oc[z] << 10);         // (the item's record for the second sort leaves with the other 15 of its batch, below)
                 }
             }
         }
-        // phase A: (context key, target row | step) of the 16 items, one coalesced store each instead of 32 single-lane ones
-        if (!PB && mine < stop) {
-            __builtin_nontemporal_store((int32_t)(uint32_t)(v_l >> 32) / q.kdiv, q.key_out + mine);
-            __builtin_nontemporal_store(((uint64_t)(uint32_t)OWN_ROW(k_l) << 32) | (uint64_t)__float_as_uint(out_g), q.val_out + mine);
-        }
+        // phase A: context key | target row | step code of the 16 items, one coalesced store
+        if (!PB && mine < stop)
+            __builtin_nontemporal_store(((uint64_t)(o_l / (uint32_t)q.kdiv) << q.ks2) | ((uint64_t)(uint32_t)OWN_ROW(k_l) << 11) | (uint64_t)(uint32_t)out_c, q.it_out + mine);
     }
     SORTED_CLOSE(stop);
 #undef SORTED_CLOSE
@@ -551,7 +559,7 @@ __global__ void __launch_bounds__(256) k_sorted_fixup(SortedParams q, int phase_
     const int64_t start = chunk * q.chunk;
     if (start >= n_valid) return;
     const int64_t end = min(start + (int64_t)q.chunk, n_valid);
-    const int32_t kr = q.key_in[end - 1];                             // the key of the chunk's last item, its row
+    const int32_t kr = (int32_t)(q.it_in[end - 1] >> (phase_b ? q.ks2 : q.ks1));      // the key of the chunk's last item, its row
     const int32_t r = kr * q.kdiv + (phase_b ? q.kpart_ctx : q.kpart_tgt);
     const int64_t r0 = q.seg[kr], r1 = q.seg[kr + 1];
     if (r1 <= end || r0 < start) return;                              // it ends here, or it began in an earlier chunk
@@ -622,16 +630,18 @@ struct CastI64 { __host__ __device__ int64_t operator()(int32_t x) const { retur
 // 3 passes there and 2 with 9-bit digits (scripts/micro/sort_bits.hip: 48 M items of 17 bits 1.01 ms against 1.15, 12.8 M 0.31 against 0.37;
 // 10-bit digits lose more per pass than they save).
 typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<512, 12>, 9,
+                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<512, 16>, 9,
                                                                        rocprim::block_radix_rank_algorithm::match>> SortWide;
-static hipError_t sort_items(void* tmp, size_t& bytes, const int32_t* k_in, int32_t* k_out, const uint64_t* v_in, uint64_t* v_out, int64_t n, int end_bit, hipStream_t st) {
-    if (end_bit > 16 && end_bit <= 18) return rocprim::radix_sort_pairs<SortWide>(tmp, bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)end_bit, st);
-    return rocprim::radix_sort_pairs(tmp, bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)end_bit, st);
+// items are single 64-bit words sorted on the key's bits [shift, shift + key_bits) only: stable, the low bits (other row, label / step code) ride along
+// (scripts/micro/sort_keys64.hip: 12.8 M items of 17 key bits 0.230 ms against 0.304 ms as (4-byte key, 8-byte value) pairs, 48 M 0.705 against 0.988)
+static hipError_t sort_items(void* tmp, size_t& bytes, const uint64_t* in, uint64_t* out, int64_t n, int shift, int key_bits, hipStream_t st) {
+    if (key_bits > 16 && key_bits <= 18) return rocprim::radix_sort_keys<SortWide>(tmp, bytes, in, out, (size_t)n, (unsigned)shift, (unsigned)(shift + key_bits), st);
+    return rocprim::radix_sort_keys(tmp, bytes, in, out, (size_t)n, (unsigned)shift, (unsigned)(shift + key_bits), st);
 }
 static size_t sort_items_tmp_bytes(int64_t cap) {
     size_t a = 0, b = 0;
-    (void)sort_items(nullptr, a, nullptr, nullptr, nullptr, nullptr, cap, 18, 0);
-    (void)sort_items(nullptr, b, nullptr, nullptr, nullptr, nullptr, cap, 31, 0);
+    (void)sort_items(nullptr, a, nullptr, nullptr, cap, 30, 18, 0);
+    (void)sort_items(nullptr, b, nullptr, nullptr, cap, 30, 31, 0);
     return std::max(a, b);
 }
 
@@ -672,9 +682,12 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     // batch's n episodes — when they fit: at most half of the free memory (cfg3 at 8 ranks: 27.6 GB); otherwise episode by episode as before
     bool use_store = p.part_n > 1 && p.part_n <= 16 && p.L <= 64 && (int64_t)p.part_n * p.n_rows + 1 < 0x7fffffffll;
     int64_t total_pairs = 0;
+    // the packed item's fields: `obits` bits of a row number (tables below 4 GiB: V < 2^24 at the narrowest stride), the key above them
+    int obits = 1;
+    while ((1ll << obits) < m->V) obits++;
+    const int ks1 = 1 + obits, ks2 = 11 + obits;
     if (use_store) {
-        const dge_sorted_work::Key key{p.sen, p.n_rows, m->seen_gen, p.L, p.W, p.K, p.part_n, p.part_ctx, p.gidx_base, p.words_done_base, p.all_words, p.V, p.T,
-                                       p.words_scale, p.alpha0, p.min_alpha, p.seed};
+        const dge_sorted_work::Key key{p.sen, p.n_rows, m->seen_gen, p.L, p.W, p.K, p.part_n, p.part_ctx, p.gidx_base, p.V, p.T, p.seed};
         const int64_t n_cells = (int64_t)p.part_n * p.n_rows;
         if (!(s->st_valid && m->seen_gen != 0 && key == s->st_key_of)) {
             s->st_valid = false;
@@ -709,20 +722,19 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
             const int64_t all_items = s->st_bucket0[(size_t)p.part_n] * K1;
             size_t free_b = 0, total_b = 0;
             DGE_HIP(hipMemGetInfo(&free_b, &total_b));
-            const size_t have = (size_t)s->st_cap_items * 12;
-            if ((size_t)all_items * 12 > have + (free_b + have) / 2) use_store = false;       // does not fit: this batch runs episode by episode
+            const size_t have = (size_t)s->st_cap_items * 8;
+            if ((size_t)all_items * 8 > have + (free_b + have) / 2) use_store = false;       // does not fit: this batch runs episode by episode
             else {
                 if (all_items > s->st_cap_items) {
                     if (s->aux) DGE_HIP(hipStreamSynchronize(s->aux));
-                    dge_dev_free(s->st_key); dge_dev_free(s->st_val); s->st_key = nullptr; s->st_val = nullptr; s->st_cap_items = 0;
+                    dge_dev_free(s->st_it); s->st_it = nullptr; s->st_cap_items = 0;
                     const int64_t cap = all_items + all_items / 16 + 1024;
-                    if ((rc = dge_dev_alloc(&s->st_key, (size_t)cap))) return rc;
-                    if ((rc = dge_dev_alloc(&s->st_val, (size_t)cap))) return rc;
+                    if ((rc = dge_dev_alloc(&s->st_it, (size_t)cap))) return rc;
                     s->st_cap_items = cap;
                 }
                 if (all_items > 0)
-                    hipLaunchKernelGGL(k_block_emit, dim3(grid_for(p.n_rows * 16, 256)), dim3(256), 0, st, p, s->st_off, s->st_key, s->st_val,
-                                       (int32_t)((m->V + p.part_n - 1) / p.part_n));
+                    hipLaunchKernelGGL(k_block_emit, dim3(grid_for(p.n_rows * 16, 256)), dim3(256), 0, st, p, s->st_off, s->st_it,
+                                       (int32_t)((m->V + p.part_n - 1) / p.part_n), (int32_t)ks1);
                 DGE_HIP(hipGetLastError());
                 s->st_key_of = key; s->st_valid = true;
             }
@@ -783,8 +795,9 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     if (g_dge_tuning[DGE_TUNE_SORTED_CHUNK] > 0) chunk = (int)std::min<int64_t>(g_dge_tuning[DGE_TUNE_SORTED_CHUNK], 1 << 20);
     const int kdiv = std::max(p.part_n, 1);
     const int64_t Vk = (m->V + kdiv - 1) / kdiv;
-    int end_bit = 1;
-    while (end_bit < 31 && (1ll << end_bit) <= Vk) end_bit++;                 // keys are 0 .. Vk (Vk = a skipped draw)
+    int key_bits = 1;
+    while (key_bits < 31 && (1ll << key_bits) <= Vk) key_bits++;              // keys are 0 .. Vk (Vk = a skipped draw)
+    if (ks2 + key_bits > 64) DGE_FAIL(DGE_ERR_ARG, "update_policy 8: %lld vocabulary rows do not fit the packed item", (long long)m->V);
     if (!s->aux) {
         DGE_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
         for (int x = 0; x < 2; x++) {
@@ -797,15 +810,13 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         const int64_t cap = max_slots + max_slots / 8 + 1024;
         size_t b = 0;
         for (int x = 0; x < 2; x++) {
-            dge_dev_free(s->key0[x]); dge_dev_free(s->key1[x]); dge_dev_free(s->val0[x]); dge_dev_free(s->val1[x]); dge_dev_free(s->sort_tmp[x]);
-            s->key0[x] = s->key1[x] = nullptr; s->val0[x] = s->val1[x] = nullptr; s->sort_tmp[x] = nullptr;
+            dge_dev_free(s->it0[x]); dge_dev_free(s->it1[x]); dge_dev_free(s->sort_tmp[x]);
+            s->it0[x] = s->it1[x] = nullptr; s->sort_tmp[x] = nullptr;
         }
         s->cap_items = 0; s->set_used[0] = s->set_used[1] = false;
         for (int x = 0; x < 2; x++) {
-            if ((rc = dge_dev_alloc(&s->key0[x], (size_t)cap))) return rc;
-            if ((rc = dge_dev_alloc(&s->key1[x], (size_t)cap))) return rc;
-            if ((rc = dge_dev_alloc(&s->val0[x], (size_t)cap))) return rc;
-            if ((rc = dge_dev_alloc(&s->val1[x], (size_t)cap))) return rc;
+            if ((rc = dge_dev_alloc(&s->it0[x], (size_t)cap))) return rc;
+            if ((rc = dge_dev_alloc(&s->it1[x], (size_t)cap))) return rc;
             b = sort_items_tmp_bytes(cap);
             DGE_HIP(hipMalloc(&s->sort_tmp[x], b ? b : 1));
         }
@@ -834,6 +845,7 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     SortedParams q;
     q.t = p; q.cnt = s->cnt; q.off = s->off; q.seg = s->seg; q.chunk = chunk; q.scratch = s->scratch; q.shadow = s->shadow;
     q.kdiv = kdiv; q.kpart_tgt = p.part_n > 1 ? p.part_tgt : 0; q.kpart_ctx = p.part_n > 1 ? p.part_ctx : 0; q.Vk = (int32_t)Vk;
+    q.ks1 = ks1; q.ks2 = ks2; q.omask = (uint32_t)((1ull << obits) - 1ull); q.mb_walk0 = 0; q.it_in = nullptr; q.it_out = nullptr;
     int64_t* const seg_a[2] = {s->seg, s->seg + Vk + 2}; int64_t* const seg_b = s->seg + 2 * (Vk + 2);
     const int dch = m->stride / 64;
     // (the offsets were read back above: everything the second stream reads — counts, offsets, walks, the unigram table — is in place)
@@ -843,24 +855,25 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         if (n == 0) continue;
         const int x = (int)(live++ & 1);
         q.unit0 = marks[(size_t)k]; q.unit1 = marks[(size_t)k + 1]; q.pair0 = h_off[(size_t)k]; q.n_slots = n;      // (unit0, unit1, pair0: the per-episode emit only)
-        // second stream: items -> (key0, val0); sorted by target row -> (key1, val1); row segments
+        // second stream: items -> it0; sorted by target row -> it1; row segments
         if (s->set_used[x]) DGE_HIP(hipStreamWaitEvent(s->aux, s->ev_done[x], 0));         // the mini-batch that held this set has finished
-        q.key_out = s->key0[x]; q.val_out = s->val0[x];
-        const int32_t* src_key = s->key0[x]; const uint64_t* src_val = s->val0[x];
-        if (use_store) { src_key = s->st_key + h_off[(size_t)k] * K1; src_val = s->st_val + h_off[(size_t)k] * K1; }      // the batch's items are already there
+        q.it_out = s->it0[x];
+        q.mb_walk0 = std::min(k * walks_per, p.n_rows - 1);                                 // the mini-batch's learning rate: that of its first walk
+        const uint64_t* src = s->it0[x];
+        if (use_store) src = s->st_it + h_off[(size_t)k] * K1;                              // the batch's items are already there
         else hipLaunchKernelGGL(k_sorted_emit, dim3(grid_for(q.unit1 - q.unit0 + 15, 256)), dim3(256), 0, s->aux, q);      // one 16-lane group per 16 units
         size_t b = s->sort_tmp_bytes;
-        DGE_HIP(sort_items(s->sort_tmp[0], b, src_key, s->key1[x], src_val, s->val1[x], n, end_bit, s->aux));
-        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(Vk + 2, 256)), dim3(256), 0, s->aux, s->key1[x], n, Vk, seg_a[x]);
+        DGE_HIP(sort_items(s->sort_tmp[0], b, src, s->it1[x], n, ks1, key_bits, s->aux));
+        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(Vk + 2, 256)), dim3(256), 0, s->aux, s->it1[x], ks1, n, Vk, seg_a[x]);
         DGE_HIP(hipEventRecord(s->ev_ready[x], s->aux));
-        // model's stream — phase A: target rows move (into the shadow table); (context, target | g) -> (key0, val0)
+        // model's stream — phase A: target rows move (into the shadow table); context key | target row | step code -> it0
         DGE_HIP(hipStreamWaitEvent(st, s->ev_ready[x], 0));
-        q.key_in = s->key1[x]; q.val_in = s->val1[x]; q.key_out = s->key0[x]; q.val_out = s->val0[x]; q.seg = seg_a[x];
+        q.it_in = s->it1[x]; q.it_out = s->it0[x]; q.seg = seg_a[x];
         launch_phase_any(dch, q, false, st);
-        // sorted by context row -> (key1, val1); phase B: context rows take their sums
+        // sorted by context row -> it1; phase B: context rows take their sums
         b = s->sort_tmp_bytes;
-        DGE_HIP(sort_items(s->sort_tmp[1], b, s->key0[x], s->key1[x], s->val0[x], s->val1[x], n, end_bit, st));
-        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(Vk + 2, 256)), dim3(256), 0, st, s->key1[x], n, Vk, seg_b);
+        DGE_HIP(sort_items(s->sort_tmp[1], b, s->it0[x], s->it1[x], n, ks2, key_bits, st));
+        hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(Vk + 2, 256)), dim3(256), 0, st, s->it1[x], ks2, n, Vk, seg_b);
         q.seg = seg_b;
         launch_phase_any(dch, q, true, st);            // reads the target rows as they stood BEFORE the mini-batch
         launch_commit_any(dch, q, seg_a[x], st);

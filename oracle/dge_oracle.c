@@ -753,10 +753,11 @@ static int64_t train_block_sorted(const orc_train_config* cfg, orc_model* m, con
         const int64_t w1 = w0 + per < n_walks ? w0 + per : n_walks;
         int64_t cap = 1024, n = 0;
         so_item* a = (so_item*)malloc((size_t)cap * sizeof(so_item));
+        /* a synchronous mini-batch trains at ONE learning rate, that of its first walk (round 4: the device's items are single 64-bit words without a rate) */
+        const float alpha = alpha_for(cfg, (int64_t)ep * m->total_words + cfg->words_before + wb[w0], all_words);
         for (int64_t w = w0; w < w1; w++) {
             int32_t buf[4096]; int len = 0;
             for (int j = 0; j < max_len && len < 4096; j++) { int32_t r = sen[w * max_len + j]; if (r >= 0) buf[len++] = r; }
-            const float alpha = alpha_for(cfg, (int64_t)ep * m->total_words + cfg->words_before + wb[w], all_words);
             const int64_t gbase = (((int64_t)ep * total_walks) + cfg->walk_index_base + w) * (int64_t)max_len;
             for (int i = 0; i < len; i++) {
                 const int32_t word = buf[i];

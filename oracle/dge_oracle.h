@@ -88,7 +88,8 @@ typedef struct orc_train_config {
                                 row, a row's items applied in order by chunks of sorted_chunk items (a row that straddles chunk
                                 borders: independent segments from the same starting row, deltas added in chunk order), the step g
                                 of every item kept; items sorted by context row, every context row takes the sum of g * target row.
-                                Lane order of the 16-byte-per-lane row layout.  Deterministic whatever the worker count. */
+                                Lane order of the 16-byte-per-lane row layout.  A mini-batch trains at the learning rate of its first walk.
+                                Deterministic whatever the worker count. */
     int32_t sorted_walks;    /* walks per synchronous mini-batch (0 = all walks of the launch) */
 } orc_train_config;
 
