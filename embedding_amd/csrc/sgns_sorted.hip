@@ -634,15 +634,22 @@ typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_con
                                                                        rocprim::block_radix_rank_algorithm::match>> SortWide;
 // items are single 64-bit words sorted on the key's bits [shift, shift + key_bits) only: stable, the low bits (other row, label / step code) ride along
 // (scripts/micro/sort_keys64.hip: 12.8 M items of 17 key bits 0.230 ms against 0.304 ms as (4-byte key, 8-byte value) pairs, 48 M 0.705 against 0.988)
+// (19 .. 20 key bits — a block of the 2-rank schedule on cfg3, a flat vocabulary of up to a million rows: two passes of 10-bit digits, 48 M items 0.970 ms
+//  against 0.998 with three of 9 bits and 1.436 ms as pairs with rocprim's 8-bit default)
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<512, 16>, 10,
+                                                                       rocprim::block_radix_rank_algorithm::match>> SortWide10;
 static hipError_t sort_items(void* tmp, size_t& bytes, const uint64_t* in, uint64_t* out, int64_t n, int shift, int key_bits, hipStream_t st) {
     if (key_bits > 16 && key_bits <= 18) return rocprim::radix_sort_keys<SortWide>(tmp, bytes, in, out, (size_t)n, (unsigned)shift, (unsigned)(shift + key_bits), st);
+    if (key_bits > 18 && key_bits <= 20) return rocprim::radix_sort_keys<SortWide10>(tmp, bytes, in, out, (size_t)n, (unsigned)shift, (unsigned)(shift + key_bits), st);
     return rocprim::radix_sort_keys(tmp, bytes, in, out, (size_t)n, (unsigned)shift, (unsigned)(shift + key_bits), st);
 }
 static size_t sort_items_tmp_bytes(int64_t cap) {
-    size_t a = 0, b = 0;
+    size_t a = 0, b = 0, c = 0;
     (void)sort_items(nullptr, a, nullptr, nullptr, cap, 30, 18, 0);
     (void)sort_items(nullptr, b, nullptr, nullptr, cap, 30, 31, 0);
-    return std::max(a, b);
+    (void)sort_items(nullptr, c, nullptr, nullptr, cap, 30, 20, 0);
+    return std::max(std::max(a, b), c);
 }
 
 typedef hipcub::TransformInputIterator<int64_t, CastI64, const int32_t*> CountIter;      // pair counts summed in 64 bits (an epoch-long launch has > 2^31 pairs)
