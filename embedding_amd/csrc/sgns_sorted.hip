@@ -54,6 +54,7 @@ struct dge_sorted_work {
     float* shadow = nullptr; int64_t cap_shadow = 0;   // the target rows as phase A leaves them, committed after phase B
     float* scratch = nullptr; int64_t cap_scratch_rows = 0;
     int64_t* d_marks = nullptr; int64_t cap_marks = 0;
+    int64_t* h_marks = nullptr; int64_t cap_h_marks = 0;      // pinned: the one read-back of a launch (first pair of every mini-batch) lands here
     // Block schedule: the items of ALL n target partitions of a rank's context partition, made once per global batch (k_block_count /
     // k_block_emit) instead of once per episode: bucket t holds, in walk order, the items of the pairs whose centre row is in partition t.
     int32_t* st_cnt = nullptr; int64_t* st_off = nullptr; int64_t st_cap_cells = 0;      // pairs per (bucket, walk) cell [n x walks], exclusive prefix
@@ -80,6 +81,7 @@ void dge_sorted_release(dge_model* m) {
     }
     dge_dev_free(s->cnt); dge_dev_free(s->off); dge_dev_free(s->scan_tmp); dge_dev_free(s->seg); dge_dev_free(s->scratch); dge_dev_free(s->d_marks); dge_dev_free(s->shadow);
     dge_dev_free(s->st_cnt); dge_dev_free(s->st_off); dge_dev_free(s->st_scan_tmp); dge_dev_free(s->st_it); dge_dev_free(s->st_words);
+    if (s->h_marks) (void)hipHostFree(s->h_marks);
     delete s;
     m->sorted = nullptr;
 }
@@ -199,6 +201,11 @@ __global__ void __launch_bounds__(256) k_sorted_count_walks(TrainParams p, int32
 __global__ void k_sorted_marks(const int64_t* off, const int64_t* units, int n, int64_t* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = off[units[i]];
+}
+// first pair of every mini-batch of `walks_per` walks: off[base + min(k * walks_per, n_rows) * mult], k = 0 .. n - 1 (no marks travel from the host)
+__global__ void k_sorted_marks_walks(const int64_t* off, int64_t base, int64_t mult, int64_t walks_per, int64_t n_rows, int n, int64_t* out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = off[base + min((int64_t)k * walks_per, n_rows) * mult];
 }
 
 // items of one mini-batch: slot (pair - pair0) * (K+1) + d holds term d of the pair (d = 0: the centre, label 1; d >= 1: negative d).
@@ -634,22 +641,17 @@ typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_con
                                                                        rocprim::block_radix_rank_algorithm::match>> SortWide;
 // items are single 64-bit words sorted on the key's bits [shift, shift + key_bits) only: stable, the low bits (other row, label / step code) ride along
 // (scripts/micro/sort_keys64.hip: 12.8 M items of 17 key bits 0.230 ms against 0.304 ms as (4-byte key, 8-byte value) pairs, 48 M 0.705 against 0.988)
-// (19 .. 20 key bits — a block of the 2-rank schedule on cfg3, a flat vocabulary of up to a million rows: two passes of 10-bit digits, 48 M items 0.970 ms
-//  against 0.998 with three of 9 bits and 1.436 ms as pairs with rocprim's 8-bit default)
-typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<512, 16>, 10,
-                                                                       rocprim::block_radix_rank_algorithm::match>> SortWide10;
+// (19 .. 20 key bits — a block of the 2-rank schedule on cfg3 —: two passes of 10-bit digits measured 0.970 ms against 0.998 alone on 48 M items and nothing
+//  in the trainer (8.09 against 8.20e8 edges/s): rocprim's default stays there)
 static hipError_t sort_items(void* tmp, size_t& bytes, const uint64_t* in, uint64_t* out, int64_t n, int shift, int key_bits, hipStream_t st) {
     if (key_bits > 16 && key_bits <= 18) return rocprim::radix_sort_keys<SortWide>(tmp, bytes, in, out, (size_t)n, (unsigned)shift, (unsigned)(shift + key_bits), st);
-    if (key_bits > 18 && key_bits <= 20) return rocprim::radix_sort_keys<SortWide10>(tmp, bytes, in, out, (size_t)n, (unsigned)shift, (unsigned)(shift + key_bits), st);
     return rocprim::radix_sort_keys(tmp, bytes, in, out, (size_t)n, (unsigned)shift, (unsigned)(shift + key_bits), st);
 }
 static size_t sort_items_tmp_bytes(int64_t cap) {
-    size_t a = 0, b = 0, c = 0;
+    size_t a = 0, b = 0;
     (void)sort_items(nullptr, a, nullptr, nullptr, cap, 30, 18, 0);
     (void)sort_items(nullptr, b, nullptr, nullptr, cap, 30, 31, 0);
-    (void)sort_items(nullptr, c, nullptr, nullptr, cap, 30, 20, 0);
-    return std::max(std::max(a, b), c);
+    return std::max(a, b);
 }
 
 typedef hipcub::TransformInputIterator<int64_t, CastI64, const int32_t*> CountIter;      // pair counts summed in 64 bits (an epoch-long launch has > 2^31 pairs)
@@ -769,19 +771,25 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     else hipLaunchKernelGGL(k_sorted_count, dim3(grid_for(n_units, 256)), dim3(256), 0, st, p, s->cnt);
     { size_t b = s->scan_tmp_bytes; DGE_HIP(hipcub::DeviceScan::ExclusiveSum(s->scan_tmp, b, CountIter(s->cnt, CastI64()), s->off, n_units + 1, st)); }
 
-    // mini-batches of whole walks (dge_sorted_batch_items: ~96 items per live row, the hottest row bounded)
-    DGE_HIP(hipMemcpyAsync(&total_pairs, s->off + n_units, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    DGE_HIP(hipStreamSynchronize(st));
-    if (total_pairs == 0) return DGE_OK;
     }
+    // mini-batches of whole walks (dge_sorted_batch_items: ~128 items per live row, the hottest row bounded).  How many walks make one: under the item store the
+    // bucket's pair count is on the host already; otherwise from the EXPECTED pairs of a full-length walk (DL4J's window: radius uniform in 1 .. W) — round 4: the
+    // launch's pair total used to be read back for this, one of two host round trips that cost a cfg2 launch ~8 % (shorter walks only make mini-batches smaller)
     int64_t want_items = dge_sorted_batch_items(m, p.part_n);
     if (want_items == 0) want_items = 1 << 20;         // asked for explicitly on a vocabulary the rule would not pick it for: smallest mini-batches
-    const double items_per_walk = (double)total_pairs * K1 / (double)p.n_rows;
+    double items_per_walk;
+    if (use_store) items_per_walk = (double)total_pairs * K1 / (double)p.n_rows;
+    else {
+        double e = 0.0;
+        for (int i = 0; i < p.L; i++)
+            for (int r = 1; r <= p.W; r++) e += (double)(std::min(p.L - 1, i + r) - std::max(0, i - r)) / (double)p.W;
+        items_per_walk = e * K1;
+    }
     int64_t walks_per = std::max<int64_t>(1, (int64_t)((double)want_items / std::max(items_per_walk, 1e-9)));
     if (g_dge_tuning[DGE_TUNE_SORTED_WALKS] > 0) walks_per = g_dge_tuning[DGE_TUNE_SORTED_WALKS];
     walks_per = std::min(walks_per, p.n_rows);
     const int64_t n_sub = (p.n_rows + walks_per - 1) / walks_per;
-    std::vector<int64_t> marks((size_t)n_sub + 1), h_off((size_t)n_sub + 1);
+    std::vector<int64_t> marks((size_t)n_sub + 1);
     // marks: the unit (per-episode path) or the (bucket, walk) cell (item store) at which every mini-batch begins -> its first pair
     for (int64_t k = 0; k <= n_sub; k++) marks[(size_t)k] = use_store ? (int64_t)p.part_tgt * p.n_rows + std::min(k * walks_per, p.n_rows) : std::min(k * walks_per, p.n_rows) * p.L;
     if (n_sub + 1 > s->cap_marks) {
@@ -790,13 +798,22 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         if ((rc = dge_dev_alloc(&s->d_marks, 2 * ((size_t)n_sub + 1)))) return rc;
         s->cap_marks = n_sub + 1;
     }
-    DGE_HIP(hipMemcpyAsync(s->d_marks, marks.data(), ((size_t)n_sub + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_sorted_marks, dim3(grid_for(n_sub + 1, 256)), dim3(256), 0, st, use_store ? s->st_off : s->off, s->d_marks, (int)(n_sub + 1), s->d_marks + s->cap_marks);
-    DGE_HIP(hipMemcpyAsync(h_off.data(), s->d_marks + s->cap_marks, ((size_t)n_sub + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (n_sub + 1 > s->cap_h_marks) {
+        if (s->h_marks) (void)hipHostFree(s->h_marks);
+        s->h_marks = nullptr; s->cap_h_marks = 0;
+        DGE_HIP(hipHostMalloc((void**)&s->h_marks, ((size_t)n_sub + 1 + 64) * sizeof(int64_t), hipHostMallocDefault));
+        s->cap_h_marks = n_sub + 1 + 64;
+    }
+    // the launch's ONE read-back: the first pair of every mini-batch (the sorts take their item counts from the host), computed on the device, into pinned memory
+    hipLaunchKernelGGL(k_sorted_marks_walks, dim3(grid_for(n_sub + 1, 256)), dim3(256), 0, st, use_store ? s->st_off : s->off,
+                       use_store ? (int64_t)p.part_tgt * p.n_rows : (int64_t)0, use_store ? (int64_t)1 : (int64_t)p.L, walks_per, p.n_rows, (int)(n_sub + 1), s->d_marks + s->cap_marks);
+    DGE_HIP(hipMemcpyAsync(s->h_marks, s->d_marks + s->cap_marks, ((size_t)n_sub + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     DGE_HIP(hipStreamSynchronize(st));
+    const int64_t* h_off = s->h_marks;
+    if (!use_store) { total_pairs = h_off[n_sub] - h_off[0]; if (total_pairs == 0) return DGE_OK; }
 
     int64_t max_slots = 0;
-    for (int64_t k = 0; k < n_sub; k++) max_slots = std::max(max_slots, (h_off[(size_t)k + 1] - h_off[(size_t)k]) * K1);
+    for (int64_t k = 0; k < n_sub; k++) max_slots = std::max(max_slots, (h_off[k + 1] - h_off[k]) * K1);
     if (max_slots >= 0x7fffffffll) DGE_FAIL(DGE_ERR_ARG, "update_policy 8: a mini-batch of %lld items; set fewer walks per mini-batch", (long long)max_slots);
     int chunk = 128;                     // (64 .. 256 measure alike; 512 and up lose: fewer work units than the device holds)
     if (g_dge_tuning[DGE_TUNE_SORTED_CHUNK] > 0) chunk = (int)std::min<int64_t>(g_dge_tuning[DGE_TUNE_SORTED_CHUNK], 1 << 20);
@@ -858,16 +875,16 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     // (the offsets were read back above: everything the second stream reads — counts, offsets, walks, the unigram table — is in place)
     int64_t live = 0;
     for (int64_t k = 0; k < n_sub; k++) {
-        const int64_t n = (h_off[(size_t)k + 1] - h_off[(size_t)k]) * K1;
+        const int64_t n = (h_off[k + 1] - h_off[k]) * K1;
         if (n == 0) continue;
         const int x = (int)(live++ & 1);
-        q.unit0 = marks[(size_t)k]; q.unit1 = marks[(size_t)k + 1]; q.pair0 = h_off[(size_t)k]; q.n_slots = n;      // (unit0, unit1, pair0: the per-episode emit only)
+        q.unit0 = marks[(size_t)k]; q.unit1 = marks[(size_t)k + 1]; q.pair0 = h_off[k]; q.n_slots = n;      // (unit0, unit1, pair0: the per-episode emit only)
         // second stream: items -> it0; sorted by target row -> it1; row segments
         if (s->set_used[x]) DGE_HIP(hipStreamWaitEvent(s->aux, s->ev_done[x], 0));         // the mini-batch that held this set has finished
         q.it_out = s->it0[x];
         q.mb_walk0 = std::min(k * walks_per, p.n_rows - 1);                                 // the mini-batch's learning rate: that of its first walk
         const uint64_t* src = s->it0[x];
-        if (use_store) src = s->st_it + h_off[(size_t)k] * K1;                              // the batch's items are already there
+        if (use_store) src = s->st_it + h_off[k] * K1;                              // the batch's items are already there
         else hipLaunchKernelGGL(k_sorted_emit, dim3(grid_for(q.unit1 - q.unit0 + 15, 256)), dim3(256), 0, s->aux, q);      // one 16-lane group per 16 units
         size_t b = s->sort_tmp_bytes;
         DGE_HIP(sort_items(s->sort_tmp[0], b, src, s->it1[x], n, ks1, key_bits, s->aux));
