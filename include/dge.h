@@ -177,7 +177,7 @@ typedef struct dge_train_config {
                                     summed — no locks, no atomics, no lost update; the result is a deterministic function of the
                                     batch whatever the worker count (bit-exact against the oracle at full concurrency).  Within a
                                     mini-batch (~100 items per live row) the other table is read as it stood before the
-                                    mini-batch.  Tables below 4 GiB, no hierarchical softmax.
+                                    mini-batch, and the whole mini-batch trains at the learning rate of its first walk.  Tables below 4 GiB, no hierarchical softmax.
                                 workers == 1 with policy 0/3/8 is the in-order schedule with plain accesses. */
     int32_t use_hs;          /* .useHierarchicSoftmax(b): 0 = negative sampling only (the north-star path);
                                 1 = the hierarchical-softmax term as well, before the negatives of each pair — what

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4: the bench line of every workload with the final build on one box (profiles/r04_final_numbers.txt)
+set -o pipefail
+O=gpurun_out/r04_run14; mkdir -p $O
+cd "$(dirname "$0")/.."
+python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; }
+bash scripts/run_final_numbers.sh 2>&1 | tee $O/final_numbers.txt
+f() { python3 -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$1  %.3e edges/s  frac %.3f  %.1f ms/launch  sched %s' % (d['value'], r['frac'], r['ms_per_launch'], r['schedule']), flush=True)"; }
+python3 bench.py --no-cpu-baseline --steps 2 --workload cfg1 2>/dev/null | f cfg1 | tee -a $O/final_numbers.txt
+python3 bench.py --no-cpu-baseline --steps 2 --workload cfg1 --hs 2>/dev/null | f "cfg1 --hs" | tee -a $O/final_numbers.txt
+python3 bench.py --no-cpu-baseline --steps 2 --workload cfg5 --sim-ranks 8 --placement-candidates 1 2>/dev/null | f "cfg5 --sim-ranks 8" | tee -a $O/final_numbers.txt
+python3 bench.py --no-cpu-baseline --steps 2 --workload cfg3_zipf --sim-ranks 8 --placement-candidates 1 2>/dev/null | f "cfg3_zipf --sim-ranks 8" | tee -a $O/final_numbers.txt
+date
