@@ -1047,6 +1047,9 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         blocks = (unsigned)((workers + 2) / 3);
         // an LDS accumulator now takes one addition per CENTRE (16 pairs' worth on cfg3): drained every 4 additions instead of every 64
         p.hs_drain = g_dge_tuning[DGE_TUNE_HS_DRAIN] >= 1 ? (int32_t)g_dge_tuning[DGE_TUNE_HS_DRAIN] : 4;
+        // ... and where the negative-sampling kernels would run under commit locks (a flat vocabulary: auto_policy 5), the pair's negatives and the centre's
+        // gathered syn1neg update go under the rows' locks instead of out as atomics (k_sgns_train_hsw<.., NLOCK>; DGE_TUNE_HS_CENTRE = 2 forces it, 1 keeps atomics)
+        if (g_dge_tuning[DGE_TUNE_HS_CENTRE] == 2 || (g_dge_tuning[DGE_TUNE_HS_CENTRE] < 0 && m->cfg.update_policy == 0 && auto_policy(m, false) == 5)) pol = 14;
     }
     // (not on small vocabularies, where the worker count is capped at half the rows and every pair is a latency chain: the reference's own
     //  801 x 8 tract graph with hierarchical softmax runs 407 ms per 6.5e7 pairs on its 3 204 workers, 552 ms on 2 400 workers and a wave)
@@ -1090,7 +1093,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     }
     if ((rc = timing_end(m, ev, DGE_OK))) return rc;
     m->launches++;
-    m->last_policy = pol >= 30 ? pol - 30 : (pol >= 20 ? pol - 20 : (pol == 13 ? 2 : (pol >= 10 ? pol - 10 : pol))); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
+    m->last_policy = pol >= 30 ? pol - 30 : (pol >= 20 ? pol - 20 : (pol == 13 ? 2 : (pol == 14 ? 5 : (pol >= 10 ? pol - 10 : pol)))); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
     DGE_HIP(hipGetLastError());
     return DGE_OK;
 }

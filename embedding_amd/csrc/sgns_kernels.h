@@ -1401,7 +1401,12 @@ __device__ __forceinline__ void row_add(Row<DCH>& y, const Row<DCH>& x) {
 #pragma unroll
     for (int c = 0; c < DCH; c++) { y.v[c].x += x.v[c].x; y.v[c].y += x.v[c].y; y.v[c].z += x.v[c].z; y.v[c].w += x.v[c].w; }
 }
-template <int DCH>
+// NLOCK (flat vocabularies, where the commit locks work — auto_policy 5): the K negatives of a pair are read-modify-written under their rows' commit locks (the
+// protocol of k_sgns_train_locked: try-lock rounds that never wait while holding, 16-byte write-through rows, relaxed commit) instead of going out as float atomics —
+// 2.5 of the 3.6 KB of atomics a pair, which is what the kernel runs against; the centre's gathered update is then flushed under the row's lock as well (by ONE group,
+// after the four groups' shares met through shuffles: a lock taken by one group of a wave must never be waited for by another), so that syn1neg is only ever
+// updated under locks.  The context row (syn0) stays on atomics.
+template <int DCH, bool NLOCK>
 __global__ void __launch_bounds__(256, 2)
 k_sgns_train_hsw(TrainParams p) {
     __shared__ float s_exp[EXP_TABLE_SIZE];
@@ -1507,6 +1512,39 @@ k_sgns_train_hsw(TrainParams p) {
                         if (t == word) t = -1;
                     }
                     sg = shfl16_u64(sl, kc - 1);
+                    if (NLOCK) {
+                        // try-lock rounds over this pair's negatives: the rows won are trained NEG_BATCH at a time under their locks and released before the next
+                        // round; nothing is ever waited for while a lock is held (the four groups of the wave loop independently)
+                        unsigned pend = (unsigned)(__ballot(t >= 0) >> (threadIdx.x & 48)) & 0xFFFFu;
+                        while (pend) {
+                            const bool want = lane < kc && ((pend >> lane) & 1u);
+                            const bool won = want ? row_trylock(p.locks, t) : false;
+                            const unsigned got = (unsigned)(__ballot(won) >> (threadIdx.x & 48)) & 0xFFFFu & pend;
+                            for (int b0 = 0; b0 < kc; b0 += NEG_BATCH) {
+                                const unsigned gb = (got >> b0) & ((1u << NEG_BATCH) - 1u);
+                                if (!gb) continue;
+                                int32_t tg[NEG_BATCH];
+                                Row<DCH> rr[NEG_BATCH];
+#pragma unroll
+                                for (int q = 0; q < NEG_BATCH; q++) tg[q] = __shfl(t, (b0 + q) & 15, 16);
+#pragma unroll
+                                for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16, false>(rr[q], syn1neg, ((gb >> q) & 1u) ? tg[q] : p.filler_row, lane);
+#pragma unroll
+                                for (int q = 0; q < NEG_BATCH; q++)
+                                    if ((gb >> q) & 1u) {
+                                        const float f = row_dot(l1, rr[q]);
+                                        const float g = sgns_g(f, 0.0f, alpha, s_exp);
+                                        row_axpy(neu, g, rr[q]);
+                                        row_axpy(rr[q], g, l1);
+                                        rowA_store<DCH, 16, false>(rr[q], syn1neg, tg[q], lane);
+                                    }
+                            }
+                            row_commit_wait(0.f);
+                            if (won) row_unlock<false>(p.locks, t);
+                            pend &= ~got;
+                            if (pend) __builtin_amdgcn_s_sleep(2);
+                        }
+                    } else {
                     float mb_g = 0.f;
                     for (int b0 = 0; b0 < kc; b0 += NEG_BATCH) {
                         int32_t tg[NEG_BATCH];
@@ -1525,6 +1563,7 @@ k_sgns_train_hsw(TrainParams p) {
                             }
                     }
                     if ((unsigned)(__ballot(t >= 0) >> (threadIdx.x & 48)) & 0xFFFFu) lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, t, mb_g, l1, lane);
+                    }
                 }
                 for (int z = 0; z < n_here; z++) s = s * mK + cK;         // the centre's stream behind this round's pairs
                 // ---- tree half: every group applies the round's contexts, one after the other, to ITS nodes of the path
@@ -1579,7 +1618,30 @@ k_sgns_train_hsw(TrainParams p) {
             }
             my_pairs += (unsigned long long)n_ctx;
             // ---- close the centre: what it gathered leaves once
-            if (dh_dirty) lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, lane == 0 ? word : -1, 1.0f, dh, lane);
+            if (NLOCK) {
+                // the four groups' shares of the centre's update meet (a group that trained no context holds zeros); group 0 adds the sum to the row under its lock
+#pragma unroll
+                for (int cc = 0; cc < DCH; cc++) {
+                    dh.v[cc].x += __shfl_xor(dh.v[cc].x, 16, 64); dh.v[cc].y += __shfl_xor(dh.v[cc].y, 16, 64);
+                    dh.v[cc].z += __shfl_xor(dh.v[cc].z, 16, 64); dh.v[cc].w += __shfl_xor(dh.v[cc].w, 16, 64);
+                    dh.v[cc].x += __shfl_xor(dh.v[cc].x, 32, 64); dh.v[cc].y += __shfl_xor(dh.v[cc].y, 32, 64);
+                    dh.v[cc].z += __shfl_xor(dh.v[cc].z, 32, 64); dh.v[cc].w += __shfl_xor(dh.v[cc].w, 32, 64);
+                }
+                if (grp == 0)
+                    for (;;) {
+                        const bool won = lane == 0 ? row_trylock(p.locks, word) : false;
+                        if (__shfl((int)won, 0, 16)) {
+                            Row<DCH> cur;
+                            rowA_load<DCH, 16, false>(cur, syn1neg, word, lane);
+                            row_add(cur, dh);
+                            rowA_store<DCH, 16, false>(cur, syn1neg, word, lane);
+                            row_commit_wait(0.f);
+                            if (won) row_unlock<false>(p.locks, word);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+            } else if (dh_dirty) lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, lane == 0 ? word : -1, 1.0f, dh, lane);
 #pragma unroll
             for (int q = 0; q < HSW_NQ; q++)
                 if (node[q] >= 0) {
@@ -1610,7 +1672,8 @@ static inline void launch_train_b(const TrainParams& p, int pol, unsigned blocks
         case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 10: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;    // + hierarchical softmax
         case 12: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, true, false>), dim3(blocks), dim3(threads), shmem, st, p); break;
-        case 13: if constexpr (DCH <= 2 && !BIG) hipLaunchKernelGGL((k_sgns_train_hsw<DCH>), dim3(blocks), dim3(threads), shmem, st, p); break;   // hierarchical softmax, a wave per centre
+        case 13: if constexpr (DCH <= 2 && !BIG) hipLaunchKernelGGL((k_sgns_train_hsw<DCH, false>), dim3(blocks), dim3(threads), shmem, st, p); break;   // hierarchical softmax, a wave per centre
+        case 14: if constexpr (DCH <= 2 && !BIG) hipLaunchKernelGGL((k_sgns_train_hsw<DCH, true>), dim3(blocks), dim3(threads), shmem, st, p); break;    // ... the negatives under commit locks
         case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 7: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;

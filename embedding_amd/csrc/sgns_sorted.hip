@@ -97,6 +97,7 @@ struct SortedParams {
     uint64_t* it_out; const uint64_t* it_in;
     int32_t ks1, ks2; uint32_t omask;            // ks1 = 1 + bits of a row number, ks2 = 11 + that; omask = (1 << bits) - 1
     int64_t mb_walk0;                            // first walk of the mini-batch: the learning rate of all its items
+    int32_t run_nb;                              // k_sorted_emit<.., RUNS>: boundaries of the table's run form that are searched (a power of two)
     const int64_t* seg;                          // seg[k] = first sorted position with key >= k; seg[Vk] = valid items
     int64_t n_slots;                             // sorted array length (valid items first, then the skipped draws with key V)
     int32_t chunk;                               // items per work unit
@@ -211,14 +212,30 @@ __global__ void k_sorted_marks_walks(const int64_t* off, int64_t base, int64_t m
 // items of one mini-batch: slot (pair - pair0) * (K+1) + d holds term d of the pair (d = 0: the centre, label 1; d >= 1: negative d).
 // A negative that drew the centre itself is not trained (word2vec): its slot gets the key V and sorts behind every row.
 // One 16-lane group per 16 (walk, centre) units; lane j draws negative j of a pair (the draws of k_sgns_train, stream for stream).
+// UPG = units a group takes: 16 under the block schedule (most units have no pair of the block), fewer otherwise.
+// RUNS (round 4): the negatives' rows from the table's RUN form in LDS (neg_row_by_runs: a binary search over the run boundaries and a few f64 operations) where the
+// model has one, instead of one 16-byte look-up per draw in the 16.7 MB rank-block table: those look-ups — 10.7 M random requests a cfg2 mini-batch — were what the
+// kernel ran against (173 us whatever UPG; the fabric's request rate).  Only the first q.run_nb boundaries are searched (a power of two above the
+// number of runs; the rest of base[] is +inf anyway).  Same rows, bit for bit: the run form was checked against the table slot by slot when the model was made.
+template <int UPG, bool RUNS>
 __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
     const TrainParams& p = q.t;
+    __shared__ double s_run_base[RUNS ? DGE_RUN_MAX : 1];
+    __shared__ uint32_t s_run_row[RUNS ? DGE_RUN_MAX + 1 : 1];
+    __shared__ uint32_t s_exc_slot[RUNS ? DGE_RUN_EXC : 1];
+    __shared__ int32_t s_exc_row[RUNS ? DGE_RUN_EXC : 1];
+    if (RUNS) {
+        for (int i = threadIdx.x; i < q.run_nb; i += blockDim.x) s_run_base[RUNS ? i : 0] = p.run_base[i];
+        for (int i = threadIdx.x; i < q.run_nb + 1; i += blockDim.x) s_run_row[RUNS ? i : 0] = p.run_row[i];
+        for (int i = threadIdx.x; i < DGE_RUN_EXC; i += blockDim.x) { s_exc_slot[RUNS ? i : 0] = p.exc_slot[i]; s_exc_row[RUNS ? i : 0] = p.exc_row[i]; }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 15;
     const int sh = threadIdx.x & 48;
-    // a group takes 16 consecutive units and works through those that have pairs (under the block schedule most have none)
-    const int64_t u0 = q.unit0 + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4) * 16;
+    // a group takes UPG consecutive units and works through those that have pairs
+    const int64_t u0 = q.unit0 + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4) * UPG;
     if (u0 >= q.unit1) return;
-    const int my_cnt = u0 + lane < q.unit1 ? q.cnt[u0 + lane] : 0;
+    const int my_cnt = (lane < UPG && u0 + lane < q.unit1) ? q.cnt[u0 + lane] : 0;
     unsigned todo = (unsigned)(__ballot(my_cnt > 0) >> sh) & 0xFFFFu;
     if (!todo) return;
     // every lane prepares ITS unit (one round of loads for the whole group), the group then walks through the units' pairs
@@ -231,6 +248,34 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
         unit_window(p, w, i, len, my_s, my_lo, my_hi);
         my_slot = (q.off[u] - q.pair0) * (int64_t)(p.K + 1);
     }
+    // a draw's table slot -> row
+    auto draw_row = [&](uint64_t slot) -> int32_t {
+        if (RUNS) {
+            const uint32_t a = (uint32_t)slot;
+            int32_t r = -2;
+            const double x = (double)(a - 1u) * p.T_inv;
+            if (a != 0u && s_run_base[0] < x) {
+                int lo = 0;
+                for (int st = q.run_nb >> 1; st >= 1; st >>= 1) if (s_run_base[RUNS ? lo + st : 0] < x) lo += st;
+                const int64_t n = (int64_t)s_run_row[RUNS ? lo + 1 : 0] - (int64_t)s_run_row[RUNS ? lo : 0];
+                int64_t k = 0;
+                if (n > 0) {
+                    const double qq = (x - s_run_base[RUNS ? lo : 0]) * (double)n / (s_run_base[RUNS ? lo + 1 : 0] - s_run_base[RUNS ? lo : 0]);
+                    k = (int64_t)ceil(qq) - 1;
+                    k = k < 0 ? 0 : (k > n ? n : k);
+                }
+                r = (int32_t)min((int64_t)s_run_row[RUNS ? lo : 0] + k, p.V - 1);
+                if (p.n_exc > 0) {
+                    int e = 0;
+#pragma unroll
+                    for (int st = DGE_RUN_EXC / 2; st >= 1; st >>= 1) if (e + st < p.n_exc && s_exc_slot[RUNS ? e + st : 0] <= a) e += st;
+                    if (s_exc_slot[RUNS ? e : 0] == a) r = s_exc_row[RUNS ? e : 0];
+                }
+            }
+            if (r != -2) return r;
+        }
+        return neg_table_row(p.ctab, slot);
+    };
     uint64_t mA = 1, cA = 0;
     for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
     const int K = p.K;
@@ -271,7 +316,7 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
                     const bool neg_on = K > 0 && lane < npair * K;
                     const uint64_t sl = p.part_n > 1 ? dge_mix64(s_centre + (uint64_t)(c0 + cl_mine)) * mD + cD : s * mA + cA;
                     if (neg_on) {
-                        int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                        int32_t t = draw_row(dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
                         if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                         if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
                         const int64_t at = slot + (int64_t)z_l * (K + 1) + 1 + d_l;
@@ -293,7 +338,7 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
                         const int kc = min(16, K - kd);
                         const uint64_t sl = s * mA + cA;
                         if (lane < kc) {
-                            int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                            int32_t t = draw_row(dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
                             if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                             if (p.part_n > 1) t = part_row(t, p.part_n, p.part_tgt, p.V);
                             q.it_out[slot + 1 + kd + lane] = ((uint64_t)(uint32_t)(t == word ? q.Vk : t / q.kdiv) << q.ks1) | oth | 1ull;
@@ -885,7 +930,18 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         q.mb_walk0 = std::min(k * walks_per, p.n_rows - 1);                                 // the mini-batch's learning rate: that of its first walk
         const uint64_t* src = s->it0[x];
         if (use_store) src = s->st_it + h_off[k] * K1;                              // the batch's items are already there
-        else hipLaunchKernelGGL(k_sorted_emit, dim3(grid_for(q.unit1 - q.unit0 + 15, 256)), dim3(256), 0, s->aux, q);      // one 16-lane group per 16 units
+        else {
+            const bool runs = p.n_runs > 0;
+            q.run_nb = 2; while (q.run_nb < p.n_runs + 2 && q.run_nb < DGE_RUN_MAX) q.run_nb <<= 1;
+            const int64_t n_units = q.unit1 - q.unit0;
+            if (p.part_n > 1) {         // one 16-lane group per 16 units
+                if (runs) hipLaunchKernelGGL((k_sorted_emit<16, true>), dim3(grid_for(n_units + 15, 256)), dim3(256), 0, s->aux, q);
+                else hipLaunchKernelGGL((k_sorted_emit<16, false>), dim3(grid_for(n_units + 15, 256)), dim3(256), 0, s->aux, q);
+            } else {                    // ... per 4 units
+                if (runs) hipLaunchKernelGGL((k_sorted_emit<4, true>), dim3(grid_for((n_units + 3) / 4 * 16, 256)), dim3(256), 0, s->aux, q);
+                else hipLaunchKernelGGL((k_sorted_emit<4, false>), dim3(grid_for((n_units + 3) / 4 * 16, 256)), dim3(256), 0, s->aux, q);
+            }
+        }
         size_t b = s->sort_tmp_bytes;
         DGE_HIP(sort_items(s->sort_tmp[0], b, src, s->it1[x], n, ks1, key_bits, s->aux));
         hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(Vk + 2, 256)), dim3(256), 0, s->aux, s->it1[x], ks1, n, Vk, seg_a[x]);

@@ -80,7 +80,7 @@ if BLOCKS:
 
 if HS:
     import os
-    variants = [("pair by pair, cold end plain, atomics through the atomics wave (round 3)", {"hs_centre": 0}), ("a wave per centre (round 4, default)", {})]
+    variants = [("pair by pair, cold end plain, atomics through the atomics wave (round 3)", {"hs_centre": 0}), ("a wave per centre, negatives by atomics", {"hs_centre": 1}), ("a wave per centre, negatives under commit locks (default on flat vocabularies)", {})]
     if os.environ.get("DGE_HS_DRAINS"):          # e.g. DGE_HS_DRAINS=6,8: only the wave-per-centre kernel with these drain periods of the LDS accumulators
         variants = [("a wave per centre, LDS accumulators drained every %s centre additions" % d, {"hs_drain": int(d)}) for d in os.environ["DGE_HS_DRAINS"].split(",")]
     for name, knobs in variants:
