@@ -32,6 +32,7 @@
 #include "dge_internal.h"
 #include "sgns_kernels.h"
 #include "sgns_model.h"
+#include "fmt_g9.h"
 
 
 std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
@@ -1508,6 +1509,28 @@ extern "C" int dge_model_reset_stats(dge_model* m) {
     return DGE_OK;
 }
 
+// dge_fmt_g9 (fmt_g9.h) against snprintf("%.9g") on `n` pseudo-random floats: half of them random bit patterns, half values of an embedding's range; host code only
+extern "C" int dge_selftest_fmt_g9(int64_t n, uint64_t seed, int64_t* fast_path, int64_t* mismatches) {
+    if (n < 0 || !fast_path || !mismatches) DGE_FAIL(DGE_ERR_ARG, "dge_selftest_fmt_g9: bad argument");
+    int64_t fast = 0, bad = 0;
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
+    char a[64], b[64];
+    for (int64_t i = 0; i < n; i++) {
+        s = dge_mix64(s + (uint64_t)i);
+        uint32_t u = (uint32_t)(s >> 32);
+        float f;
+        if (i & 1) memcpy(&f, &u, 4);
+        else f = (float)(((double)(s & 0xFFFFFFFFull) / 4294967296.0 * 2.0 - 1.0) * ((i & 6) == 0 ? 1e-3 : ((i & 6) == 2 ? 1.0 : 40.0)));
+        char* e = dge_fmt_g9(f, a);
+        if (!e) continue;
+        *e = 0; fast++;
+        snprintf(b, sizeof(b), "%.9g", (double)f);
+        if (strcmp(a, b) != 0) bad++;
+    }
+    *fast_path = fast; *mismatches = bad;
+    return DGE_OK;
+}
+
 // WordVectorSerializer.writeWordVectors: V lines of D decimal numbers.  At the reference's sizes (6 408 x 20) that is nothing; at cfg3's (10^6 x 128 =
 // 1.3e8 conversions, 1.5 GB of text) one thread formats for ~25 s — longer than the epoch trained.  Rows are formatted in slabs by up to 16 host threads
 // (each row into its own string, the slab written in row order): same bytes as the serial loop.
@@ -1532,17 +1555,27 @@ extern "C" int dge_write_vec(dge_model* m, const char* const* names, const char*
         const int64_t r1 = std::min(V, r0 + slab);
         std::vector<std::string>& ob = out[cur];
         auto work = [&, r0, r1](int t) {
-            std::string& sbuf = ob[(size_t)t]; sbuf.clear();
+            std::string& sbuf = ob[(size_t)t];
             const int64_t a = r0 + (r1 - r0) * t / n_thr, b = r0 + (r1 - r0) * (t + 1) / n_thr;
-            char num[40];
+            // the rows' text goes straight into the buffer: at most 17 characters an element (sign, nine digits, point, e-XX, the blank in front)
+            size_t cap = 0;
+            for (int64_t r = a; r < b; r++) { const int32_t id = m->h_vocab_ids[(size_t)r]; cap += (names && names[id] ? strlen(names[id]) : 12) + (size_t)D * 26 + 2; }
+            sbuf.resize(cap);
+            char* o = sbuf.data();
             for (int64_t r = a; r < b; r++) {
                 const int32_t id = m->h_vocab_ids[(size_t)r];
-                if (names && names[id]) sbuf += names[id]; else { snprintf(num, sizeof(num), "%d", id); sbuf += num; }
+                if (names && names[id]) { const size_t n = strlen(names[id]); memcpy(o, names[id], n); o += n; } else o = std::to_chars(o, o + 12, id).ptr;
                 const float* v = m->h_syn0.data() + r * D;
-                // (std::to_chars(double, general, 9) is specified to give printf's "%.9g" — same bytes, half the time)
-                for (int j = 0; j < D; j++) { num[0] = ' '; const auto res = std::to_chars(num + 1, num + sizeof(num), (double)v[j], std::chars_format::general, 9); sbuf.append(num, (size_t)(res.ptr - num)); }
-                sbuf += '\n';
+                // "%.9g" of every element: dge_fmt_g9 (integer arithmetic, the same bytes: fmt_g9.h) for the values an embedding holds, and for the rest
+                // std::to_chars(double, general, 9), which is specified to give printf's "%.9g"
+                for (int j = 0; j < D; j++) {
+                    *o++ = ' ';
+                    char* e = dge_fmt_g9(v[j], o);
+                    o = e ? e : std::to_chars(o, o + 25, (double)v[j], std::chars_format::general, 9).ptr;
+                }
+                *o++ = '\n';
             }
+            sbuf.resize((size_t)(o - sbuf.data()));
         };
         if (n_thr == 1) work(0);
         else {

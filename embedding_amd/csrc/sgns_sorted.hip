@@ -139,16 +139,33 @@ __device__ __forceinline__ float code_step(int code, float label, float alpha, c
     return (label - s_exp[code]) * alpha;
 }
 
+// totals of a launch's pairs and words: one atomic per WORKGROUP and counter, from launches of at most COUNT_BLOCKS workgroups — atomics on one address complete one
+// per ~12 ns at the memory side, and a wave's worth each (12 500 x 2 on a cfg2 step) made the count kernel 300 us long (round 4)
+#define COUNT_BLOCKS 256      /* the count kernels' grids: at most 2 x this */
+__device__ __forceinline__ void count_tally(long long pn, long long words, unsigned long long* pairs_out, unsigned long long* words_out) {
+    __shared__ long long s_t[2][4];
+    for (int o = 32; o > 0; o >>= 1) { pn += __shfl_xor(pn, o); words += __shfl_xor(words, o); }
+    if ((threadIdx.x & 63) == 0) { s_t[0][threadIdx.x >> 6] = pn; s_t[1][threadIdx.x >> 6] = words; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        long long a = 0, b = 0;
+        for (int i = 0; i < nw; i++) { a += s_t[0][i]; b += s_t[1][i]; }
+        if (a) atomicAdd(pairs_out, (unsigned long long)a);
+        if (b) atomicAdd(words_out, (unsigned long long)b);
+    }
+}
+
 // pairs of every (walk, centre) unit; totals of pairs and words for dge_model_stats
 __global__ void __launch_bounds__(256) k_sorted_count(TrainParams p, int32_t* cnt) {
-    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_units = p.n_rows * (int64_t)p.L;
-    int n = 0; long long words = 0;
-    if (u < n_units) {
+    long long pn = 0, words = 0;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += (int64_t)gridDim.x * blockDim.x) {
+        int n = 0;
         const int64_t w = u / p.L; const int i = (int)(u % p.L);
         const int len = (int)p.len[w];
         const int32_t* sen = p.sen + w * p.L;
-        if (i == 0 && (p.part_n <= 1 || p.part_ctx == p.part_tgt)) words = len;
+        if (i == 0 && (p.part_n <= 1 || p.part_ctx == p.part_tgt)) words += len;
         if (i < len && (p.part_n <= 1 || sen[i] % p.part_n == p.part_tgt)) {
             uint64_t s; int lo, hi;
             unit_window(p, w, i, len, s, lo, hi);
@@ -156,21 +173,16 @@ __global__ void __launch_bounds__(256) k_sorted_count(TrainParams p, int32_t* cn
             else for (int c = lo; c <= hi; c++) n += (c != i && sen[c] % p.part_n == p.part_ctx) ? 1 : 0;
         }
         cnt[u] = n;
+        pn += n;
     }
-    long long pn = n;
-    for (int o = 32; o > 0; o >>= 1) { pn += __shfl_xor(pn, o); words += __shfl_xor(words, o); }
-    if ((threadIdx.x & 63) == 0) {
-        if (pn) atomicAdd(&p.counters[0], (unsigned long long)pn);
-        if (words) atomicAdd(&p.counters[1], (unsigned long long)words);
-    }
+    count_tally(pn, words, &p.counters[0], &p.counters[1]);
 }
 
 // the same counts with one thread per WALK (walks of up to 64 tokens: the partition tests become two bit masks over the walk's
 // tokens, a unit's pair count a popcount) — the block schedule visits every walk of the global batch for a few pairs each
 __global__ void __launch_bounds__(256) k_sorted_count_walks(TrainParams p, int32_t* cnt) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     long long pn = 0, words = 0;
-    if (w < p.n_rows) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < p.n_rows; w += (int64_t)gridDim.x * blockDim.x) {
         const int len = (int)p.len[w];
         const int32_t* sen = p.sen + w * p.L;
         uint64_t ctx_mask = 0, tgt_mask = 0;
@@ -179,7 +191,7 @@ __global__ void __launch_bounds__(256) k_sorted_count_walks(TrainParams p, int32
             const int r = sen[j] % p.part_n;
             ctx_mask |= (uint64_t)(r == p.part_ctx) << j; tgt_mask |= (uint64_t)(r == p.part_tgt) << j;
         }
-        if (p.part_n <= 1 || p.part_ctx == p.part_tgt) words = len;
+        if (p.part_n <= 1 || p.part_ctx == p.part_tgt) words += len;
         for (int i = 0; i < p.L; i++) {
             int n = 0;
             if (i < len && ((tgt_mask >> i) & 1ull)) {
@@ -192,11 +204,7 @@ __global__ void __launch_bounds__(256) k_sorted_count_walks(TrainParams p, int32
             pn += n;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) { pn += __shfl_xor(pn, o); words += __shfl_xor(words, o); }
-    if ((threadIdx.x & 63) == 0) {
-        if (pn) atomicAdd(&p.counters[0], (unsigned long long)pn);
-        if (words) atomicAdd(&p.counters[1], (unsigned long long)words);
-    }
+    count_tally(pn, words, &p.counters[0], &p.counters[1]);
 }
 
 __global__ void k_sorted_marks(const int64_t* off, const int64_t* units, int n, int64_t* out) {
@@ -212,6 +220,45 @@ __global__ void k_sorted_marks_walks(const int64_t* off, int64_t base, int64_t m
 // items of one mini-batch: slot (pair - pair0) * (K+1) + d holds term d of the pair (d = 0: the centre, label 1; d >= 1: negative d).
 // A negative that drew the centre itself is not trained (word2vec): its slot gets the key V and sorts behind every row.
 // One 16-lane group per 16 (walk, centre) units; lane j draws negative j of a pair (the draws of k_sgns_train, stream for stream).
+// the table's run form in LDS and a draw's table slot -> row through it (k_sorted_emit, k_block_emit; RUNS, p in scope)
+#define EMIT_RUNS_LDS(run_nb_) \
+    __shared__ double s_run_base[RUNS ? DGE_RUN_MAX : 1]; \
+    __shared__ uint32_t s_run_row[RUNS ? DGE_RUN_MAX + 1 : 1]; \
+    __shared__ uint32_t s_exc_slot[RUNS ? DGE_RUN_EXC : 1]; \
+    __shared__ int32_t s_exc_row[RUNS ? DGE_RUN_EXC : 1]; \
+    if (RUNS) { \
+        for (int i = threadIdx.x; i < (run_nb_); i += blockDim.x) s_run_base[RUNS ? i : 0] = p.run_base[i]; \
+        for (int i = threadIdx.x; i < (run_nb_) + 1; i += blockDim.x) s_run_row[RUNS ? i : 0] = p.run_row[i]; \
+        for (int i = threadIdx.x; i < DGE_RUN_EXC; i += blockDim.x) { s_exc_slot[RUNS ? i : 0] = p.exc_slot[i]; s_exc_row[RUNS ? i : 0] = p.exc_row[i]; } \
+        __syncthreads(); \
+    }
+#define EMIT_DRAW_ROW(run_nb_) \
+    auto draw_row = [&](uint64_t slot) -> int32_t { \
+        if (RUNS) { \
+            const uint32_t a = (uint32_t)slot; \
+            int32_t r = -2; \
+            const double x = (double)(a - 1u) * p.T_inv; \
+            if (a != 0u && s_run_base[0] < x) { \
+                int lo = 0; \
+                for (int st = (run_nb_) >> 1; st >= 1; st >>= 1) if (s_run_base[RUNS ? lo + st : 0] < x) lo += st; \
+                const int64_t n = (int64_t)s_run_row[RUNS ? lo + 1 : 0] - (int64_t)s_run_row[RUNS ? lo : 0]; \
+                int64_t k = 0; \
+                if (n > 0) { \
+                    const double qq = (x - s_run_base[RUNS ? lo : 0]) * (double)n / (s_run_base[RUNS ? lo + 1 : 0] - s_run_base[RUNS ? lo : 0]); \
+                    k = (int64_t)ceil(qq) - 1; \
+                    k = k < 0 ? 0 : (k > n ? n : k); \
+                } \
+                r = (int32_t)min((int64_t)s_run_row[RUNS ? lo : 0] + k, p.V - 1); \
+                if (p.n_exc > 0) { \
+                    int e = 0; \
+                    for (int st = DGE_RUN_EXC / 2; st >= 1; st >>= 1) if (e + st < p.n_exc && s_exc_slot[RUNS ? e + st : 0] <= a) e += st; \
+                    if (s_exc_slot[RUNS ? e : 0] == a) r = s_exc_row[RUNS ? e : 0]; \
+                } \
+            } \
+            if (r != -2) return r; \
+        } \
+        return neg_table_row(p.ctab, slot); \
+    };
 // UPG = units a group takes: 16 under the block schedule (most units have no pair of the block), fewer otherwise.
 // RUNS (round 4): the negatives' rows from the table's RUN form in LDS (neg_row_by_runs: a binary search over the run boundaries and a few f64 operations) where the
 // model has one, instead of one 16-byte look-up per draw in the 16.7 MB rank-block table: those look-ups — 10.7 M random requests a cfg2 mini-batch — were what the
@@ -220,16 +267,7 @@ __global__ void k_sorted_marks_walks(const int64_t* off, int64_t base, int64_t m
 template <int UPG, bool RUNS>
 __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
     const TrainParams& p = q.t;
-    __shared__ double s_run_base[RUNS ? DGE_RUN_MAX : 1];
-    __shared__ uint32_t s_run_row[RUNS ? DGE_RUN_MAX + 1 : 1];
-    __shared__ uint32_t s_exc_slot[RUNS ? DGE_RUN_EXC : 1];
-    __shared__ int32_t s_exc_row[RUNS ? DGE_RUN_EXC : 1];
-    if (RUNS) {
-        for (int i = threadIdx.x; i < q.run_nb; i += blockDim.x) s_run_base[RUNS ? i : 0] = p.run_base[i];
-        for (int i = threadIdx.x; i < q.run_nb + 1; i += blockDim.x) s_run_row[RUNS ? i : 0] = p.run_row[i];
-        for (int i = threadIdx.x; i < DGE_RUN_EXC; i += blockDim.x) { s_exc_slot[RUNS ? i : 0] = p.exc_slot[i]; s_exc_row[RUNS ? i : 0] = p.exc_row[i]; }
-        __syncthreads();
-    }
+    EMIT_RUNS_LDS(q.run_nb)
     const int lane = threadIdx.x & 15;
     const int sh = threadIdx.x & 48;
     // a group takes UPG consecutive units and works through those that have pairs
@@ -248,34 +286,7 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
         unit_window(p, w, i, len, my_s, my_lo, my_hi);
         my_slot = (q.off[u] - q.pair0) * (int64_t)(p.K + 1);
     }
-    // a draw's table slot -> row
-    auto draw_row = [&](uint64_t slot) -> int32_t {
-        if (RUNS) {
-            const uint32_t a = (uint32_t)slot;
-            int32_t r = -2;
-            const double x = (double)(a - 1u) * p.T_inv;
-            if (a != 0u && s_run_base[0] < x) {
-                int lo = 0;
-                for (int st = q.run_nb >> 1; st >= 1; st >>= 1) if (s_run_base[RUNS ? lo + st : 0] < x) lo += st;
-                const int64_t n = (int64_t)s_run_row[RUNS ? lo + 1 : 0] - (int64_t)s_run_row[RUNS ? lo : 0];
-                int64_t k = 0;
-                if (n > 0) {
-                    const double qq = (x - s_run_base[RUNS ? lo : 0]) * (double)n / (s_run_base[RUNS ? lo + 1 : 0] - s_run_base[RUNS ? lo : 0]);
-                    k = (int64_t)ceil(qq) - 1;
-                    k = k < 0 ? 0 : (k > n ? n : k);
-                }
-                r = (int32_t)min((int64_t)s_run_row[RUNS ? lo : 0] + k, p.V - 1);
-                if (p.n_exc > 0) {
-                    int e = 0;
-#pragma unroll
-                    for (int st = DGE_RUN_EXC / 2; st >= 1; st >>= 1) if (e + st < p.n_exc && s_exc_slot[RUNS ? e + st : 0] <= a) e += st;
-                    if (s_exc_slot[RUNS ? e : 0] == a) r = s_exc_row[RUNS ? e : 0];
-                }
-            }
-            if (r != -2) return r;
-        }
-        return neg_table_row(p.ctab, slot);
-    };
+    EMIT_DRAW_ROW(q.run_nb)
     uint64_t mA = 1, cA = 0;
     for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
     const int K = p.K;
@@ -360,14 +371,13 @@ __global__ void __launch_bounds__(256) k_sorted_emit(SortedParams q) {
 // (k_block_emit: one 16-lane group per walk, tokens in registers).  Episode (part_ctx, t) then sorts and trains slices of bucket t: the same
 // items in the same order as the per-episode kernels produce (bit-exact tests: tests/test_gpu_sorted.py).
 __global__ void __launch_bounds__(256) k_block_count(TrainParams p, int32_t* cells, unsigned long long* words_out) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     long long words = 0;
-    if (w < p.n_rows) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < p.n_rows; w += (int64_t)gridDim.x * blockDim.x) {
         const int len = (int)p.len[w];
         const int32_t* sen = p.sen + w * p.L;
         uint64_t ctx_mask = 0;
         for (int j = 0; j < len; j++) { const int32_t v = sen[j]; ctx_mask |= (uint64_t)(v - dge_fast_div32(v, p.part_n, p.N_magic) * p.part_n == p.part_ctx) << j; }
-        words = len;
+        words += len;
         int cnt[16];
 #pragma unroll
         for (int t = 0; t < 16; t++) cnt[t] = 0;
@@ -383,11 +393,13 @@ __global__ void __launch_bounds__(256) k_block_count(TrainParams p, int32_t* cel
 #pragma unroll
         for (int t = 0; t < 16; t++) if (t < p.part_n) cells[(int64_t)t * p.n_rows + w] = cnt[t];
     }
-    for (int o = 32; o > 0; o >>= 1) words += __shfl_xor(words, o);
-    if ((threadIdx.x & 63) == 0 && words) atomicAdd(words_out, (unsigned long long)words);
+    count_tally(0, words, words_out, words_out);
 }
 
-__global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t* __restrict__ cell_off, uint64_t* __restrict__ it_out, int32_t Vk, int32_t ks1) {
+template <bool RUNS>
+__global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t* __restrict__ cell_off, uint64_t* __restrict__ it_out, int32_t Vk, int32_t ks1, int32_t run_nb) {
+    EMIT_RUNS_LDS(run_nb)
+    EMIT_DRAW_ROW(run_nb)
     const int lane = threadIdx.x & 15;
     const int sh = threadIdx.x & 48;
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -438,7 +450,7 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
                 const int32_t last_mine = __shfl(last_pos, z_l, 16);
                 if (K > 0 && lane < npair * K) {
                     const uint64_t sl = dge_mix64(s_centre + (uint64_t)c_mine) * mD + cD;       // every pair draws from its own stream
-                    int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                    int32_t t = draw_row(dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
                     if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                     int32_t tk = dge_fast_div32(t, N, p.N_magic);              // part_row: the row of the bucket's partition nearest below the draw
                     if ((int64_t)tk * N + bucket >= p.V) tk--;
@@ -460,7 +472,7 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
                     const int kc = min(16, K - kd);
                     const uint64_t sl = sp * mA + cA;
                     if (lane < kc) {
-                        int32_t t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                        int32_t t = draw_row(dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
                         if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
                         int32_t tk = dge_fast_div32(t, N, p.N_magic);
                         if ((int64_t)tk * N + bucket >= p.V) tk--;
@@ -758,7 +770,7 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
             if (!s->st_words && (rc = dge_dev_alloc(&s->st_words, 1))) return rc;
             DGE_HIP(hipMemsetAsync(s->st_words, 0, sizeof(unsigned long long), st));
             DGE_HIP(hipMemsetAsync(s->st_cnt + n_cells, 0, sizeof(int32_t), st));
-            hipLaunchKernelGGL(k_block_count, dim3(grid_for(p.n_rows, 256)), dim3(256), 0, st, p, s->st_cnt, s->st_words);
+            hipLaunchKernelGGL(k_block_count, dim3(std::min<unsigned>(grid_for(p.n_rows, 256), COUNT_BLOCKS * 8)), dim3(256), 0, st, p, s->st_cnt, s->st_words);
             { size_t b = s->st_scan_bytes; DGE_HIP(hipcub::DeviceScan::ExclusiveSum(s->st_scan_tmp, b, CountIter(s->st_cnt, CastI64()), s->st_off, n_cells + 1, st)); }
             // first pair of every bucket
             std::vector<int64_t> cells((size_t)p.part_n + 1);
@@ -786,9 +798,15 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
                     if ((rc = dge_dev_alloc(&s->st_it, (size_t)cap))) return rc;
                     s->st_cap_items = cap;
                 }
-                if (all_items > 0)
-                    hipLaunchKernelGGL(k_block_emit, dim3(grid_for(p.n_rows * 16, 256)), dim3(256), 0, st, p, s->st_off, s->st_it,
-                                       (int32_t)((m->V + p.part_n - 1) / p.part_n), (int32_t)ks1);
+                if (all_items > 0) {
+                    // (the run form pays where few runs are searched and a workgroup has work for its 25 KB of LDS: cfg3's 1 716 runs and the 16 walks of a workgroup
+                    //  here made this kernel slower, 38 against 31 ms a batch — a vocabulary of up to 510 runs takes it)
+                    int32_t run_nb = 2; while (run_nb < p.n_runs + 2 && run_nb < DGE_RUN_MAX) run_nb <<= 1;
+                    if (p.n_runs > 0 && run_nb <= 512) hipLaunchKernelGGL(k_block_emit<true>, dim3(grid_for(p.n_rows * 16, 256)), dim3(256), 0, st, p, s->st_off, s->st_it,
+                                                         (int32_t)((m->V + p.part_n - 1) / p.part_n), (int32_t)ks1, run_nb);
+                    else hipLaunchKernelGGL(k_block_emit<false>, dim3(grid_for(p.n_rows * 16, 256)), dim3(256), 0, st, p, s->st_off, s->st_it,
+                                            (int32_t)((m->V + p.part_n - 1) / p.part_n), (int32_t)ks1, run_nb);
+                }
                 DGE_HIP(hipGetLastError());
                 s->st_key_of = key; s->st_valid = true;
             }
@@ -812,8 +830,9 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     }
     // pairs of every (walk, centre) unit and their exclusive prefix (one extra zero unit carries the total)
     DGE_HIP(hipMemsetAsync(s->cnt + n_units, 0, sizeof(int32_t), st));
-    if (p.L <= 64) hipLaunchKernelGGL(k_sorted_count_walks, dim3(grid_for(p.n_rows, 256)), dim3(256), 0, st, p, s->cnt);
-    else hipLaunchKernelGGL(k_sorted_count, dim3(grid_for(n_units, 256)), dim3(256), 0, st, p, s->cnt);
+    // (one thread per walk where the partition masks pay; without partitions a unit's count is its window's width: one thread per unit — 42 -> ~10 us on cfg2)
+    if (p.L <= 64 && p.part_n > 1) hipLaunchKernelGGL(k_sorted_count_walks, dim3(std::min<unsigned>(grid_for(p.n_rows, 256), COUNT_BLOCKS * 2)), dim3(256), 0, st, p, s->cnt);
+    else hipLaunchKernelGGL(k_sorted_count, dim3(std::min<unsigned>(grid_for(n_units, 256), COUNT_BLOCKS * 2)), dim3(256), 0, st, p, s->cnt);
     { size_t b = s->scan_tmp_bytes; DGE_HIP(hipcub::DeviceScan::ExclusiveSum(s->scan_tmp, b, CountIter(s->cnt, CastI64()), s->off, n_units + 1, st)); }
 
     }
@@ -931,8 +950,8 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         const uint64_t* src = s->it0[x];
         if (use_store) src = s->st_it + h_off[k] * K1;                              // the batch's items are already there
         else {
-            const bool runs = p.n_runs > 0;
             q.run_nb = 2; while (q.run_nb < p.n_runs + 2 && q.run_nb < DGE_RUN_MAX) q.run_nb <<= 1;
+            const bool runs = p.n_runs > 0 && q.run_nb <= 512;          // (more runs: the LDS fill and the longer search cost what the look-ups did — k_block_emit below)
             const int64_t n_units = q.unit1 - q.unit0;
             if (p.part_n > 1) {         // one 16-lane group per 16 units
                 if (runs) hipLaunchKernelGGL((k_sorted_emit<16, true>), dim3(grid_for(n_units + 15, 256)), dim3(256), 0, s->aux, q);

@@ -369,6 +369,9 @@ int  dge_selftest_atomics_wave(int device, int32_t n_rows, int32_t n_acc, int32_
 /* the LDS combining of the hierarchical-softmax updates near the root (hot_add) in isolation: n_workers workers add 1.0
  * to skewed pseudo-random rows `iters` times with the given drain period; max_abs_error = worst |row element - additions
  * that row received| (0 when no addition is lost or doubled). */
+/* host code only: the vector file's number formatter (csrc/fmt_g9.h: printf's "%.9g" by integer arithmetic) against snprintf on n pseudo-random floats;
+ * *fast_path = how many took the formatter (the rest are outside its range and go through std::to_chars in dge_write_vec), *mismatches must come back 0 */
+int  dge_selftest_fmt_g9(int64_t n, uint64_t seed, int64_t* fast_path, int64_t* mismatches);
 int  dge_selftest_hot_add(int device, int32_t n_hot, int64_t n_workers, int32_t iters, int32_t drain, uint64_t seed,
                           int64_t* total_additions, double* max_abs_error);
 

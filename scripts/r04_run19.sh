@@ -18,4 +18,4 @@ cd $root
 f=$(find $O/trace -name "*kernel_trace.csv" | head -1)
 python3 scripts/trace_timeline.py $f 130 > $O/timeline.txt
 rm -rf $O/trace
-grep -E "emit|count_walks|phase" $O/timeline.txt | tail -12
+grep -E "emit|count|phase" $O/timeline.txt | tail -14

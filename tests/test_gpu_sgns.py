@@ -379,6 +379,9 @@ def test_vec_writer_roundtrip(dge, oracle, tmp_path):
     assert first == [str(len(vid)), "20"]
     rn2, rv2 = io.read_vec(str(tmp_path / "y.vec"), header=True)
     assert rn2 == [str(v) for v in vid] and np.array_equal(rv2, syn0)
+    # ... and the bytes are printf's "%.9g" (the writer formats by integer arithmetic, csrc/fmt_g9.h; values outside its range through std::to_chars)
+    lines = open(tmp_path / "x.vec").read().split("\n")
+    assert lines[:len(vid)] == [" ".join([names[v]] + ["%.9g" % float(x) for x in row]) for v, row in zip(vid, syn0)]
 
 
 def test_cfg3_sized_epoch_slice_properties(dge):
