@@ -35,7 +35,7 @@
 #include "fmt_g9.h"
 
 
-std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
@@ -1041,16 +1041,36 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // its contexts and their gathered updates leave once per centre.  `workers` = walks in flight = waves that train: two resident workgroups of three
         // such waves (and one atomics wave) a compute unit; never more than an eighth of the vocabulary (a wave works on four context rows at a time).
         pol = 13;
+        int nw = 3;
+        // ... and where the negative-sampling kernels would run under commit locks (a flat vocabulary: auto_policy 5), the pair's negatives and the centre's
+        // gathered syn1neg update go under the rows' locks instead of out as atomics (k_sgns_train_hsw<.., NLOCK>) — in ONE workgroup of seven training waves a
+        // compute unit, which share their LDS accumulators (DGE_TUNE_HS_CENTRE: 1 keeps atomics, 2 = locks in workgroups of three waves, 3 = of seven)
+        const int64_t centre_knob = g_dge_tuning[DGE_TUNE_HS_CENTRE];
+        if (centre_knob == 2 || centre_knob == 3 || (centre_knob < 0 && m->cfg.update_policy == 0 && auto_policy(m, false) == 5)) {
+            pol = centre_knob == 2 ? 14 : 15;
+            if (pol == 15) nw = 7;
+        }
         if (m->cfg.workers == 0 && !(g_dge_tuning[DGE_TUNE_WORKERS] > 0))
-            workers = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)m->n_cus * 2 * 3, std::max<int64_t>(1, m->V / 8)), std::max<int64_t>(16, (int64_t)(12.0 / std::max(m->row_share_max, 1e-12)))));
+            workers = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)m->n_cus * (nw == 3 ? 6 : 7), std::max<int64_t>(1, m->V / 8)), std::max<int64_t>(16, (int64_t)(12.0 / std::max(m->row_share_max, 1e-12)))));
         workers = std::max<int64_t>(1, std::min<int64_t>(workers, n_rows));
         p.n_workers = workers;
-        blocks = (unsigned)((workers + 2) / 3);
-        // an LDS accumulator now takes one addition per CENTRE (16 pairs' worth on cfg3): drained every 4 additions instead of every 64
-        p.hs_drain = g_dge_tuning[DGE_TUNE_HS_DRAIN] >= 1 ? (int32_t)g_dge_tuning[DGE_TUNE_HS_DRAIN] : 4;
-        // ... and where the negative-sampling kernels would run under commit locks (a flat vocabulary: auto_policy 5), the pair's negatives and the centre's
-        // gathered syn1neg update go under the rows' locks instead of out as atomics (k_sgns_train_hsw<.., NLOCK>; DGE_TUNE_HS_CENTRE = 2 forces it, 1 keeps atomics)
-        if (g_dge_tuning[DGE_TUNE_HS_CENTRE] == 2 || (g_dge_tuning[DGE_TUNE_HS_CENTRE] < 0 && m->cfg.update_policy == 0 && auto_policy(m, false) == 5)) pol = 14;
+        blocks = (unsigned)((workers + nw - 1) / nw);
+        threads = (unsigned)(nw + 1) * 64u;
+        // an LDS accumulator now takes one addition per CENTRE (16 pairs' worth on cfg3): drained every 4 additions instead of every 64 — every 8 where seven
+        // waves share it (the same number of additions parked device-wide: workgroups x drain)
+        p.hs_drain = g_dge_tuning[DGE_TUNE_HS_DRAIN] >= 1 ? (int32_t)g_dge_tuning[DGE_TUNE_HS_DRAIN] : (nw == 3 ? 4 : 8);
+        // Measured on cfg3 and the cfg3-sized community graph (profiles/r04_hs_waves7.txt; three waves, drain 4: 3.3e8 edges/s, AUC 0.9534): seven waves with 15 KB of
+        // accumulators (the 29 nodes next to the root) and a drain every 8 additions 3.6e8 at AUC 0.9533; with 30 KB 3.64e8 / 0.9526, with 60 KB 3.7e8 / 0.9519 — every
+        // accumulator is a row whose readers lag workgroups x drain / 2 updates behind, so fewer of them and shared by more waves is the better trade (three waves at
+        // drain 8: 3.63e8 / 0.9518).
+        if (nw == 7) {      // one workgroup a compute unit
+            const int64_t row_b = (int64_t)m->stride * 4 + 4;
+            const int64_t hot_kb = g_dge_tuning[DGE_TUNE_HS_HOT_KB];
+            p.hs_n_hot = (int32_t)std::min<int64_t>(std::max<int64_t>(m->V - 1, 0), (hot_kb >= 0 ? std::min<int64_t>(hot_kb, 100) * 1024 : 15360) / row_b);
+            p.hs_hot0 = (int32_t)(std::max<int64_t>(m->V - 1, 0) - p.hs_n_hot);
+            { const int64_t cold_knob = g_dge_tuning[DGE_TUNE_HS_COLD]; p.hs_cold = (int32_t)std::min<int64_t>(cold_knob >= 0 ? cold_knob : (int64_t)m->hs_cold_auto, p.hs_hot0); }
+            shmem = (size_t)p.hs_n_hot * (size_t)row_b;
+        }
     }
     // (not on small vocabularies, where the worker count is capped at half the rows and every pair is a latency chain: the reference's own
     //  801 x 8 tract graph with hierarchical softmax runs 407 ms per 6.5e7 pairs on its 3 204 workers, 552 ms on 2 400 workers and a wave)
@@ -1094,7 +1114,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     }
     if ((rc = timing_end(m, ev, DGE_OK))) return rc;
     m->launches++;
-    m->last_policy = pol >= 30 ? pol - 30 : (pol >= 20 ? pol - 20 : (pol == 13 ? 2 : (pol == 14 ? 5 : (pol >= 10 ? pol - 10 : pol)))); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
+    m->last_policy = pol >= 30 ? pol - 30 : (pol >= 20 ? pol - 20 : (pol == 13 ? 2 : (pol == 14 || pol == 15 ? 5 : (pol >= 10 ? pol - 10 : pol)))); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
     DGE_HIP(hipGetLastError());
     return DGE_OK;
 }

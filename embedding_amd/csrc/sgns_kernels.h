@@ -512,13 +512,13 @@ __device__ __forceinline__ void lk_acc_flush(float* acc, int row, const TableVie
         if ((uint32_t)(c * 64 + wl) < t.valid) atomicAdd(pr + c * 64, v);
     }
 }
-template <int DCH>
+template <int DCH, int NBOX = LK_MB_WORKERS * 2>
 __device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* done, int n_workers_here, const TableView& syn0, const TableView& syn1neg, const TableView& syn1,
                                                 float* acc = nullptr, int* acc_cnt = nullptr, int n_acc = 0, int drain = 1) {
     const int wl = threadIdx.x & 63;
     for (;;) {
         bool any = false;
-        for (int b = 0; b < LK_MB_WORKERS * 2; b++) {
+        for (int b = 0; b < NBOX; b++) {
             const int f = __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b]));       // (every lane reads the same word)
             if (f == 0) continue;
             any = true;
@@ -555,7 +555,7 @@ __device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* d
             const int d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
             if (d >= n_workers_here) {                      // every worker has left: whatever it posted is visible now — one last look
                 bool left_over = false;
-                for (int b = 0; b < LK_MB_WORKERS * 2; b++) left_over |= __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b])) != 0;
+                for (int b = 0; b < NBOX; b++) left_over |= __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b])) != 0;
                 if (!left_over) {
                     for (int r = 0; r < n_acc; r++)         // what is still parked goes out
                         if (__builtin_amdgcn_readfirstlane(acc_cnt[r]) > 0) lk_acc_flush<DCH>(acc, r, syn1neg, wl);
@@ -1406,15 +1406,21 @@ __device__ __forceinline__ void row_add(Row<DCH>& y, const Row<DCH>& x) {
 // 2.5 of the 3.6 KB of atomics a pair, which is what the kernel runs against; the centre's gathered update is then flushed under the row's lock as well (by ONE group,
 // after the four groups' shares met through shuffles: a lock taken by one group of a wave must never be waited for by another), so that syn1neg is only ever
 // updated under locks.  The context row (syn0) stays on atomics.
-template <int DCH, bool NLOCK>
-__global__ void __launch_bounds__(256, 2)
+// NW = waves of a workgroup that train (one more issues the atomics): 3, two workgroups a compute unit — or 7 in ONE workgroup of 512 threads (with NLOCK, where the
+// atomics wave has half the messages to serve): the LDS accumulators of the nodes next to the root are then shared by 7 waves instead of 3, so at the same number of
+// additions parked device-wide (workgroups x hs_drain) each is drained half as often — the root's row takes every centre's update and its atomics complete one
+// 64-byte request per ~12 ns: at 3.3e8 edges/s and a drain every 4 additions that row alone was busy half the time —, 7 of a compute unit's 8 waves train instead
+// of 6.  (How many accumulators: sgns.hip — fewer than the small workgroups hold turned out better.)
+template <int DCH, bool NLOCK, int NW>
+__global__ void __launch_bounds__((NW + 1) * 64, NW == 3 ? 2 : 1)
 k_sgns_train_hsw(TrainParams p) {
+    constexpr int NBOX = NW * 4 * 2;                       // two message boxes per 16-lane group that trains
     __shared__ float s_exp[EXP_TABLE_SIZE];
-    __shared__ __attribute__((aligned(16))) float s_mb[LK_MB_WORKERS * 2 * LkBox<DCH>::FLOATS];
-    __shared__ int s_mb_flag[LK_MB_WORKERS * 2];
+    __shared__ __attribute__((aligned(16))) float s_mb[NBOX * LkBox<DCH>::FLOATS];
+    __shared__ int s_mb_flag[NBOX];
     __shared__ int s_mb_done;
     for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
-    if (threadIdx.x < LK_MB_WORKERS * 2) s_mb_flag[threadIdx.x] = 0;
+    if (threadIdx.x < NBOX) s_mb_flag[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_mb_done = 0;
     float* s_hot = s_dyn;
     int* s_hot_cnt = (int*)(s_dyn + (size_t)p.hs_n_hot * DCH * 64);
@@ -1422,14 +1428,14 @@ k_sgns_train_hsw(TrainParams p) {
     __syncthreads();
 
     const int lane = threadIdx.x & 15, grp = (threadIdx.x >> 4) & 3, wl = threadIdx.x & 63;
-    const int wk = threadIdx.x >> 4;                       // this group's message boxes (groups 0 .. 11 train, the fourth wave issues the atomics)
+    const int wk = threadIdx.x >> 4;                       // this group's message boxes (groups 0 .. 4 NW - 1 train, the last wave issues the atomics)
     const int wv = threadIdx.x >> 6;
     TableView syn0 = make_view(p.syn0, p.V, p.stride), syn1neg = make_view(p.syn1neg, p.V, p.stride), syn1 = make_view(p.syn1, p.V, p.stride);
     syn0.valid = syn1neg.valid = syn1.valid = (uint32_t)p.D;
-    const int64_t wave = (int64_t)blockIdx.x * 3 + wv;     // p.n_workers = waves that train
-    if (wv == 3) {
-        const int64_t waves_here = min((int64_t)3, p.n_workers - (int64_t)blockIdx.x * 3);
-        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(waves_here, (int64_t)0) * 4, syn0, syn1neg, syn1);
+    const int64_t wave = (int64_t)blockIdx.x * NW + wv;    // p.n_workers = waves that train
+    if (wv == NW) {
+        const int64_t waves_here = min((int64_t)NW, p.n_workers - (int64_t)blockIdx.x * NW);
+        lk_atomics_wave<DCH, NBOX>(s_mb, s_mb_flag, &s_mb_done, (int)max(waves_here, (int64_t)0) * 4, syn0, syn1neg, syn1);
     }
     unsigned n_posts = 0;
     const int L = p.L, W = p.W, K = p.K;
@@ -1440,7 +1446,7 @@ k_sgns_train_hsw(TrainParams p) {
     for (int j = 0; j < K; j++) { mK *= DGE_W2V_MULT; cK = cK * DGE_W2V_MULT + 11; }
     unsigned long long my_pairs = 0, my_words = 0;
 
-    int64_t w_next = (wv == 3 || wave >= p.n_workers) ? p.n_rows : wave;
+    int64_t w_next = (wv == NW || wave >= p.n_workers) ? p.n_rows : wave;
     while (w_next < p.n_rows) {
         const int64_t w = w_next;
         if (p.next_walk) {
@@ -1655,7 +1661,7 @@ k_sgns_train_hsw(TrainParams p) {
                 }
         }
     }
-    if (wv != 3) {
+    if (wv != NW) {
         if (wl == 0) {
             if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
             if (my_words) atomicAdd(&p.counters[1], my_words);
@@ -1672,8 +1678,15 @@ static inline void launch_train_b(const TrainParams& p, int pol, unsigned blocks
         case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 10: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;    // + hierarchical softmax
         case 12: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, true, false>), dim3(blocks), dim3(threads), shmem, st, p); break;
-        case 13: if constexpr (DCH <= 2 && !BIG) hipLaunchKernelGGL((k_sgns_train_hsw<DCH, false>), dim3(blocks), dim3(threads), shmem, st, p); break;   // hierarchical softmax, a wave per centre
-        case 14: if constexpr (DCH <= 2 && !BIG) hipLaunchKernelGGL((k_sgns_train_hsw<DCH, true>), dim3(blocks), dim3(threads), shmem, st, p); break;    // ... the negatives under commit locks
+        case 13: if constexpr (DCH <= 2 && !BIG) hipLaunchKernelGGL((k_sgns_train_hsw<DCH, false, 3>), dim3(blocks), dim3(threads), shmem, st, p); break;   // hierarchical softmax, a wave per centre
+        case 14: if constexpr (DCH <= 2 && !BIG) hipLaunchKernelGGL((k_sgns_train_hsw<DCH, true, 3>), dim3(blocks), dim3(threads), shmem, st, p); break;    // ... the negatives under commit locks
+        case 15:                                                                                                                                             // ... seven such waves a workgroup
+            if constexpr (DCH <= 2 && !BIG) {
+                // (the workgroup's 41 KB of static LDS and these up to 60 KB together pass 64 KB: asked for per kernel; an error comes back from the launch)
+                (void)hipFuncSetAttribute((const void*)k_sgns_train_hsw<DCH, true, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                hipLaunchKernelGGL((k_sgns_train_hsw<DCH, true, 7>), dim3(blocks), dim3(threads), shmem, st, p);
+            }
+            break;
         case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 7: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;

@@ -80,9 +80,11 @@ if BLOCKS:
 
 if HS:
     import os
-    variants = [("pair by pair, cold end plain, atomics through the atomics wave (round 3)", {"hs_centre": 0}), ("a wave per centre, negatives by atomics", {"hs_centre": 1}), ("a wave per centre, negatives under commit locks (default on flat vocabularies)", {})]
+    variants = [("pair by pair, cold end plain, atomics through the atomics wave (round 3)", {"hs_centre": 0}), ("a wave per centre, negatives by atomics", {"hs_centre": 1}), ("a wave per centre, negatives under commit locks, three waves a workgroup", {"hs_centre": 2}), ("a wave per centre, negatives under commit locks, seven waves a workgroup", {"hs_centre": 3}), ("default", {})]
     if os.environ.get("DGE_HS_DRAINS"):          # e.g. DGE_HS_DRAINS=6,8: only the wave-per-centre kernel with these drain periods of the LDS accumulators
         variants = [("a wave per centre, LDS accumulators drained every %s centre additions" % d, {"hs_drain": int(d)}) for d in os.environ["DGE_HS_DRAINS"].split(",")]
+    if os.environ.get("DGE_HS_VARIANTS"):        # e.g. DGE_HS_VARIANTS="hs_centre=3,hs_hot_kb=30,hs_drain=8;hs_centre=2,hs_drain=8": these knob sets only
+        variants = [(v, {k: int(x) for k, x in (kv.split("=") for kv in v.split(","))}) for v in os.environ["DGE_HS_VARIANTS"].split(";")]
     for name, knobs in variants:
         with E.tuning(**knobs):
             m = E.SgnsModel.create(E.make_config(D, L, NV, negative=K, workers=0, use_hs=True), counts, 0)

@@ -517,10 +517,10 @@ def test_hierarchical_softmax_long_paths_and_word2vec_order(dge, oracle):
     assert cosine_rows(dm.vectors()[0], o0.syn0).min() > 1 - 1e-4
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["pair_by_pair", "wave_per_centre", "wave_per_centre_locks"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["pair_by_pair", "wave_per_centre", "wave_per_centre_locks", "wave_per_centre_locks_7"])
 def hs_kernel(request, dge):
     """The Hogwild kernels of the hierarchical softmax: k_sgns_train<.., HS> (pair by pair), k_sgns_train_hsw (a wave per centre, round 4: the
-    default where it applies) and the latter with the negatives' and the centre's syn1neg rows under commit locks (the default on flat vocabularies)."""
+    default where it applies) and the latter with the negatives' and the centre's syn1neg rows under commit locks, in workgroups of three and of seven training waves (the default on flat vocabularies)."""
     with dge.tuning(hs_centre=request.param):
         yield request.param
 
@@ -612,7 +612,7 @@ def test_hierarchical_softmax_wave_per_centre_linear_regime(dge, oracle, dim, ne
     init = oracle.train_sgns(ids[:1], NV, dim, window, threads=1, arith=1, use_hs=True, counts=counts, **dict(kw, alpha=0.0, min_alpha=0.0))
     corpus = dge.WalkCorpus.from_host(ids, 0)
     d_counts = torch.from_numpy(counts).to("cuda:0")
-    for centre in (2, 1, 0):
+    for centre in (3, 2, 1, 0):
         # (hs_cold = 0: the "cold" class — plain read-modify-write for inner nodes on < 2e-5 of the paths BY THE COUNTS — assumes the corpus follows the
         #  counts; these artificial counts do not, the bushy tail is visited all the time)
         with dge.tuning(hs_centre=centre, hs_cold=0):
