@@ -858,6 +858,12 @@ static int64_t block_head(dge_model* m, int n, int64_t W) {
 //     popularity over 300 000 rows: 9.5e8 against 7.3e8 owner-computes);
 //   * when the busiest row's share caps the workers below a quarter of the device (train_rows: at most 48 of a row's updates in flight), the lock protocol has
 //     nothing to win over atomics (rank^-1 over 300 000 words: 1.37e8 against 5.9e7).
+// (the first two conditions alone: a try-lock on a syn1neg row rarely fails — what the hierarchical-softmax kernel's lock form needs; it never locks a context row,
+//  so a vocabulary with a handful of rows whose OWN pairs would serialise under a syn0 lock, policy 7 with a tiny head, takes it as well)
+static bool syn1neg_locks_work(const dge_model* m) {
+    const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
+    return (int64_t)(48.0 / std::max(m->row_share_max, 1e-12)) >= 4096 && m->V >= 131072 && fail < 0.4;
+}
 static int auto_policy(const dge_model* m, bool hs) {
     if (hs) return 2;
     const double fail = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
@@ -1046,7 +1052,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // gathered syn1neg update go under the rows' locks instead of out as atomics (k_sgns_train_hsw<.., NLOCK>) — in ONE workgroup of seven training waves a
         // compute unit, which share their LDS accumulators (DGE_TUNE_HS_CENTRE: 1 keeps atomics, 2 = locks in workgroups of three waves, 3 = of seven)
         const int64_t centre_knob = g_dge_tuning[DGE_TUNE_HS_CENTRE];
-        if (centre_knob == 2 || centre_knob == 3 || (centre_knob < 0 && m->cfg.update_policy == 0 && auto_policy(m, false) == 5)) {
+        if (centre_knob == 2 || centre_knob == 3 || (centre_knob < 0 && m->cfg.update_policy == 0 && syn1neg_locks_work(m))) {
             pol = centre_knob == 2 ? 14 : 15;
             if (pol == 15) nw = 7;
         }

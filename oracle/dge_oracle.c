@@ -818,6 +818,11 @@ int orc_train_sgns(const int32_t* walks, int64_t n_walks, int32_t max_len,
  * sides then train the same further slice of walks — sequentially here, at full concurrency there. */
 int orc_train_sgns_from(const int32_t* walks, int64_t n_walks, int32_t max_len, const orc_train_config* cfg,
                         const int64_t* counts, const float* syn0_init, const float* syn1neg_init, orc_model** out) {
+    return orc_train_sgns_from_hs(walks, n_walks, max_len, cfg, counts, syn0_init, syn1neg_init, NULL, out);
+}
+/* ... and the inner-node rows of the Huffman tree as well (use_hs; [V-1 x dim], syn1_init may be NULL: zeros, word2vec.c's start) */
+int orc_train_sgns_from_hs(const int32_t* walks, int64_t n_walks, int32_t max_len, const orc_train_config* cfg,
+                           const int64_t* counts, const float* syn0_init, const float* syn1neg_init, const float* syn1_init, orc_model** out) {
     if (!walks || !cfg || !out || cfg->dim <= 0 || cfg->window <= 0 || cfg->negative < 0 ||
         cfg->n_vertices <= 0 || cfg->table_size <= 0 || max_len <= 0) return 1;
     init_exp_table();
@@ -866,6 +871,7 @@ int orc_train_sgns_from(const int32_t* walks, int64_t n_walks, int32_t max_len, 
     }
     if (syn0_init) memcpy(m->syn0, syn0_init, (size_t)(V * D) * sizeof(float));
     if (syn1neg_init) memcpy(m->syn1neg, syn1neg_init, (size_t)(V * D) * sizeof(float));
+    if (syn1_init && m->syn1 && V > 1) memcpy(m->syn1, syn1_init, (size_t)((V - 1) * D) * sizeof(float));
 
     /* --- unigram^0.75 table: word2vec.c InitUnigramTable --- */
     const int64_t T = cfg->table_size;

@@ -100,6 +100,8 @@ int   orc_train_sgns(const int32_t* walks, int64_t n_walks, int32_t max_len,
  * tables reached so far, rows in the vocabulary's order (count desc, vertex id asc); any of the three may be NULL */
 int   orc_train_sgns_from(const int32_t* walks, int64_t n_walks, int32_t max_len, const orc_train_config* cfg,
                           const int64_t* counts, const float* syn0_init, const float* syn1neg_init, orc_model** out);
+int   orc_train_sgns_from_hs(const int32_t* walks, int64_t n_walks, int32_t max_len, const orc_train_config* cfg,
+                             const int64_t* counts, const float* syn0_init, const float* syn1neg_init, const float* syn1_init, orc_model** out);
 int64_t orc_model_vocab_size(const orc_model* m);
 int32_t orc_model_dim(const orc_model* m);
 const float*   orc_model_syn0(const orc_model* m);      /* [V x dim] */

@@ -66,6 +66,7 @@ def lib():
     L.orc_sample_walks.argtypes = [vp, i64, i32, i64, C.c_int, i64, vp, P(i64)]
     L.orc_train_sgns.argtypes = [vp, i64, i32, P(TrainConfig), P(vp)]
     L.orc_train_sgns_from.argtypes = [vp, i64, i32, P(TrainConfig), vp, vp, vp, P(vp)]
+    L.orc_train_sgns_from_hs.argtypes = [vp, i64, i32, P(TrainConfig), vp, vp, vp, vp, P(vp)]
     for name, rt in (("vocab_size", i64), ("dim", i32), ("syn0", vp), ("syn1neg", vp), ("syn1", vp), ("vocab_ids", vp),
                      ("counts", vp), ("table", vp), ("pairs", i64), ("total_words", i64), ("seconds", dbl)):
         f = getattr(L, "orc_model_" + name); f.argtypes = [vp]; f.restype = rt
@@ -240,8 +241,8 @@ class Model:
 def train_sgns(walks, n_vertices, dim, window, negative=5, min_count=2, epochs=1, threads=1, alpha=0.025,
                min_alpha=1e-4, seed=1, table_size=100_000_000, arith=0, walk_index_base=0, total_walks=0,
                total_words=0, words_before=0, use_hs=False, part_n=0, sorted_chunk=0, sorted_walks=0, counts=None, syn0_init=None,
-               syn1neg_init=None):
-    """counts / syn0_init / syn1neg_init: continue from a given state (orc_train_sgns_from) — the vocabulary, unigram table and total_words
+               syn1neg_init=None, syn1_init=None):
+    """counts / syn0_init / syn1neg_init / syn1_init (the Huffman tree's inner nodes, [V-1 x dim], use_hs): continue from a given state (orc_train_sgns_from[_hs]) — the vocabulary, unigram table and total_words
     from `counts` ([n_vertices], the whole corpus) instead of from `walks`, the tables as a run has left them (rows in vocabulary order)."""
     walks = np.ascontiguousarray(walks, np.int32)
     n, L = walks.shape
@@ -249,7 +250,7 @@ def train_sgns(walks, n_vertices, dim, window, negative=5, min_count=2, epochs=1
                       arith, n_vertices, walk_index_base, total_walks, total_words, words_before, int(bool(use_hs)), int(part_n),
                       int(sorted_chunk), int(sorted_walks))
     h = C.c_void_p(0)
-    if counts is None and syn0_init is None and syn1neg_init is None:
+    if counts is None and syn0_init is None and syn1neg_init is None and syn1_init is None:
         rc = lib().orc_train_sgns(_ptr(walks), n, L, C.byref(cfg), C.byref(h))
     else:
         cn = None if counts is None else np.ascontiguousarray(counts, np.int64)
@@ -257,8 +258,9 @@ def train_sgns(walks, n_vertices, dim, window, negative=5, min_count=2, epochs=1
         s1 = None if syn1neg_init is None else np.ascontiguousarray(syn1neg_init, np.float32)
         if cn is not None and len(cn) != n_vertices:
             raise ValueError("counts must have n_vertices entries")
-        rc = lib().orc_train_sgns_from(_ptr(walks), n, L, C.byref(cfg), None if cn is None else _ptr(cn), None if s0 is None else _ptr(s0),
-                                       None if s1 is None else _ptr(s1), C.byref(h))
+        s2 = None if syn1_init is None else np.ascontiguousarray(syn1_init, np.float32)
+        rc = lib().orc_train_sgns_from_hs(_ptr(walks), n, L, C.byref(cfg), None if cn is None else _ptr(cn), None if s0 is None else _ptr(s0),
+                                          None if s1 is None else _ptr(s1), None if s2 is None else _ptr(s2), C.byref(h))
     if rc != 0:
         raise RuntimeError("oracle train_sgns failed: rc=%d" % rc)
     return Model(h)

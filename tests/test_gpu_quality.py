@@ -14,6 +14,9 @@ Hogwild schedule, trains pairs in another order than the sequential loop.  Eleme
 On the Zipf graph the slice is trained a second time with 1/33 of the workers — the slice is 1/33 of a bench launch, so the same ~100 walks per worker —
 and the strict comparisons apply to that run (with device-filling workers a third of this short slice is in flight at once: reported, weaker bounds).
 
+The tree term (use_hs, DL4J's builder default) has its own leg on the flat graph: a use_hs model trains the long corpus with the kernel auto picks, all THREE tables
+go to the oracle (orc_train_sgns_from_hs), and every Hogwild form of the term trains a further slice beside the oracle (test_hierarchical_softmax_launch_...).
+
 Compared: the pair count (identical); per row, the direction of the slice's update (row after - row before) against the sequential update;
 link-prediction AUC and mean negative-sampling loss on held-out walk steps.  The device must be as close to the sequential result as the
 CPU's 8-thread Hogwild is.  (SGNS half of the oracle: a restatement of word2vec.c / DL4J, parity unpinned — DESIGN.md §3.)"""
@@ -28,6 +31,7 @@ pytestmark = pytest.mark.gpu
 
 T, L, D, K = 24, 24, 128, 5
 N_SLICE = 30_000
+N_HS = 8_000          # walks of the hierarchical-softmax leg (the sequential oracle trains ~20 inner nodes a pair on top of the 6 rows)
 
 
 def _host_loss(syn0, syn1neg, vocab_ids, test_walks, R, seed=3):
@@ -57,7 +61,7 @@ def runs(dge, oracle):
     from embedding_amd import synth
     dev = "cuda:0"
     out = {}
-    pool = cf.ThreadPoolExecutor(max_workers=2)
+    pool = cf.ThreadPoolExecutor(max_workers=3)
     pending = {}
     # flat: 480 000 vertices — auto takes the lock kernel (5) from ~350 000 flat rows on (below, the owner-computes schedule); ~200 tokens per vertex in the long corpus
     for name, R, dst, N_LONG in (("flat", 20000, "community", 4_000_000), ("zipf", 14500, "community_zipf", 2_900_000)):
@@ -95,14 +99,43 @@ def runs(dge, oracle):
             with dge.tuning(workers=max(16, sch["workers"] * N_SLICE // 1_000_008 // 16 * 16)):
                 m.train(corpus, N_LONG, N_SLICE, walk_index_base=N_LONG, words_before=st_long["words"], total_walks=n_tot)
             prop = dict(dev=(m.vectors()[0], m.syn1neg()), st=m.stats(), sch=m.schedule())
+        # The hierarchical-softmax term (what DL4J's builder default adds, J/DeepWalk.java:73-76), flat graph: a model with use_hs trains the long corpus (the kernel
+        # auto picks), its THREE tables go to the oracle (orc_train_sgns_from_hs), and a shorter slice is trained from that state by every Hogwild form of the tree
+        # term — with as many walks per wave as a launch has (N_HS / 64 ~ 1 000 008 / 1 792 x 1/4) — and by the oracle, sequentially and with 8 threads.
+        # (Not from inner nodes at zero beside trained vectors: there the wave-per-centre kernels' longer staleness — a centre's 16 pairs against one pair —
+        #  overshoots on the first updates, loss + 4 % against the sequential run; that state does not occur in a training.)
+        if name == "flat":
+            mcfg = dge.make_config(D, L, NV, negative=K, workers=0, epochs=4, seed=1, table_size=10_000_000, use_hs=True)
+            mh = dge.SgnsModel.create(mcfg, counts, 0)
+            mh.train(corpus, 0, N_LONG, walk_index_base=0, total_walks=n_tot)
+            hst, hsch_long = mh.stats(), mh.schedule()
+            hkeep = [device_table(mh, t).clone() for t in (0, 1, 2)]
+            hb = (mh.vectors()[0], mh.syn1neg(), mh.syn1())
+            mh.close()
+            hs = dict(sl=sl[:N_HS], kw=dict(kw, use_hs=True, syn0_init=hb[0], syn1neg_init=hb[1], syn1_init=hb[2], words_before=hst["words"]), legs={}, before=hb,
+                      sch_long=hsch_long, pairs_long=hst["pairs"])
+            pending["hs"] = pool.submit(oracle.train_sgns, hs["sl"], NV, D, L, threads=1, **hs["kw"])
+            for leg, knobs in (("auto", {}), ("pair_by_pair", {"hs_centre": 0}), ("centre_atomics", {"hs_centre": 1}), ("centre_locks_3", {"hs_centre": 2})):
+                mh = dge.SgnsModel.create(mcfg, counts, 0)
+                for t in (0, 1, 2):
+                    mh.import_partition(t, 1, 0, hkeep[t].view(-1))
+                with dge.tuning(workers=64, **knobs):
+                    mh.train(corpus, N_LONG, N_HS, walk_index_base=N_LONG, words_before=hst["words"], total_walks=n_tot)
+                hs["legs"][leg] = dict(dev=(mh.vectors()[0], mh.syn1neg(), mh.syn1()), st=mh.stats(), sch=mh.schedule())
+                mh.close()
+            del hkeep
         del keep
         m.close(); corpus.close(); g.close()
         torch.cuda.empty_cache()
-        out[name] = dict(R=R, NV=NV, n_long=N_LONG, vid=vid, test=test, before=(s0_0, s1_0), dev=(s0_d, s1_d), st=st, sch=sch, sch_long=sch_long, kw=kw, sl=sl, V=len(vid), prop=prop)
+        out[name] = dict(R=R, NV=NV, n_long=N_LONG, vid=vid, test=test, before=(s0_0, s1_0), dev=(s0_d, s1_d), st=st, sch=sch, sch_long=sch_long, kw=kw, sl=sl, V=len(vid), prop=prop, st_long_pairs=st_long["pairs"])
+        if name == "flat":
+            out[name]["hs"] = hs
     for name, o in out.items():
         o["cpu8"] = oracle.train_sgns(o["sl"], o["NV"], D, L, threads=8, **o["kw"])
+    out["flat"]["hs"]["cpu8"] = oracle.train_sgns(out["flat"]["hs"]["sl"], out["flat"]["NV"], D, L, threads=8, **out["flat"]["hs"]["kw"])
     for name, o in out.items():
         o["seq"] = pending[name].result()
+    out["flat"]["hs"]["seq"] = pending["hs"].result()
     pool.shutdown()
     return out
 
@@ -145,3 +178,37 @@ def test_full_concurrency_launch_against_the_sequential_oracle(runs, name, polic
     assert res[strict]["cos0_med"] > res["cpu8"]["cos0_med"] - 0.02 and res[strict]["cos1_med"] > res["cpu8"]["cos1_med"] - 0.02, res
     assert res[strict]["cos0_p05"] > res["cpu8"]["cos0_p05"] - 0.05 and res[strict]["cos1_p05"] > res["cpu8"]["cos1_p05"] - 0.05, res
     assert res[strict]["auc"] >= res["cpu8"]["auc"] - 0.002, res
+
+
+def test_hierarchical_softmax_launch_against_the_sequential_oracle(runs):
+    """The tree term at concurrency, anchored on the oracle like the negative-sampling kernels above: from the trained flat state (inner-node rows at zero on
+    both sides) the kernel auto picks — a wave per centre, the negatives under commit locks (k_sgns_train_hsw) — trains the same walks as the oracle's
+    sequential loop and its 8 Hogwild threads."""
+    o = runs["flat"]; h = o["hs"]
+    seq, cpu8 = h["seq"], h["cpu8"]
+    b0, b1, b2 = h["before"]
+    R, vid, test = o["R"], o["vid"], o["test"]
+    assert seq.pairs == cpu8.pairs > 2.0e6 and np.array_equal(seq.vocab_ids, o["vid"])
+    # the long training ran the kernel auto picks at device-filling concurrency: a wave per centre, negatives under commit locks (reported as the locks, 5)
+    assert h["sch_long"]["update_policy"] == 5 and h["sch_long"]["workers"] >= 1000 and h["pairs_long"] == o["st_long_pairs"], h["sch_long"]
+    res = {}
+    tabs = [("before", (b0, b1, b2)), ("seq", (seq.syn0, seq.syn1neg, seq.syn1)), ("cpu8", (cpu8.syn0, cpu8.syn1neg, cpu8.syn1))] + [(leg, v["dev"]) for leg, v in h["legs"].items()]
+    for tag, (s0, s1, s2) in tabs:
+        res[tag] = dict(auc=link_auc(s0, s1, vid, test, R), loss=_host_loss(s0, s1, vid, test, R))
+        if tag in ("before", "seq"):
+            continue
+        assert np.isfinite(s0).all() and np.isfinite(s1).all() and np.isfinite(s2).all(), tag
+        c0 = _delta_cosine(s0, b0, seq.syn0); c1 = _delta_cosine(s1, b1, seq.syn1neg); c2 = _delta_cosine(s2[: len(b2)], b2, seq.syn1)
+        res[tag].update(cos0_med=float(np.median(c0)), cos0_p05=float(np.percentile(c0, 5)), cos1_med=float(np.median(c1)), cos2_med=float(np.median(c2)),
+                        cos2_p05=float(np.percentile(c2, 5)))
+    print("\n[quality hs] %s" % (res,), flush=True)
+    assert res["before"]["auc"] > 0.85, res                     # a trained embedding (with the tree term on)
+    for leg, v in h["legs"].items():
+        assert v["st"]["pairs"] == seq.pairs and v["sch"]["workers"] == 64, (leg, v["sch"])
+    assert h["legs"]["auto"]["sch"]["update_policy"] == 5, h["legs"]["auto"]["sch"]
+    for leg in h["legs"]:
+        assert abs(res[leg]["auc"] - res["seq"]["auc"]) < 0.005 and abs(res[leg]["loss"] / res["seq"]["loss"] - 1) < 0.01, (leg, res)
+        # as close to the sequential result as the reference's own 8 Hogwild workers: update directions of the vectors, of the negative-sampling rows, of the inner nodes
+        for k in ("cos0_med", "cos1_med", "cos2_med"):
+            assert res[leg][k] > res["cpu8"][k] - 0.02, (leg, k, res)
+        assert res[leg]["cos0_p05"] > res["cpu8"]["cos0_p05"] - 0.05 and res[leg]["cos2_p05"] > res["cpu8"]["cos2_p05"] - 0.05, (leg, res)

@@ -431,5 +431,16 @@ def test_oracle_continues_from_a_given_state(oracle):
                                words_before=words_before, syn0_init=h1.syn0, syn1neg_init=h1.syn1neg, **kw)
         assert h1.pairs + h2.pairs == whole.pairs
         assert np.array_equal(h2.syn0.view(np.int32), whole.syn0.view(np.int32)) and np.array_equal(h2.syn1neg.view(np.int32), whole.syn1neg.view(np.int32))
+    # ... and with the hierarchical softmax: the inner-node table is handed over as well (orc_train_sgns_from_hs)
+    kw = dict(negative=3, table_size=1009, arith=0, seed=3, use_hs=True)
+    whole = oracle.train_sgns(w, 50, 16, 6, **kw)
+    cnt = np.bincount(w[w >= 0], minlength=50).astype(np.int64)
+    h1 = oracle.train_sgns(w[:100], 50, 16, 6, counts=cnt, total_walks=200, total_words=whole.total_words, **kw)
+    words_before = int(np.isin(w[:100], whole.vocab_ids).sum())
+    h2 = oracle.train_sgns(w[100:], 50, 16, 6, counts=cnt, total_walks=200, total_words=whole.total_words, walk_index_base=100,
+                           words_before=words_before, syn0_init=h1.syn0, syn1neg_init=h1.syn1neg, syn1_init=h1.syn1, **kw)
+    assert h1.pairs + h2.pairs == whole.pairs and np.abs(whole.syn1).max() > 0
+    for a, b in ((h2.syn0, whole.syn0), (h2.syn1neg, whole.syn1neg), (h2.syn1, whole.syn1)):
+        assert np.array_equal(a.view(np.int32), b.view(np.int32))
     with pytest.raises(ValueError):
         oracle.train_sgns(w, 50, 16, 6, counts=np.zeros(7, np.int64))
