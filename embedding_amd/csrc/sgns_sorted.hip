@@ -402,18 +402,7 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
     EMIT_DRAW_ROW(run_nb)
     const int lane = threadIdx.x & 15;
     const int sh = threadIdx.x & 48;
-    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    if (w >= p.n_rows) return;
     const int L = p.L, K = p.K, N = p.part_n;
-    const int len = (int)p.len[w];
-    if (len <= 1) return;
-    const int32_t* sen = p.sen + w * L;
-    const int32_t tk0 = lane < len ? sen[lane] : -1, tk1 = lane + 16 < len ? sen[lane + 16] : -1;
-    const int32_t tk2 = lane + 32 < len ? sen[lane + 32] : -1, tk3 = lane + 48 < len ? sen[lane + 48] : -1;
-    const uint64_t ctx_mask = part_token_mask(tk0, tk1, tk2, tk3, N, p.part_ctx);
-    if (!ctx_mask) return;
-    // lane t keeps the next free pair position of bucket t
-    int64_t my_pos = lane < N ? cell_off[(int64_t)lane * p.n_rows + w] : 0;
     uint64_t mA = 1, cA = 0;
     for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
     // K <= 16: up to P = 16 / K pairs of a centre per trip (k_sorted_emit): lane l = z * K + d draws negative d of the trip's pair z from that
@@ -425,6 +414,17 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
     // token at walk position c, c different in every lane: lane c & 15 holds it in register c >> 4
 #define BLOCK_TOK(c_) ({ const int c__ = (c_); const int32_t a0 = __shfl(tk0, c__ & 15, 16), a1 = __shfl(tk1, c__ & 15, 16), a2 = __shfl(tk2, c__ & 15, 16), a3 = __shfl(tk3, c__ & 15, 16); \
                          (c__ >> 4) == 0 ? a0 : ((c__ >> 4) == 1 ? a1 : ((c__ >> 4) == 2 ? a2 : a3)); })
+    // a group takes walk after walk (with the run form the grid is sized to fill the device, not to the batch: its LDS arrays are filled once per workgroup)
+    for (int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; w < p.n_rows; w += ((int64_t)gridDim.x * blockDim.x) >> 4) {
+    const int len = (int)p.len[w];
+    if (len <= 1) continue;
+    const int32_t* sen = p.sen + w * L;
+    const int32_t tk0 = lane < len ? sen[lane] : -1, tk1 = lane + 16 < len ? sen[lane + 16] : -1;
+    const int32_t tk2 = lane + 32 < len ? sen[lane + 32] : -1, tk3 = lane + 48 < len ? sen[lane + 48] : -1;
+    const uint64_t ctx_mask = part_token_mask(tk0, tk1, tk2, tk3, N, p.part_ctx);
+    if (!ctx_mask) continue;
+    // lane t keeps the next free pair position of bucket t
+    int64_t my_pos = lane < N ? cell_off[(int64_t)lane * p.n_rows + w] : 0;
     for (int i = 0; i < len; i++) {
         uint64_t s; int lo, hi;
         unit_window(p, w, i, len, s, lo, hi);
@@ -483,6 +483,7 @@ __global__ void __launch_bounds__(256) k_block_emit(TrainParams p, const int64_t
                 slot += K + 1;
             }
         }
+    }
     }
 #undef BLOCK_TOK
     (void)sh;
@@ -799,12 +800,15 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
                     s->st_cap_items = cap;
                 }
                 if (all_items > 0) {
-                    // (the run form pays where few runs are searched and a workgroup has work for its 25 KB of LDS: cfg3's 1 716 runs and the 16 walks of a workgroup
-                    //  here made this kernel slower, 38 against 31 ms a batch — a vocabulary of up to 510 runs takes it)
+                    // (the run form only for vocabularies of up to 510 runs: with cfg3's 1 716 — an 11-step search in LDS and f64 arithmetic per draw — this kernel took
+                    //  38 ms a batch with one walk per group and 40.8 ms with the groups looping over the batch from a device-filling grid, against 31 ms on the table:
+                    //  unlike the lock kernel (§5.1) it is not bound by requests)
                     int32_t run_nb = 2; while (run_nb < p.n_runs + 2 && run_nb < DGE_RUN_MAX) run_nb <<= 1;
-                    if (p.n_runs > 0 && run_nb <= 512) hipLaunchKernelGGL(k_block_emit<true>, dim3(grid_for(p.n_rows * 16, 256)), dim3(256), 0, st, p, s->st_off, s->st_it,
+                    const bool runs = p.n_runs > 0 && run_nb <= 512;
+                    const unsigned eg = runs ? std::min<unsigned>(grid_for(p.n_rows * 16, 256), (unsigned)m->n_cus * 8u) : grid_for(p.n_rows * 16, 256);
+                    if (runs) hipLaunchKernelGGL(k_block_emit<true>, dim3(eg), dim3(256), 0, st, p, s->st_off, s->st_it,
                                                          (int32_t)((m->V + p.part_n - 1) / p.part_n), (int32_t)ks1, run_nb);
-                    else hipLaunchKernelGGL(k_block_emit<false>, dim3(grid_for(p.n_rows * 16, 256)), dim3(256), 0, st, p, s->st_off, s->st_it,
+                    else hipLaunchKernelGGL(k_block_emit<false>, dim3(eg), dim3(256), 0, st, p, s->st_off, s->st_it,
                                             (int32_t)((m->V + p.part_n - 1) / p.part_n), (int32_t)ks1, run_nb);
                 }
                 DGE_HIP(hipGetLastError());
