@@ -66,6 +66,32 @@ def test_owner_computes_row_numbers_of_17_and_18_bits(dge, oracle):
         assert np.array_equal(bits(s0), bits(om.syn0)) and np.array_equal(bits(dm.syn1neg()), bits(om.syn1neg)), NV
 
 
+def test_owner_computes_generator_run_form_draws_the_tables_rows(dge, oracle):
+    """The item generator takes a negative's row from the unigram table's RUN form in LDS where the vocabulary has at most 510 runs of equal counts
+    (round 4), from the rank-block table otherwise: the same rows either way — with the run form switched off (DGE_TUNE_TABLE_RUNS = 0) the tables end
+    bit-identical, and both equal the oracle's, which reads word2vec's plain table."""
+    rng = np.random.default_rng(23)
+    for NV, few_counts in ((3000, True), (2500, False)):
+        L, n = 10, 4000
+        if few_counts:      # every vertex ~ equally often: a few dozen distinct counts
+            ids = rng.integers(0, NV, (n, L)).astype(np.int32)
+        else:               # a smooth popularity ramp: thousands of distinct counts (more runs than the generator's LDS search takes)
+            p = np.linspace(1.0, 300.0, NV); p /= p.sum()
+            ids = rng.choice(NV, size=(n * 30, L), p=p).astype(np.int32)
+        kw = dict(negative=5, min_count=1, epochs=1, seed=9, table_size=1_000_003)
+        om = oracle.train_sgns(ids, NV, 32, 5, sorted_chunk=64, sorted_walks=500, **kw)
+        res = []
+        for runs_knob in (None, 0):
+            with dge.tuning(sorted_chunk=64, sorted_walks=500, **({} if runs_knob is None else {"table_runs": runs_knob})):
+                dm = dge.SgnsModel.fit(ids, dge.make_config(32, 5, NV, workers=0, update_policy=8, **kw), 0)
+                res.append((dm.vectors()[0], dm.syn1neg(), dm.table_runs(), dm.stats()["pairs"]))
+        (a0, a1, runs_a, pa), (b0, b1, runs_b, pb) = res
+        assert runs_b[0] == 0 and pa == pb == om.pairs                   # (with the knob at 0 a model has no run form at all)
+        assert (0 < runs_a[0] <= 510) if few_counts else runs_a[0] > 510, runs_a
+        assert np.array_equal(bits(a0), bits(b0)) and np.array_equal(bits(a1), bits(b1)), NV
+        assert np.array_equal(bits(a0), bits(om.syn0)) and np.array_equal(bits(a1), bits(om.syn1neg)), NV
+
+
 def test_owner_computes_under_the_block_schedule(dge, oracle):
     """N = 3 ranks on one device, every block a device-filling owner-computes launch: bit-identical to the oracle running the 3 x 3
     blocks one after the other with the same schedule."""
