@@ -749,9 +749,15 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         // cold inner nodes: on fewer than 2e-5 of all paths (their weights ascend with the node number: a prefix)
         { int64_t tot = 0; for (int64_t c : m->h_counts) tot += c;
           const int64_t limit = (int64_t)((double)tot * 2e-5);
-          m->hs_cold_auto = (int32_t)(std::upper_bound(node_w.begin(), node_w.end(), limit) - node_w.begin()); }
-        MC(table_alloc(&m->d_syn1, tab + 64, device, st, &m->placed_seen[2], &m->placed_best[2], &m->placed_worst[2]));
-        MH(hipMemsetAsync(m->d_syn1, 0, (tab + 64) * sizeof(float), st));
+          m->hs_cold_auto = (int32_t)(std::upper_bound(node_w.begin(), node_w.end(), limit) - node_w.begin());
+          // busy inner nodes: on a tenth of all paths and more (a suffix; the balanced tree of a flat vocabulary has 15 of them, a skewed one a few more) — at most 64
+          const int64_t busy = (int64_t)((double)tot * 0.1);
+          m->hs_rep_auto = (int32_t)std::min<int64_t>(64, node_w.end() - std::lower_bound(node_w.begin(), node_w.end(), busy));
+          for (int k = 0; k < 8; k++)      // first node on more than k/8 of all paths (weights ascend with the node number)
+              m->hs_rep_thr8[k] = (int32_t)(std::upper_bound(node_w.begin(), node_w.end(), (int64_t)((double)tot * k / 8.0)) - node_w.begin()); }
+        // (behind the table: HS_REP_ROWS spare rows for k_sgns_train_hsw's copies of the busiest inner nodes — zero between launches)
+        MC(table_alloc(&m->d_syn1, tab + 64 + (size_t)HS_REP_ROWS * m->stride, device, st, &m->placed_seen[2], &m->placed_best[2], &m->placed_worst[2]));
+        MH(hipMemsetAsync(m->d_syn1, 0, (tab + 64 + (size_t)HS_REP_ROWS * m->stride) * sizeof(float), st));
         if (longest > 40) { model_release(m); delete m; DGE_FAIL(DGE_ERR_ARG, "dge_model_create: a Huffman code of %d bits exceeds word2vec's MAX_CODE_LENGTH 40", longest); }
         MC(dge_dev_alloc(&m->d_hs_off, (size_t)V + 1)); MC(dge_dev_alloc(&m->d_hs_points, m->h_hs_points.size())); MC(dge_dev_alloc(&m->d_hs_codes, (size_t)V));
         MH(hipMemcpyAsync(m->d_hs_off, m->h_hs_off.data(), ((size_t)V + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
@@ -873,6 +879,16 @@ static int auto_policy(const dge_model* m, bool hs) {
     return 2;
 }
 
+// k_sgns_train_hsw's copies of the busiest inner nodes: row j of `rows` += its HS_REP - 1 copies, which are cleared (one workgroup a node; runs behind the trainer)
+__global__ void k_hs_rep_fold(float* rows, float* rep, int32_t n_rep, int32_t stride) {
+    const int j = blockIdx.x;
+    for (int e = threadIdx.x; e < stride; e += blockDim.x) {
+        float v = rows[(size_t)j * stride + e];
+        for (int c = 0; c < HS_REP - 1; c++) { float* q = rep + ((size_t)c * n_rep + j) * stride + e; v += *q; *q = 0.f; }
+        rows[(size_t)j * stride + e] = v;
+    }
+}
+
 static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32_t L, int64_t walk_index_base, int32_t epoch,
                       int64_t words_before, double words_scale, int64_t total_walks, uint64_t corpus_gen) {
     if (n_rows == 0 || m->V == 0) return DGE_OK;
@@ -908,6 +924,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.locks = m->d_locks;
     p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
     p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0; p.hs_cold = 0; p.hs_wave = 0;
+    p.hs_rep0 = 0x7fffffff; p.hs_rep_n = 0; for (int k = 0; k < HS_REP; k++) p.hs_rep_thr[k] = 0x7fffffff;
     p.part_n = m->part_n; p.part_ctx = m->part_ctx; p.part_tgt = m->part_tgt; p.syn0_free = 0; p.acc_rows = 0; p.acc_drain = 16;
     p.N_magic = 0xFFFFFFFFu / (uint32_t)std::max(m->part_n, 1);
     p.big_seg_shift = 0;
@@ -1069,7 +1086,20 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // accumulators (the 29 nodes next to the root) and a drain every 8 additions 3.6e8 at AUC 0.9533; with 30 KB 3.64e8 / 0.9526, with 60 KB 3.7e8 / 0.9519 — every
         // accumulator is a row whose readers lag workgroups x drain / 2 updates behind, so fewer of them and shared by more waves is the better trade (three waves at
         // drain 8: 3.63e8 / 0.9518).
-        if (nw == 7) {      // one workgroup a compute unit
+        // The busiest inner nodes in copies instead of LDS accumulators (k_sgns_train_hsw, HS_REP): the default; DGE_TUNE_HS_HOT_KB > 0 brings the accumulators back
+        // (that many KB of them; the drain period then matters again) for comparison.
+        const int64_t hot_kb_knob = g_dge_tuning[DGE_TUNE_HS_HOT_KB];
+        if (hot_kb_knob <= 0 && m->hs_rep_auto > 0 && m->V > 1) {
+            const int64_t n_rep = std::min<int64_t>(std::min<int64_t>(m->hs_rep_auto, HS_REP_NODES), m->V - 1);
+            p.hs_rep_n = (int32_t)n_rep; p.hs_rep0 = (int32_t)(m->V - 1 - n_rep);      // (the copies: rows V .. of syn1, zero between launches: k_hs_rep_fold)
+            // copies per node: ceil(share of the paths x F), F = HS_REP (the root: HS_REP copies; DGE_TUNE_HS_DRAIN = F for comparison: 4 = the root four copies, ...)
+            { const int64_t f_knob = g_dge_tuning[DGE_TUNE_HS_DRAIN];
+              const int F = (int)std::min<int64_t>(HS_REP, f_knob >= 1 ? f_knob : (int64_t)HS_REP);
+              for (int k = 1; k < HS_REP; k++) p.hs_rep_thr[k] = k < F ? std::max(m->hs_rep_thr8[std::min(7, k * 8 / F)], p.hs_rep0) : 0x7fffffff;
+              p.hs_rep_thr[0] = 0; }
+            p.hs_n_hot = 0; p.hs_hot0 = (int32_t)std::max<int64_t>(m->V - 1, 0); shmem = 0;
+            { const int64_t cold_knob = g_dge_tuning[DGE_TUNE_HS_COLD]; p.hs_cold = (int32_t)std::min<int64_t>(cold_knob >= 0 ? cold_knob : (int64_t)m->hs_cold_auto, p.hs_rep0); }
+        } else if (nw == 7) {      // one workgroup a compute unit
             const int64_t row_b = (int64_t)m->stride * 4 + 4;
             const int64_t hot_kb = g_dge_tuning[DGE_TUNE_HS_HOT_KB];
             p.hs_n_hot = (int32_t)std::min<int64_t>(std::max<int64_t>(m->V - 1, 0), (hot_kb >= 0 ? std::min<int64_t>(hot_kb, 100) * 1024 : 15360) / row_b);
@@ -1118,6 +1148,8 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         case 6: dge_launch_train_dch6(p, pol, big, blocks, threads, shmem, st); break;
         default: dge_launch_train_dch8(p, pol, big, blocks, threads, shmem, st); break;
     }
+    if (p.hs_rep_n > 0)      // the copies of the busiest inner nodes go back into their rows (and are zero again for the next launch's memset to find nothing)
+        hipLaunchKernelGGL(k_hs_rep_fold, dim3((unsigned)p.hs_rep_n), dim3(128), 0, st, m->d_syn1 + (size_t)p.hs_rep0 * m->stride, m->d_syn1 + (size_t)m->V * m->stride, p.hs_rep_n, m->stride);
     if ((rc = timing_end(m, ev, DGE_OK))) return rc;
     m->launches++;
     m->last_policy = pol >= 30 ? pol - 30 : (pol >= 20 ? pol - 20 : (pol == 13 ? 2 : (pol == 14 || pol == 15 ? 5 : (pol >= 10 ? pol - 10 : pol)))); m->last_workers = workers; m->last_hot_rows = p.hot_rows;

@@ -10,6 +10,9 @@
 
 #define EXP_TABLE_SIZE 1000
 #define MAX_EXP 6
+#define HS_REP 8             /* most copies an inner node has during a launch of k_sgns_train_hsw (the root's) */
+#define HS_REP_NODES 64      /* at most this many inner nodes have copies */
+#define HS_REP_ROWS ((HS_REP - 1) * HS_REP_NODES)      /* spare rows behind syn1 for them */
 #define NEG_BATCH 5
 #ifndef DGE_LOCKED_WAVES
 #define DGE_LOCKED_WAVES 3
@@ -55,6 +58,11 @@ struct TrainParams {
     const int64_t* hs_off; const int32_t* hs_points; const uint64_t* hs_codes;
     int32_t hs_hot0, hs_n_hot; // inner nodes [hs_hot0, hs_hot0 + hs_n_hot) — the ones nearest the root — combine in LDS
     int32_t hs_drain;         // an LDS accumulator is drained to memory every hs_drain additions
+    // k_sgns_train_hsw: the busiest inner nodes [hs_rep0, hs_rep0 + hs_rep_n) — each on a tenth of all paths and more — live in up to HS_REP copies during a launch: copy 0
+    // is the row itself, copy c = 1 .. HS_REP-1 is row V + (c-1) * hs_rep_n + node - hs_rep0 of syn1 (HS_REP_ROWS spare rows behind the table: dge_model_create); a reader
+    // adds the copies up, a writer's atomics go to ITS copy
+    int32_t hs_rep0, hs_rep_n;
+    int32_t hs_rep_thr[HS_REP];   // node >= hs_rep_thr[k]: the node has more than k copies (k = 1 .. HS_REP-1; ascending weights: a node's copies grow with its number)
     int32_t hot_rows;         // policy 7: vocabulary rows [0, hot_rows) — the most frequent — are never locked, they take atomics
     // multi-GPU block schedule (dge_model_set_partition): only pairs whose context row is in partition part_ctx and whose
     // centre row is in partition part_tgt (row % part_n) are trained; negatives are moved into partition part_tgt
@@ -441,7 +449,7 @@ __device__ __forceinline__ int32_t walk_tok(bool in_regs, const int32_t* sen, in
 // of every workgroup trains nothing: the 12 workers of the other three waves post (vector, rows, steps) messages into LDS boxes, the atomics
 // wave turns them into float atomics and never waits for their completion.  A message: LK_MB_HDR floats of header (count, then 16 rows as
 // int bits, then 16 steps) followed by the vector in element order; two boxes per worker.  Box states: 0 = free, 1 = rows of syn1neg, 2 = of syn0,
-// 3 = of syn1 (hierarchical softmax).
+// 3 = of syn1 (hierarchical softmax; k_sgns_train_hsw's copies of the busiest inner nodes are rows behind the table's V).
 #define LK_MB_WORKERS 12
 #define LK_MB_HDR 36
 template <int DCH> struct LkBox { static constexpr int FLOATS = LK_MB_HDR + DCH * 64; };
@@ -516,11 +524,15 @@ template <int DCH, int NBOX = LK_MB_WORKERS * 2>
 __device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* done, int n_workers_here, const TableView& syn0, const TableView& syn1neg, const TableView& syn1,
                                                 float* acc = nullptr, int* acc_cnt = nullptr, int n_acc = 0, int drain = 1) {
     const int wl = threadIdx.x & 63;
+    static_assert(NBOX <= 64, "one flag per lane");
     for (;;) {
         bool any = false;
-        for (int b = 0; b < NBOX; b++) {
-            const int f = __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b]));       // (every lane reads the same word)
-            if (f == 0) continue;
+        // all flags in ONE look (lane b reads flag b; round 4: one LDS read per box and sweep was 56 dependent reads in the seven-wave workgroups, more than the
+        // messages found cost), then the boxes that are full in turn
+        const int my_flag = wl < NBOX ? lk_flag_load(&flags[wl]) : 0;
+        for (unsigned long long full = __ballot(my_flag != 0); full; full &= full - 1ull) {
+            const int b = __builtin_ctzll(full);
+            const int f = __builtin_amdgcn_readlane(my_flag, b);
             any = true;
             const float* box = boxes + (size_t)b * LkBox<DCH>::FLOATS;
             const unsigned have = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(box[0]));
@@ -1401,6 +1413,26 @@ __device__ __forceinline__ void row_add(Row<DCH>& y, const Row<DCH>& x) {
 #pragma unroll
     for (int c = 0; c < DCH; c++) { y.v[c].x += x.v[c].x; y.v[c].y += x.v[c].y; y.v[c].z += x.v[c].z; y.v[c].w += x.v[c].w; }
 }
+// (a node's copies in proportion to its share of the paths: the root HS_REP, a node on half the paths half as many, ... — a reader pays a row read per copy)
+__device__ __forceinline__ int hsw_n_copies(const TrainParams& p, int32_t nd) {
+    int r = 1;
+#pragma unroll
+    for (int k = 1; k < HS_REP; k++) r += nd >= p.hs_rep_thr[k] ? 1 : 0;
+    return r;
+}
+// adds the copies 1 .. n-1 of node nd to its row r (loaded by the caller), four rows in flight at a time (a copy index behind the last reads the last again: not added)
+template <int DCH>
+__device__ __forceinline__ void hsw_add_copies(Row<DCH>& r, int32_t nd, const TableView& syn1, const TrainParams& p, int lane) {
+    const int nc = hsw_n_copies(p, nd);
+    const int32_t j = (int32_t)p.V + nd - p.hs_rep0;
+    for (int c = 1; c < nc; c += 4) {
+        Row<DCH> t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) rowA_load<DCH, 16, false>(t[u], syn1, (min(c + u, nc - 1) - 1) * p.hs_rep_n + j, lane);
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (c + u < nc) row_add(r, t[u]);
+    }
+}
 // NLOCK (flat vocabularies, where the commit locks work — auto_policy 5): the K negatives of a pair are read-modify-written under their rows' commit locks (the
 // protocol of k_sgns_train_locked: try-lock rounds that never wait while holding, 16-byte write-through rows, relaxed commit) instead of going out as float atomics —
 // 2.5 of the 3.6 KB of atomics a pair, which is what the kernel runs against; the centre's gathered update is then flushed under the row's lock as well (by ONE group,
@@ -1430,13 +1462,20 @@ k_sgns_train_hsw(TrainParams p) {
     const int lane = threadIdx.x & 15, grp = (threadIdx.x >> 4) & 3, wl = threadIdx.x & 63;
     const int wk = threadIdx.x >> 4;                       // this group's message boxes (groups 0 .. 4 NW - 1 train, the last wave issues the atomics)
     const int wv = threadIdx.x >> 6;
-    TableView syn0 = make_view(p.syn0, p.V, p.stride), syn1neg = make_view(p.syn1neg, p.V, p.stride), syn1 = make_view(p.syn1, p.V, p.stride);
+    TableView syn0 = make_view(p.syn0, p.V, p.stride), syn1neg = make_view(p.syn1neg, p.V, p.stride), syn1 = make_view(p.syn1, p.V + HS_REP_ROWS, p.stride);
     syn0.valid = syn1neg.valid = syn1.valid = (uint32_t)p.D;
     const int64_t wave = (int64_t)blockIdx.x * NW + wv;    // p.n_workers = waves that train
     if (wv == NW) {
         const int64_t waves_here = min((int64_t)NW, p.n_workers - (int64_t)blockIdx.x * NW);
         lk_atomics_wave<DCH, NBOX>(s_mb, s_mb_flag, &s_mb_done, (int)max(waves_here, (int64_t)0) * 4, syn0, syn1neg, syn1);
     }
+    // The busiest inner nodes (p.hs_rep_n of them, the root first among them) take an update from every centre — or every second, fourth … — and float atomics on
+    // ONE row complete at 78 ns a row (scripts/micro/hot_row_spread.hip: 1.3e7 a second, against 2.2e7 centres a second here).  Parking their updates in LDS
+    // accumulators (above; still what the pair-by-pair kernel does) trades that for staleness, and on a skewed tree the staleness costs quality (the Zipf community
+    // graph's epoch: AUC 0.9541 with a drain every 4 additions, 0.9585 with every addition drained at half the speed).  So these few rows are kept in HS_REP copies for
+    // the launch: a wave adds to ITS copy (wave % copies of the node; copy 0 is the row itself) and reads the sum of all copies — nothing is parked, nobody's update
+    // waits for a drain, and no row takes more than an eighth of all centres' updates.  train_rows zeroes the copies before the launch and folds them into the rows behind it.
+#define HSW_COPY_OF(nd_) (((int)(wave & (HS_REP - 1)) * hsw_n_copies(p, nd_)) >> 3)       /* this wave's copy of the node (0: the row itself); HS_REP = 8 */
     unsigned n_posts = 0;
     const int L = p.L, W = p.W, K = p.K;
     // lane j turns a state into the state j + 1 draws on; (mK, cK): K draws on
@@ -1485,6 +1524,11 @@ k_sgns_train_hsw(TrainParams p) {
                 rowA_load<DCH, 16, false>(S[q], syn1, node[q] >= 0 ? node[q] : p.filler_row, lane);
                 row_zero(dS[q]);
             }
+            // (behind the six row loads, which go out together: the copies of the few busy nodes among them — on a balanced tree the path's first four, one a group)
+            // (a node on a tenth of all paths lies at depth <= 5 of a Huffman tree — its weight is at most 2 / Fib(depth + 2) —: among a group's first two nodes)
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                if (node[q] >= p.hs_rep0) hsw_add_copies<DCH>(S[q], node[q], syn1, p, lane);
             Row<DCH> h, dh;                                               // the positive target syn1neg[word]: a copy per group, its gathered update
             rowA_load<DCH, 16, false>(h, syn1neg, word, lane);
             row_zero(dh);
@@ -1651,7 +1695,10 @@ k_sgns_train_hsw(TrainParams p) {
 #pragma unroll
             for (int q = 0; q < HSW_NQ; q++)
                 if (node[q] >= 0) {
-                    if (node[q] >= p.hs_hot0) hot_addA<DCH>(s_hot, s_hot_cnt, node[q] - p.hs_hot0, p.hs_drain, syn1, node[q], lane, dS[q]);
+                    if (q < 2 && node[q] >= p.hs_rep0) {
+                        const int my_copy = HSW_COPY_OF(node[q]);
+                        lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 3, lane != 0 ? -1 : (my_copy == 0 ? node[q] : (int32_t)p.V + (my_copy - 1) * p.hs_rep_n + (node[q] - p.hs_rep0)), 1.0f, dS[q], lane);
+                    } else if (node[q] >= p.hs_hot0) hot_addA<DCH>(s_hot, s_hot_cnt, node[q] - p.hs_hot0, p.hs_drain, syn1, node[q], lane, dS[q]);
                     else if (node[q] < p.hs_cold) {
                         Row<DCH> r;
                         rowA_load<DCH, 16, false>(r, syn1, node[q], lane);

@@ -9,13 +9,13 @@ import embedding_amd as E
 
 # "zipf": the same graph, but a vertex's flow that LEAVES its community goes to a region drawn with P(rank r) ~ 1/(r+1)
 # (popular regions, as in cfg5) instead of a uniform one -> a skewed vocabulary, where auto selects the mixed policy 7.
-ZIPF = len(sys.argv) > 1 and sys.argv[1] == "zipf"
+ZIPF = "zipf" in sys.argv[1:]          # ("hs zipf": the tree term on the skewed graph)
 # "blocks N": the multi-GPU block schedule with N ranks simulated on this GPU (N models), 10 global batches per epoch,
 # against the one-GPU run of the same epoch.
 BLOCKS = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] == "blocks" else 0
 # "hs": hierarchical softmax + 5 negatives (what DL4J's builder default trains): every inner node under atomics, and with the cold end of
 # the tree updated by plain read-modify-write (the library's rule), one epoch each
-HS = len(sys.argv) > 1 and sys.argv[1] == "hs"
+HS = "hs" in sys.argv[1:]
 
 R, T, L, D, K = 41667, 24, 24, 128, 5
 NV = R * T
