@@ -753,8 +753,8 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
           // busy inner nodes: on a tenth of all paths and more (a suffix; the balanced tree of a flat vocabulary has 15 of them, a skewed one a few more) — at most 64
           const int64_t busy = (int64_t)((double)tot * 0.1);
           m->hs_rep_auto = (int32_t)std::min<int64_t>(64, node_w.end() - std::lower_bound(node_w.begin(), node_w.end(), busy));
-          for (int k = 0; k < 8; k++)      // first node on more than k/8 of all paths (weights ascend with the node number)
-              m->hs_rep_thr8[k] = (int32_t)(std::upper_bound(node_w.begin(), node_w.end(), (int64_t)((double)tot * k / 8.0)) - node_w.begin()); }
+          for (int k = 0; k < 32; k++)     // first node on more than k/32 of all paths (weights ascend with the node number)
+              m->hs_rep_thr32[k] = (int32_t)(std::upper_bound(node_w.begin(), node_w.end(), (int64_t)((double)tot * k / 32.0)) - node_w.begin()); }
         // (behind the table: HS_REP_ROWS spare rows for k_sgns_train_hsw's copies of the busiest inner nodes — zero between launches)
         MC(table_alloc(&m->d_syn1, tab + 64 + (size_t)HS_REP_ROWS * m->stride, device, st, &m->placed_seen[2], &m->placed_best[2], &m->placed_worst[2]));
         MH(hipMemsetAsync(m->d_syn1, 0, (tab + 64 + (size_t)HS_REP_ROWS * m->stride) * sizeof(float), st));
@@ -1092,10 +1092,10 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         if (hot_kb_knob <= 0 && m->hs_rep_auto > 0 && m->V > 1) {
             const int64_t n_rep = std::min<int64_t>(std::min<int64_t>(m->hs_rep_auto, HS_REP_NODES), m->V - 1);
             p.hs_rep_n = (int32_t)n_rep; p.hs_rep0 = (int32_t)(m->V - 1 - n_rep);      // (the copies: rows V .. of syn1, zero between launches: k_hs_rep_fold)
-            // copies per node: ceil(share of the paths x F), F = HS_REP (the root: HS_REP copies; DGE_TUNE_HS_DRAIN = F for comparison: 4 = the root four copies, ...)
+            // copies per node: ceil(share of the paths x F), F = HS_REP (the root: HS_REP = 16 copies, a node on half the paths 8, ...; DGE_TUNE_HS_DRAIN = F for comparison: 4 = the root four copies, ...)
             { const int64_t f_knob = g_dge_tuning[DGE_TUNE_HS_DRAIN];
               const int F = (int)std::min<int64_t>(HS_REP, f_knob >= 1 ? f_knob : (int64_t)HS_REP);
-              for (int k = 1; k < HS_REP; k++) p.hs_rep_thr[k] = k < F ? std::max(m->hs_rep_thr8[std::min(7, k * 8 / F)], p.hs_rep0) : 0x7fffffff;
+              for (int k = 1; k < HS_REP; k++) p.hs_rep_thr[k] = k < F ? std::max(m->hs_rep_thr32[std::min(31, k * 32 / F)], p.hs_rep0) : 0x7fffffff;      // more than k copies: share x F > k
               p.hs_rep_thr[0] = 0; }
             p.hs_n_hot = 0; p.hs_hot0 = (int32_t)std::max<int64_t>(m->V - 1, 0); shmem = 0;
             { const int64_t cold_knob = g_dge_tuning[DGE_TUNE_HS_COLD]; p.hs_cold = (int32_t)std::min<int64_t>(cold_knob >= 0 ? cold_knob : (int64_t)m->hs_cold_auto, p.hs_rep0); }

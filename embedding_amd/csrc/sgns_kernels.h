@@ -10,7 +10,7 @@
 
 #define EXP_TABLE_SIZE 1000
 #define MAX_EXP 6
-#define HS_REP 8             /* most copies an inner node has during a launch of k_sgns_train_hsw (the root's) */
+#define HS_REP 16            /* most copies an inner node has during a launch of k_sgns_train_hsw (the root's) */
 #define HS_REP_NODES 64      /* at most this many inner nodes have copies */
 #define HS_REP_ROWS ((HS_REP - 1) * HS_REP_NODES)      /* spare rows behind syn1 for them */
 #define NEG_BATCH 5
@@ -1474,8 +1474,9 @@ k_sgns_train_hsw(TrainParams p) {
     // accumulators (above; still what the pair-by-pair kernel does) trades that for staleness, and on a skewed tree the staleness costs quality (the Zipf community
     // graph's epoch: AUC 0.9541 with a drain every 4 additions, 0.9585 with every addition drained at half the speed).  So these few rows are kept in HS_REP copies for
     // the launch: a wave adds to ITS copy (wave % copies of the node; copy 0 is the row itself) and reads the sum of all copies — nothing is parked, nobody's update
-    // waits for a drain, and no row takes more than an eighth of all centres' updates.  train_rows zeroes the copies before the launch and folds them into the rows behind it.
-#define HSW_COPY_OF(nd_) (((int)(wave & (HS_REP - 1)) * hsw_n_copies(p, nd_)) >> 3)       /* this wave's copy of the node (0: the row itself); HS_REP = 8 */
+    // waits for a drain, and no row takes more than a sixteenth of all centres' updates (the root's copies against speed, cfg3: 2 1.97e8, 4 2.98e8, 8 3.55e8, 16 3.70e8,
+    // 24 3.61e8, 32 3.55e8 edges/s — fewer serialise, more cost the readers their row reads).  train_rows zeroes the copies before the launch and folds them into the rows behind it.
+#define HSW_COPY_OF(nd_) (((int)(wave & (HS_REP - 1)) * hsw_n_copies(p, nd_)) >> 4)       /* this wave's copy of the node (0: the row itself); HS_REP = 16 */
     unsigned n_posts = 0;
     const int L = p.L, W = p.W, K = p.K;
     // lane j turns a state into the state j + 1 draws on; (mK, cK): K draws on

@@ -47,7 +47,7 @@ struct dge_model {
     double* d_run_base = nullptr; uint32_t* d_run_row = nullptr; uint32_t* d_exc_slot = nullptr; int32_t* d_exc_row = nullptr;
     int32_t n_runs = 0, n_exc = 0;
     int32_t hs_rep_auto = 0;                    // hierarchical softmax: the inner nodes [V-1 - hs_rep_auto, V-1) are each on a tenth of all paths and more (copies in k_sgns_train_hsw)
-    int32_t hs_rep_thr8[8] = {0};               // node >= hs_rep_thr8[k]: on more than k/8 of all paths
+    int32_t hs_rep_thr32[32] = {0};             // node >= hs_rep_thr32[k]: on more than k/32 of all paths
     int32_t hs_cold_auto = 0;                   // hierarchical softmax: inner nodes [0, hs_cold_auto) are each on fewer than 2e-5 of the paths
     float* d_exp = nullptr;
     // per-call work buffers

@@ -348,7 +348,7 @@ enum {
     DGE_TUNE_TABLE_RUNS = 12,     /* the negative-sampling table's run form (dge_model_table_runs): 0 = not built / not used (the lock kernels read the table), N > 0 = built from at most N runs of the vocabulary's tail (tests: the head rows in front stay on the table); default: up to 2 046 runs */
     DGE_TUNE_BLOCK_SYN0_FREE = 13, /* block schedule, mixed lock kernel: 1 = the pair's syn0 row is never locked (agent-scope read, atomics), 0 = it is locked unless it is a head row; default: the library's rule */
     DGE_TUNE_HS_CENTRE = 14,      /* hierarchical softmax under atomics: 0 = pair by pair (k_sgns_train), 1 = a wave per centre wherever it applies (rows of up to 128 floats, walks of up to 64 tokens; k_sgns_train_hsw); 2 = that kernel with the pair's negatives and the centre's gathered syn1neg update under the rows' commit locks instead of atomics, 3 = the same in workgroups of seven training waves (one a compute unit) that share their LDS accumulators; default: a wave per centre from 65 536 vocabulary rows on — form 3 where update_policy 0 would pick the commit locks for the negative-sampling kernels, form 1 elsewhere */
-    DGE_TUNE_HS_HOT_KB = 15,      /* k_sgns_train_hsw: > 0 = keep the inner nodes next to the root in that many KB of LDS accumulators per workgroup (drained every DGE_TUNE_HS_DRAIN additions; round 4's first form: faster by a tenth, staler) instead of the default, the busiest nodes in copies (nothing parked; DGE_TUNE_HS_DRAIN then = the root's number of copies, default 8) */
+    DGE_TUNE_HS_HOT_KB = 15,      /* k_sgns_train_hsw: > 0 = keep the inner nodes next to the root in that many KB of LDS accumulators per workgroup (drained every DGE_TUNE_HS_DRAIN additions; round 4's first form: faster by a tenth, staler) instead of the default, the busiest nodes in copies (nothing parked; DGE_TUNE_HS_DRAIN then = the root's number of copies, default 16) */
     DGE_TUNE_COUNT = 16
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
