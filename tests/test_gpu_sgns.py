@@ -612,10 +612,11 @@ def test_hierarchical_softmax_wave_per_centre_linear_regime(dge, oracle, dim, ne
     init = oracle.train_sgns(ids[:1], NV, dim, window, threads=1, arith=1, use_hs=True, counts=counts, **dict(kw, alpha=0.0, min_alpha=0.0))
     corpus = dge.WalkCorpus.from_host(ids, 0)
     d_counts = torch.from_numpy(counts).to("cuda:0")
-    for centre in (3, 2, 1, 0):
+    # (the wave-per-centre kernel keeps the busiest inner nodes in copies; hs_hot_kb > 0 = its first form, LDS accumulators, kept for comparison)
+    for centre, extra in ((3, {}), (3, {"hs_hot_kb": 15}), (2, {}), (1, {}), (1, {"hs_hot_kb": 30}), (0, {})):
         # (hs_cold = 0: the "cold" class — plain read-modify-write for inner nodes on < 2e-5 of the paths BY THE COUNTS — assumes the corpus follows the
         #  counts; these artificial counts do not, the bushy tail is visited all the time)
-        with dge.tuning(hs_centre=centre, hs_cold=0):
+        with dge.tuning(hs_centre=centre, hs_cold=0, **extra):
             dm = dge.SgnsModel.create(dge.make_config(dim, window, NV, workers=0, use_hs=True, **kw), d_counts, 0)
             dm.train(corpus)
         assert dm.stats()["pairs"] == om.pairs and np.array_equal(dm.vectors()[1], om.vocab_ids)
@@ -625,7 +626,7 @@ def test_hierarchical_softmax_wave_per_centre_linear_regime(dge, oracle, dim, ne
             busy = nb > np.percentile(nb[nb > 0], 20)                               # rows with more than a couple of terms (LUT step noise averages out)
             cos = cosine_rows(da[busy], db[busy])
             # (not 1.0: a row is its initial value plus thousands of additions ~1e4 times smaller — float32 rounds each, in another order here)
-            assert cos.min() > 0.99 and np.median(cos) > 0.9995, (name, centre, float(cos.min()), float(np.median(cos)))
+            assert cos.min() > 0.99 and np.median(cos) > 0.9995, (name, centre, extra, float(cos.min()), float(np.median(cos)))
             assert np.abs(np.linalg.norm(da[busy], axis=1) / nb[busy] - 1).max() < 0.05, (name, centre)
             assert not np.abs(da[nb == 0]).any(), (name, centre)                    # rows the oracle never touched stay untouched
 
