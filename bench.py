@@ -49,7 +49,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch-walks", type=int, default=0, help="walks per step per GPU (default: epoch/10)")
+    ap.add_argument("--batch-walks", type=int, default=0,
+                    help="walks per step per GPU.  Default, one GPU: epoch/10.  Default, N ranks of the block schedule: the GLOBAL batch is epoch/10 whatever N "
+                         "(what embedding_amd.distributed.fit_distributed steps in: the schedule reproduces the one-GPU embedding only in batches of at most a fifth of "
+                         "the epoch, profiles/r04_blocks_quality.txt), i.e. epoch/(10 N) walks per GPU; given explicitly, the global batch is N x this")
+    ap.add_argument("--weak-batch", action="store_true",
+                    help="N ranks: the round-1..4 step, a global batch of N x epoch/10 walks (8 M at N = 8: 0.8 of the epoch in ONE batch — a batch the product does "
+                         "not train with, it costs link-prediction AUC 0.959 -> 0.915; kept to compare per-rank throughput at large batches)")
     ap.add_argument("--workers", type=int, default=0, help="SGNS walk workers (0 = fill the device)")
     ap.add_argument("--multi-gpu", choices=["blocks", "allreduce"], default="blocks",
                     help="N>1: 'blocks' = row-partitioned block schedule, exact (default); 'allreduce' = the earlier walk-shard + delta "
@@ -191,13 +197,15 @@ def main():
     model = E.SgnsModel.create(cfg, counts, local_rank)
     stage("vocabulary, unigram table and weights ready")
     total_words = int(counts.sum().item())
-    B = args.batch_walks or max(1, epoch_walks // 10)
-    B = min(B, shard)
-    delta = None
     NB = args.sim_ranks if (N == 1 and args.sim_ranks > 1) else N          # ranks of the block schedule
     blocks = NB > 1 and args.multi_gpu == "blocks"
+    B = args.batch_walks or max(1, epoch_walks // 10)
+    if blocks and not args.batch_walks and not args.weak_batch:
+        B = max(1, epoch_walks // 10 // NB)                                # the global batch stays epoch/10 (fit_distributed's step): strong scaling
+    B = min(B, shard if not blocks else epoch_walks)
+    delta = None
     if blocks:
-        # weak scaling: the global batch is NB x the single-GPU batch; every rank samples ALL of it from its replica of the
+        # the global batch is NB x the per-rank batch; every rank samples ALL of it from its replica of the
         # graph (walk i is the same walk on any rank) and trains its row blocks of it
         del corpus
         torch.cuda.empty_cache()
@@ -270,8 +278,9 @@ def main():
             for e in range(NB):
                 model.set_partition(NB, 0, e % NB)
                 train_fn()
-                model.export_partition(1, NB, e % NB, part_buf)
-                model.import_partition(1, NB, e % NB, part_buf)
+                ms = model.stream()                          # (pack and unpack stay on the library's stream, as a hand-off's would; no host wait)
+                model.export_partition_async(1, NB, e % NB, part_buf, ms)
+                model.import_partition_async(1, NB, e % NB, part_buf, ms)
             model.set_partition(1)
 
     def step(i):
@@ -312,20 +321,23 @@ def main():
     if rank == 0:
         value = total_pairs / elapsed
         bytes_per_pair = 8 * D * (K + 2)                      # one syn0 row + K+1 syn1neg rows, read+written
-        if args.hs:                                           # + the inner-node rows on the centre's Huffman path (count-weighted mean)
+        hs_path = None
+        if args.hs:
+            # + the inner-node rows on the centre's Huffman path (count-weighted mean length), ONCE PER CENTRE: the path belongs to the centre, all its contexts
+            # meet the same nodes, so what the term must move per pair is path rows / contexts per centre (round 5: until then the rows were charged per pair —
+            # what the pair-by-pair kernel moves, not what the algorithm needs — and the wave-per-centre kernel printed a fraction above 1)
             off, _, _ = model.huffman()
             cnt = model.counts().astype(np.float64)
-            bytes_per_pair += 8 * D * float((np.diff(off) * cnt).sum() / max(cnt.sum(), 1.0))
+            hs_path = float((np.diff(off) * cnt).sum() / max(cnt.sum(), 1.0))
+            ctx_per_centre = st["pairs"] / max(st["words"], 1)
+            bytes_per_pair += 8 * D * hs_path / max(ctx_per_centre, 1.0)
         launches = max(st["launches"], 1)
         ms_per_launch = st["kernel_ms"] / launches
         pairs_per_launch = st["pairs"] / launches
         achieved = pairs_per_launch * bytes_per_pair / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
         sched = model.schedule()
         stamp = E.engine.build_stamp()
-        kernel_name = ("k_sgns_train<HS>" if args.hs else
-                       {5: "k_sgns_train_locked", 6: "k_sgns_train_locked<strict>", 7: "k_sgns_train_locked<head rows by atomics>",
-                        2: "k_sgns_train<atomics>", 1: "k_sgns_train<row rmw>", 0: "k_sgns_train<in-order>",
-                        8: "k_sorted_phase (owner-computes: emit + 2 sorts + 2 phases)"}[sched["update_policy"]])
+        kernel_name = model.kernel()                         # what the library's latest launch ran (include/dge.h: dge_model_kernel)
         out = {
             "metric": "SGNS training edges/sec",
             "value": value,
@@ -335,12 +347,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            # one GPU, and --weak-batch: per-GPU work fixed; N ranks at the default: the GLOBAL batch is fixed at epoch/10 (the batch size that keeps the embedding)
+            "scaling": "strong" if (blocks and not args.batch_walks and not args.weak_batch) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["name"], "vertices": NV, "edges": int(n_edges), "timeslices": T, "dim": D,
                        "negatives": K, "walk_len": L, "window": L, "walks_per_step_per_gpu": B,
+                       "global_batch_walks": BG if blocks else B * N, "batch_fraction_of_epoch": round((BG if blocks else B * N) / epoch_walks, 4),
                        "pairs_per_step_per_gpu": st["pairs"] / args.steps, "vocabulary": int((counts >= 2).sum().item()),
                        "sgns_workers": args.workers, "table_placement": model.table_placement(), "table_runs": model.table_runs(), "placement_search": placement, "placement_trial_ms": trial_ms and [round(x, 1) for x in trial_ms],
                        "lr_horizon_epochs": 1000, "ring_transport": ring and ring.mode, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, syn1neg partitions passed round a ring" % N if blocks and N > 1
@@ -348,18 +362,19 @@ def main():
                                        else "walk-shard x%d, RCCL all-reduce of deltas per step (comparison mode)" % N if N > 1 else "1 GPU"),
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None if (args.dim or args.negative >= 0 or NB > 1) else measured_traffic(args.workload, "hs" if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch, stamp),
+                         "traffic": None if (args.dim or args.negative >= 0 or NB > 1) else measured_traffic(args.workload, ("hs_centre" if "hsw" in kernel_name else "hs_pairs") if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch, stamp),
                          "traffic_source": "profiles/traffic.json: bytes per pair from the committed rocprofv3 PMC passes of this workload x the pairs of this run (not counters of this run); null unless those passes were collected with the kernels of the loaded library (build stamp %s)" % json.dumps(stamp),
                          "kernel": kernel_name, "schedule": sched,
                          "ms_per_launch": ms_per_launch,
                          "bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
+                         "hs_path_rows_per_centre": hs_path,
                          "walk_kernel_ms_per_launch": st["walk_kernel_ms"] / launches,
                          "walk_steps_per_s": (B * L) / (st["walk_kernel_ms"] / launches * 1e-3) if st["walk_kernel_ms"] > 0 else None,
                          "walk_bytes_per_step": 36, "box_copy_GBps": copy_rate,
                          "row_read_GBps": row_rates and round(row_rates[0], 1), "row_rewrite_GBps": row_rates and round(row_rates[1], 1),
                          # what the lock kernel actually runs against (profiles/r03_shape_sweep.txt): requests at the L2's memory side — reads leave as 128 bytes,
                          # writes as 64 — at ~8.5e10/s in every shape measured; from the committed PMC passes like `traffic`, not from counters of this run
-                         "fabric_requests_per_s": None if (args.dim or args.negative >= 0 or NB > 1) else measured_requests(args.workload, "hs" if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch, ms_per_launch, stamp)},
+                         "fabric_requests_per_s": None if (args.dim or args.negative >= 0 or NB > 1) else measured_requests(args.workload, ("hs_centre" if "hsw" in kernel_name else "hs_pairs") if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch, ms_per_launch, stamp)},
         }
         if "expect_policy" in wl and not (args.policy or args.workers or args.hs or NB > 1) and sched["update_policy"] != wl["expect_policy"]:
             print("warning: workload %s resolved to policy %d, the committed traffic profile is for policy %d" % (args.workload, sched["update_policy"], wl["expect_policy"]), file=sys.stderr)

@@ -4,4 +4,4 @@ The package is a thin host layer over libdge.so (hand-written HIP for gfx950, C 
 Importing it loads the library; there is no CPU fallback.
 """
 from ._native import DgeError, TrainConfig, TrainStats, lib, LIB_PATH  # noqa: F401
-from .engine import DeviceGraph, SgnsModel, WalkCorpus, deepwalk_config, make_config, tuning  # noqa: F401
+from .engine import DeviceGraph, SgnsModel, WalkCorpus, deepwalk_config, host_sync_count, make_config, tuning  # noqa: F401

@@ -83,12 +83,17 @@ SIGNATURES = {
     "dge_model_placement_search": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "dge_model_reset_stats": (_int, [_vp]),
     "dge_model_schedule": (_int, [_vp, _P(_i32), _P(_i64), _P(_i32)]),
+    "dge_model_kernel": (_int, [_vp, C.c_char_p, _i32]),
     "dge_write_vec": (_int, [_vp, _vp, C.c_char_p, _int]),
     "dge_model_free": (None, [_vp]),
     "dge_model_set_partition": (_int, [_vp, _i32, _i32, _i32]),
     "dge_model_partition_floats": (_int, [_vp, _i32, _P(_i64)]),
     "dge_model_export_partition": (_int, [_vp, _int, _i32, _i32, _vp]),
     "dge_model_import_partition": (_int, [_vp, _int, _i32, _i32, _vp]),
+    "dge_model_export_partition_async": (_int, [_vp, _int, _i32, _i32, _vp, _vp]),
+    "dge_model_import_partition_async": (_int, [_vp, _int, _i32, _i32, _vp, _vp]),
+    "dge_model_stream": (_int, [_vp, _P(_vp)]),
+    "dge_host_sync_count": (_int, [_P(_i64)]),
     "dge_model_sync_size": (_int, [_vp, _P(_i64)]),
     "dge_model_snapshot": (_int, [_vp]),
     "dge_model_export_delta": (_int, [_vp, _vp]),

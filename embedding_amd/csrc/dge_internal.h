@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,18 @@ void dge_set_error(const char* fmt, ...);
             return DGE_ERR_DEVICE;                                                            \
         }                                                                                     \
     } while (0)
+
+// Host synchronisations the library performs (blocking stream / device / event waits and blocking copies), counted process-wide: a multi-GPU episode must not
+// contain any in steady state (tests count them: dge_host_sync_count, include/dge.h).  Every call site below goes through these wrappers.
+extern std::atomic<int64_t> g_dge_host_syncs;
+static inline hipError_t dge_counted_stream_sync(hipStream_t s) { g_dge_host_syncs.fetch_add(1, std::memory_order_relaxed); return hipStreamSynchronize(s); }
+static inline hipError_t dge_counted_device_sync() { g_dge_host_syncs.fetch_add(1, std::memory_order_relaxed); return hipDeviceSynchronize(); }
+static inline hipError_t dge_counted_event_sync(hipEvent_t e) { g_dge_host_syncs.fetch_add(1, std::memory_order_relaxed); return hipEventSynchronize(e); }
+static inline hipError_t dge_counted_memcpy(void* d, const void* s, size_t n, hipMemcpyKind k) { g_dge_host_syncs.fetch_add(1, std::memory_order_relaxed); return hipMemcpy(d, s, n, k); }
+#define hipStreamSynchronize(s) dge_counted_stream_sync(s)
+#define hipDeviceSynchronize() dge_counted_device_sync()
+#define hipEventSynchronize(e) dge_counted_event_sync(e)
+#define hipMemcpy(d, s, n, k) dge_counted_memcpy((d), (s), (n), (k))
 
 int dge_require_device(int device);   // DGE_OK when `device` is a usable gfx950 device, sets it current
 

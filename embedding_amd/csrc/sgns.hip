@@ -35,7 +35,14 @@
 #include "fmt_g9.h"
 
 
-std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+std::atomic<int64_t> g_dge_tuning[DGE_TUNE_COUNT];
+namespace { struct TuningInit { TuningInit() { for (auto& k : g_dge_tuning) k.store(-1); } } g_tuning_init; }
+std::atomic<int64_t> g_dge_host_syncs{0};
+extern "C" int dge_host_sync_count(int64_t* n) {
+    if (!n) DGE_FAIL(DGE_ERR_ARG, "dge_host_sync_count: null output");
+    *n = g_dge_host_syncs.load(std::memory_order_relaxed);
+    return DGE_OK;
+}
 extern "C" int dge_set_tuning(int32_t knob, int64_t value) {
     if (knob < 0 || knob >= DGE_TUNE_COUNT) DGE_FAIL(DGE_ERR_ARG, "dge_set_tuning: unknown knob %d", knob);
     g_dge_tuning[knob] = value < 0 ? -1 : value;
@@ -520,6 +527,7 @@ static void model_release(dge_model* m) {
     dge_dev_free(m->d_counts); dge_dev_free(m->d_remap); dge_dev_free(m->d_exp);
     dge_dev_free(m->d_sen); dge_dev_free(m->d_len); dge_dev_free(m->d_wb); dge_dev_free(m->d_scan_tmp); dge_dev_free(m->d_counters);
     dge_sorted_release(m);
+    if (m->ev_peer) (void)hipEventDestroy(m->ev_peer);
     for (auto& e : m->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
 }
@@ -765,8 +773,8 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         if (V) MH(hipMemcpyAsync(m->d_hs_codes, m->h_hs_codes.data(), (size_t)V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     }
     MH(hipMemsetAsync(m->d_locks, 0, 2 * ((size_t)V + 1) * sizeof(int), st));
-    MC(dge_dev_alloc(&m->d_counters, 3));       // pairs, words, the lock kernels' walk counter
-    MH(hipMemsetAsync(m->d_counters, 0, 3 * sizeof(unsigned long long), st));
+    MC(dge_dev_alloc(&m->d_counters, 4));       // pairs, words, the lock kernels' walk counter, the lock kernels' watchdog flag
+    MH(hipMemsetAsync(m->d_counters, 0, 4 * sizeof(unsigned long long), st));
     MH(hipStreamSynchronize(st));
     MH(hipGetLastError());
 #undef MC
@@ -920,7 +928,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     p.alpha0 = m->cfg.alpha; p.min_alpha = m->cfg.min_alpha;
     p.D = m->D;
     p.counters = m->d_counters;
-    p.next_walk = nullptr;
+    p.next_walk = nullptr; p.wd_ticks = 0;
     p.locks = m->d_locks;
     p.syn1 = m->d_syn1; p.hs_off = m->d_hs_off; p.hs_points = m->d_hs_points; p.hs_codes = m->d_hs_codes;
     p.hs_hot0 = 0x7fffffff; p.hs_n_hot = 0; p.hs_drain = 1; p.hot_rows = 0; p.hs_cold = 0; p.hs_wave = 0;
@@ -944,14 +952,27 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         if (part) sorted_auto = m->part_n >= 2 && dge_sorted_batch_items(m, m->part_n) > 0;         // (per rank on cfg3, owner-computes vs locks, round 3 with the items made once per batch: N = 2 7.5e8 vs 7.2e8, N = 4 7.8e8 vs 7.4e8, N = 8 7.5e8 vs 4.8e8)
         else sorted_auto = !locks_work && dge_sorted_batch_items(m, 1) > 0;                         // (what used to fall back to atomics)
     }
+    const bool allow_unsafe = g_dge_tuning[DGE_TUNE_ALLOW_UNSAFE] > 0;
+    const double launch_pairs = (double)n_rows * dge_expected_pairs_per_walk(L, m->cfg.window) / ((double)m->part_n * (double)m->part_n);      // (full-length walks: an upper estimate)
     if ((m->cfg.update_policy == 8 && m->cfg.workers != 1) || sorted_auto) {
         // owner-computes schedule (sgns_sorted.hip): items sorted by row, no locks, no atomics, deterministic
         if (hs) DGE_FAIL(DGE_ERR_ARG, "update_policy 8 does not carry the hierarchical-softmax term");
+        // FORCED on a vocabulary the rule would not pick it for (dge_sorted_batch_items == 0): a small vocabulary is merely slow, but on a skewed one the busiest row takes
+        // thousands of terms of one synchronous mini-batch with no feedback between them and the tables go to NaN within an epoch (profiles/r02_quality_zipf_sorted_diverges.txt;
+        // rank^-1 over 50 000 words: 9 % of a million-item mini-batch on one row).  Refused instead (round 5; a mini-batch size set by hand — DGE_TUNE_SORTED_WALKS — is the caller's business).
+        if (!sorted_auto && !allow_unsafe && g_dge_tuning[DGE_TUNE_SORTED_WALKS] <= 0 && dge_sorted_batch_items(m, m->part_n) == 0) {
+            const double hottest = std::min(1.0, m->row_share_max * (double)std::max(m->part_n, 1));
+            const double mb_items = std::min((double)(1 << 20), launch_pairs * (double)(m->cfg.negative + 1));
+            if (hottest * mb_items > 8192.0)
+                DGE_FAIL(DGE_ERR_ARG, "update_policy 8 (owner-computes) on this vocabulary: its busiest row holds %.2g of the terms, ~%.0f of one synchronous mini-batch "
+                         "with no feedback between them (the schedule keeps that below 2048; beyond, the tables diverge): use update_policy 0 (auto), 2 or 7", hottest, hottest * mb_items);
+        }
         EventPair ev;
         if ((rc = timing_begin(m, ev, 0))) return rc;
         if ((rc = timing_end(m, ev, dge_sorted_train(m, p)))) return rc;
         m->launches++;
         m->last_policy = 8; m->last_workers = 0; m->last_hot_rows = 0;
+        m->last_kernel = part ? "k_sorted_phase (owner-computes, one block of the multi-GPU schedule: k_block_emit + 2 item sorts + 2 phases)" : "k_sorted_phase (owner-computes: k_sorted_emit + 2 item sorts + 2 phases)";
         return DGE_OK;
     }
     int64_t workers;
@@ -984,6 +1005,19 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // In between (a skewed head over a long tail — cfg5, and what real trip data looks like) the head rows alone are
         // taken out of the lock protocol: policy 7.  (auto_policy above)
         pol = workers == 1 ? 100 : auto_policy(m, hs);
+    }
+    // FORCED commit locks (5 / 6) on a vocabulary with a busy row: a pair holds its context row's lock for its whole duration, so the pairs of row i run one behind
+    // the other — p_i x pairs of them while the launch as a whole should last pairs / W pair-times — and the waiting workers keep hammering that lock word: measured
+    // (profiles/r04_policy_sweep.txt) 60x slower at W x p = 6 (rank^-0.5 over 1e6 rows), "minutes" on rank^-1.  Auto moves such rows to the atomics side (7); a forced 5 / 6 is
+    // refused beyond W x p = 2 (the community graph's W x p = 1.2 runs 1.8x slower: still a choice).  Same rule inside a block, whose rows take n times their share.
+    if ((m->cfg.update_policy == 5 || m->cfg.update_policy == 6) && workers > 1 && !allow_unsafe) {
+        const double chain = (double)workers * m->row_share_max * (double)std::max(m->part_n, 1);
+        // (and only where that chain is long: a contended hand-over of a row lock takes ~100 us — rank^-0.5 over 1e6 rows: 38 000 pairs of the busiest row in 5 s —, so a
+        //  launch whose busiest row has fewer than 50 000 pairs is merely slow for seconds: the edge-case tests on 1- and 3-row vocabularies)
+        if (chain > 2.0 && m->row_share_max * (double)std::max(m->part_n, 1) * launch_pairs > 5e4)
+            DGE_FAIL(DGE_ERR_ARG, "update_policy %d (commit locks on every row) on this vocabulary: its busiest row holds %.2g of the tokens, %lld workers x that share = %.1f pairs "
+                     "queue behind ONE row lock at any time and the launch would be that row's chain (bound 2): use update_policy 0 (auto) or 7 (the head by atomics)",
+                     m->cfg.update_policy, m->row_share_max, (long long)workers, chain);
     }
     if (pol == 7) {
         const double fail_all = (double)((int64_t)m->n_cus * 3 * 16) * 5.0 * m->neg_collision;
@@ -1092,17 +1126,17 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         if (hot_kb_knob <= 0 && m->hs_rep_auto > 0 && m->V > 1) {
             const int64_t n_rep = std::min<int64_t>(std::min<int64_t>(m->hs_rep_auto, HS_REP_NODES), m->V - 1);
             p.hs_rep_n = (int32_t)n_rep; p.hs_rep0 = (int32_t)(m->V - 1 - n_rep);      // (the copies: rows V .. of syn1, zero between launches: k_hs_rep_fold)
-            // copies per node: ceil(share of the paths x F), F = HS_REP (the root: HS_REP = 16 copies, a node on half the paths 8, ...; DGE_TUNE_HS_DRAIN = F for comparison: 4 = the root four copies, ...)
-            { const int64_t f_knob = g_dge_tuning[DGE_TUNE_HS_DRAIN];
+            // copies per node: ceil(share of the paths x F), F = HS_REP (the root: HS_REP = 16 copies, a node on half the paths 8, ...; DGE_TUNE_HS_COPIES = F for comparison: 4 = the root four copies, ...)
+            { const int64_t f_knob = g_dge_tuning[DGE_TUNE_HS_COPIES];
               const int F = (int)std::min<int64_t>(HS_REP, f_knob >= 1 ? f_knob : (int64_t)HS_REP);
               for (int k = 1; k < HS_REP; k++) p.hs_rep_thr[k] = k < F ? std::max(m->hs_rep_thr32[std::min(31, k * 32 / F)], p.hs_rep0) : 0x7fffffff;      // more than k copies: share x F > k
               p.hs_rep_thr[0] = 0; }
             p.hs_n_hot = 0; p.hs_hot0 = (int32_t)std::max<int64_t>(m->V - 1, 0); shmem = 0;
             { const int64_t cold_knob = g_dge_tuning[DGE_TUNE_HS_COLD]; p.hs_cold = (int32_t)std::min<int64_t>(cold_knob >= 0 ? cold_knob : (int64_t)m->hs_cold_auto, p.hs_rep0); }
-        } else if (nw == 7) {      // one workgroup a compute unit
+        } else {                   // LDS accumulators (DGE_TUNE_HS_HOT_KB > 0; or a tree without a busy node): seven waves, one workgroup a compute unit — up to 100 KB; three waves, two workgroups — up to 30 KB each
             const int64_t row_b = (int64_t)m->stride * 4 + 4;
             const int64_t hot_kb = g_dge_tuning[DGE_TUNE_HS_HOT_KB];
-            p.hs_n_hot = (int32_t)std::min<int64_t>(std::max<int64_t>(m->V - 1, 0), (hot_kb >= 0 ? std::min<int64_t>(hot_kb, 100) * 1024 : 15360) / row_b);
+            p.hs_n_hot = (int32_t)std::min<int64_t>(std::max<int64_t>(m->V - 1, 0), (hot_kb > 0 ? std::min<int64_t>(hot_kb, nw == 7 ? 100 : 30) * 1024 : (nw == 7 ? 15360 : 30720)) / row_b);
             p.hs_hot0 = (int32_t)(std::max<int64_t>(m->V - 1, 0) - p.hs_n_hot);
             { const int64_t cold_knob = g_dge_tuning[DGE_TUNE_HS_COLD]; p.hs_cold = (int32_t)std::min<int64_t>(cold_knob >= 0 ? cold_knob : (int64_t)m->hs_cold_auto, p.hs_hot0); }
             shmem = (size_t)p.hs_n_hot * (size_t)row_b;
@@ -1138,6 +1172,20 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     // requests, and the 11 dependent LDS reads of the table's run form are slower than a table look-up that hits the caches (15.4-15.9 s against 12.8 s
     // on the community graph of scripts/quality_scale.py): there the table stays.
     if (m->hot_rows_serial > 0 && workers > 1) p.n_runs = 0;
+    // The lock kernels' watchdog: a worker that is still waiting for a row lock when the launch has run 100x longer than its bytes take at the roofline (+ 5 s) gives up,
+    // counts itself in counters[3] and leaves; dge_model_stats then reports DGE_ERR_STATE.  Checked on the waiting paths only (100 MHz s_memrealtime ticks).
+    {
+        const double bytes = launch_pairs * 8.0 * (double)m->stride * (double)(m->cfg.negative + 2);
+        double budget_s = 5.0 + 100.0 * bytes / 8e12;
+        if (g_dge_tuning[DGE_TUNE_WATCHDOG_MS] > 0) budget_s = (double)g_dge_tuning[DGE_TUNE_WATCHDOG_MS] * 1e-3;
+        // only where the commit locks on every row were FORCED (update_policy 5 / 6): what auto picks them for cannot make them wait, and the watchdog is its own kernel
+        // instantiation so that the headline launch does not pay for it (sgns_kernels.h: WDOG)
+        const bool forced_locks = m->cfg.update_policy == 5 || m->cfg.update_policy == 6;
+        p.wd_ticks = (!forced_locks || g_dge_tuning[DGE_TUNE_WATCHDOG_MS] == 0) ? 0ull : (uint64_t)(budget_s * 1e8);
+    }
+    // k_sgns_train_hsw's copies of the busiest inner nodes must be zero when the launch starts.  k_hs_rep_fold leaves them so behind every launch; an abandoned launch
+    // (an error between the two) would not — so they are cleared here as well (hs_rep_n x 15 rows, < 1 MB)
+    if (p.hs_rep_n > 0) DGE_HIP(hipMemsetAsync(m->d_syn1 + (size_t)m->V * m->stride, 0, (size_t)(HS_REP - 1) * (size_t)p.hs_rep_n * (size_t)m->stride * sizeof(float), st));
     EventPair ev;
     if ((rc = timing_begin(m, ev, 0))) return rc;
     switch (m->stride / 64) {
@@ -1152,6 +1200,17 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         hipLaunchKernelGGL(k_hs_rep_fold, dim3((unsigned)p.hs_rep_n), dim3(128), 0, st, m->d_syn1 + (size_t)p.hs_rep0 * m->stride, m->d_syn1 + (size_t)m->V * m->stride, p.hs_rep_n, m->stride);
     if ((rc = timing_end(m, ev, DGE_OK))) return rc;
     m->launches++;
+    {   // which trainer kernel ran (dge_model_kernel): the bench line names it from here, not from the policy number
+        const int base = pol >= 30 ? pol - 30 : (pol >= 20 ? pol - 20 : (pol >= 10 ? pol - 10 : pol));
+        const bool blk = pol >= 20;
+        std::string k;
+        if (pol == 13) k = "k_sgns_train_hsw<atomics, 3 waves> (hierarchical softmax, a wave per centre)";
+        else if (pol == 14) k = "k_sgns_train_hsw<negatives under commit locks, 3 waves> (hierarchical softmax, a wave per centre)";
+        else if (pol == 15) k = "k_sgns_train_hsw<negatives under commit locks, 7 waves> (hierarchical softmax, a wave per centre)";
+        else if (base == 5 || base == 6 || base == 7) k = std::string("k_sgns_train_locked<") + (base == 6 ? "strict" : "relaxed") + (base == 7 ? ", head rows by atomics" : "") + (blk ? ", one block" : "") + ">";
+        else k = std::string("k_sgns_train<") + (base == 2 ? "atomics" : (base == 1 ? "row rmw" : "in-order")) + (hs ? ", hierarchical softmax pair by pair" : "") + (blk ? ", one block" : "") + ">";
+        m->last_kernel = k;
+    }
     m->last_policy = pol >= 30 ? pol - 30 : (pol >= 20 ? pol - 20 : (pol == 13 ? 2 : (pol == 14 || pol == 15 ? 5 : (pol >= 10 ? pol - 10 : pol)))); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
     DGE_HIP(hipGetLastError());
     return DGE_OK;
@@ -1317,10 +1376,16 @@ extern "C" int dge_model_stats(const dge_model* mc, dge_train_stats* out) {
     if (!m || !out) DGE_FAIL(DGE_ERR_ARG, "dge_model_stats: null argument");
     int rc = drain_events(m);
     if (rc) return rc;
-    unsigned long long c[2] = {0, 0};
+    unsigned long long c[4] = {0, 0, 0, 0};
     DGE_HIP(hipMemcpy(c, m->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     out->pairs = (int64_t)c[0]; out->words = (int64_t)c[1];
     out->kernel_ms = m->kernel_ms; out->walk_kernel_ms = m->walk_ms; out->launches = m->launches;
+    if (c[3]) {     // a lock kernel's watchdog ended a launch (train_rows: wd_ticks): reported once, here — the first call that looks at the device after the launch
+        DGE_HIP(hipMemsetAsync(m->d_counters + 3, 0, sizeof(unsigned long long), m->stream));
+        DGE_HIP(hipStreamSynchronize(m->stream));
+        DGE_FAIL(DGE_ERR_STATE, "a training launch was ended by its watchdog: %llu workers waited for row locks beyond the launch's time budget and left their walks untrained "
+                 "(update_policy %d on this vocabulary: use 0 (auto) or 7)", c[3], m->cfg.update_policy);
+    }
     return DGE_OK;
 }
 
@@ -1555,6 +1620,13 @@ extern "C" int dge_model_schedule(const dge_model* m, int32_t* update_policy, in
     return DGE_OK;
 }
 
+extern "C" int dge_model_kernel(const dge_model* m, char* buf, int32_t cap) {
+    if (!m || !buf || cap <= 0) DGE_FAIL(DGE_ERR_ARG, "dge_model_kernel: bad argument");
+    if (m->last_policy < 0) DGE_FAIL(DGE_ERR_STATE, "dge_model_kernel: nothing has been trained yet");
+    snprintf(buf, (size_t)cap, "%s", m->last_kernel.c_str());
+    return DGE_OK;
+}
+
 extern "C" int dge_model_reset_stats(dge_model* m) {
     if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_reset_stats: null model");
     int rc = drain_events(m);
@@ -1688,11 +1760,21 @@ extern "C" int dge_model_partition_floats(const dge_model* m, int32_t n_parts, i
     return DGE_OK;
 }
 
-static int partition_copy(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf, bool pack) {
+// `peer`: the caller's stream the buffer is produced / consumed on.  DGE_STREAM_BLOCKING (the synchronous entry points): a reader of a caller's buffer first waits for
+// the whole device, a writer returns after the model's stream has drained.  Otherwise the copy is STREAM-ORDERED and the host never waits: an import makes the
+// model's stream wait for what `peer` holds at the time of the call (an event), an export makes `peer` wait for the pack kernel.
+#define DGE_STREAM_BLOCKING ((hipStream_t)(intptr_t)-1)
+static int partition_copy(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf, bool pack, hipStream_t peer) {
     if (!m || !d_buf || n_parts <= 0 || part < 0 || part >= n_parts || table < 0 || table > 2) DGE_FAIL(DGE_ERR_ARG, "dge_model_%s_partition: bad argument", pack ? "export" : "import");
     if (table == 2 && !m->d_syn1) DGE_FAIL(DGE_ERR_STATE, "dge_model_%s_partition: table 2 (syn1) exists with use_hs only", pack ? "export" : "import");
     DGE_HIP(hipSetDevice(m->device));
-    if (!pack) DGE_HIP(hipDeviceSynchronize());          // d_buf comes from the caller's collective, on the caller's stream
+    const bool blocking = peer == DGE_STREAM_BLOCKING;
+    const bool handshake = !blocking && peer != m->stream;
+    if (handshake && !m->ev_peer) DGE_HIP(hipEventCreateWithFlags(&m->ev_peer, hipEventDisableTiming));
+    if (!pack) {
+        if (blocking) DGE_HIP(hipDeviceSynchronize());          // d_buf comes from the caller's collective, on the caller's stream
+        else if (handshake) { DGE_HIP(hipEventRecord(m->ev_peer, peer)); DGE_HIP(hipStreamWaitEvent(m->stream, m->ev_peer, 0)); }
+    }
     float* tab = table == 0 ? m->d_syn0 : (table == 1 ? m->d_syn1neg : m->d_syn1);
     const int64_t rows = (m->V + n_parts - 1) / n_parts;
     if (rows > 0) {
@@ -1700,11 +1782,23 @@ static int partition_copy(dge_model* m, int table, int32_t n_parts, int32_t part
         else hipLaunchKernelGGL(k_partition_unpack, dim3(2048), dim3(256), 0, m->stream, tab, d_buf, m->V, m->stride, n_parts, part, rows);
     }
     DGE_HIP(hipGetLastError());
-    DGE_HIP(hipStreamSynchronize(m->stream));
+    if (blocking) DGE_HIP(hipStreamSynchronize(m->stream));
+    else if (handshake && pack) { DGE_HIP(hipEventRecord(m->ev_peer, m->stream)); DGE_HIP(hipStreamWaitEvent(peer, m->ev_peer, 0)); }
     return DGE_OK;
 }
-extern "C" int dge_model_export_partition(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf) { return partition_copy(m, table, n_parts, part, d_buf, true); }
-extern "C" int dge_model_import_partition(dge_model* m, int table, int32_t n_parts, int32_t part, const float* d_buf) { return partition_copy(m, table, n_parts, part, const_cast<float*>(d_buf), false); }
+extern "C" int dge_model_export_partition(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf) { return partition_copy(m, table, n_parts, part, d_buf, true, DGE_STREAM_BLOCKING); }
+extern "C" int dge_model_import_partition(dge_model* m, int table, int32_t n_parts, int32_t part, const float* d_buf) { return partition_copy(m, table, n_parts, part, const_cast<float*>(d_buf), false, DGE_STREAM_BLOCKING); }
+extern "C" int dge_model_export_partition_async(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf, void* consumer_stream) {
+    return partition_copy(m, table, n_parts, part, d_buf, true, (hipStream_t)consumer_stream);
+}
+extern "C" int dge_model_import_partition_async(dge_model* m, int table, int32_t n_parts, int32_t part, const float* d_buf, void* producer_stream) {
+    return partition_copy(m, table, n_parts, part, const_cast<float*>(d_buf), false, (hipStream_t)producer_stream);
+}
+extern "C" int dge_model_stream(const dge_model* m, void** hip_stream) {
+    if (!m || !hip_stream) DGE_FAIL(DGE_ERR_ARG, "dge_model_stream: null argument");
+    *hip_stream = (void*)m->stream;
+    return DGE_OK;
+}
 
 // ------------------------------------------------------------------------------------------ multi-GPU exchange
 extern "C" int dge_model_sync_size(const dge_model* m, int64_t* n_floats) {
@@ -1881,17 +1975,17 @@ extern "C" int dge_model_ring_pass(dge_model* m, dge_comm* c, int32_t episode) {
     const int n_tab = m->d_syn1 ? 2 : 1;                   // with the hierarchical softmax the syn1 partition of the same number travels along
     if ((rc = comm_buffers(m, c, 2 * pf * n_tab))) return rc;
     float* mine = c->d_buf; float* next = c->d_buf + pf * n_tab;
+    // everything below is enqueued on the model's stream — pack, ncclSend / ncclRecv, unpack — and the host never waits: the next episode's launches queue up behind
     for (int t = 0; t < n_tab; t++)
-        if ((rc = dge_model_export_partition(m, 1 + t, c->nranks, (c->rank + episode) % c->nranks, mine + t * pf))) return rc;
+        if ((rc = partition_copy(m, 1 + t, c->nranks, (c->rank + episode) % c->nranks, mine + t * pf, true, m->stream))) return rc;
     const int dst = (c->rank + c->nranks - 1) % c->nranks, src = (c->rank + 1) % c->nranks;
     int n = g_rccl.GroupStart();
     if (!n) n = g_rccl.Send(mine, (size_t)(pf * n_tab), ncclFloat32, dst, c->nccl, m->stream);
     if (!n) n = g_rccl.Recv(next, (size_t)(pf * n_tab), ncclFloat32, src, c->nccl, m->stream);
     const int n2 = g_rccl.GroupEnd();
     if (n || n2) return rccl_fail(n ? n : n2, "ncclSend/ncclRecv");
-    DGE_HIP(hipStreamSynchronize(m->stream));
     for (int t = 0; t < n_tab; t++)
-        if ((rc = dge_model_import_partition(m, 1 + t, c->nranks, (c->rank + 1 + episode) % c->nranks, next + t * pf))) return rc;
+        if ((rc = partition_copy(m, 1 + t, c->nranks, (c->rank + 1 + episode) % c->nranks, next + t * pf, false, m->stream))) return rc;
     return DGE_OK;
 }
 
@@ -1904,11 +1998,11 @@ extern "C" int dge_model_gather_table(dge_model* m, dge_comm* c, int table) {
     if (rc) return rc;
     if ((rc = comm_buffers(m, c, pf * ((int64_t)c->nranks + 1)))) return rc;
     float* mine = c->d_buf; float* all = c->d_buf + pf;
-    if ((rc = dge_model_export_partition(m, table, c->nranks, c->rank, mine))) return rc;
+    if ((rc = partition_copy(m, table, c->nranks, c->rank, mine, true, m->stream))) return rc;
     int n = g_rccl.AllGather(mine, all, (size_t)pf, ncclFloat32, c->nccl, m->stream);
     if (n) return rccl_fail(n, "ncclAllGather");
-    DGE_HIP(hipStreamSynchronize(m->stream));
     for (int r = 0; r < c->nranks; r++)
-        if (r != c->rank && (rc = dge_model_import_partition(m, table, c->nranks, r, all + (int64_t)r * pf))) return rc;
+        if (r != c->rank && (rc = partition_copy(m, table, c->nranks, r, all + (int64_t)r * pf, false, m->stream))) return rc;
+    DGE_HIP(hipStreamSynchronize(m->stream));              // (end of training: the caller reads the tables next)
     return DGE_OK;
 }

@@ -70,7 +70,13 @@ struct TrainParams {
     int32_t filler_row;       // a row index whose offset is outside every table descriptor (see row_load): loads of it cost no traffic
     int32_t big_seg_shift;    // BIG: 0, or (tests) a smaller segment size than the 4 GiB window allows
     int32_t syn0_free;        // HOTMIX kernels: the pair's syn0 row is never locked either (read agent-scope, updated with atomics)
+    // The lock kernels' watchdog (round 5): a worker that is still WAITING for a row lock wd_ticks (100 MHz s_memrealtime ticks) after its wave started gives up — it
+    // releases what it holds, counts itself in counters[3] and leaves its walks untrained; dge_model_stats reports the launch as failed.  Looked at on the waiting
+    // paths only (a busy pair row, a round that left rows unwon, a blocking flush): the pair that wins its locks never reads the clock.  0 = off.
+    uint64_t wd_ticks;
 };
+// (the deadline lives in LDS, written once per workgroup: the watchdog costs the lock kernels no register)
+__device__ __forceinline__ bool lk_timed_out(const unsigned long long* s_deadline) { return (unsigned long long)wall_clock64() > *s_deadline; }
 
 // PART: which of a walk's (<= 64, register-resident) tokens lie in partition `part`: bit j of the result = token j.
 // Lane j of the group holds tokens j, j+16, j+32, j+48; a ballot collects 16 of them at a time.
@@ -986,8 +992,8 @@ __device__ __forceinline__ void ldsA_atomic_add(const TableView& t, int32_t row,
 }
 
 template <int DCH, bool STRICT, bool BIG, bool HOTMIX = false>
-__device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* locks, int32_t row, const float* d, int lane, int32_t hot_rows = 0) {
-    if (HOTMIX && row < hot_rows) { ldsA_atomic_add<DCH>(syn1neg, row, lane, d - lane); return; }
+__device__ __forceinline__ bool flushA_blocking(const TableView& syn1neg, int* locks, int32_t row, const float* d, int lane, int32_t hot_rows = 0, const unsigned long long* s_deadline = nullptr) {
+    if (HOTMIX && row < hot_rows) { ldsA_atomic_add<DCH>(syn1neg, row, lane, d - lane); return true; }
     for (;;) {
         const bool won = lane == 0 ? row_trylock(locks, row) : false;
         const bool got = __shfl((int)won, 0, 16) != 0;
@@ -1001,8 +1007,9 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
             rowA_store<DCH, 16, BIG>(cur, syn1neg, row, lane);
             row_commit_wait(STRICT ? row_probe_lines(syn1neg, row, lane, DCH * 2) : 0.f);
             if (won) row_unlock<STRICT>(locks, row);
-            return;
+            return true;
         }
+        if (s_deadline && lk_timed_out(s_deadline)) return false;        // (the watchdog: this delta stays unflushed, the launch is reported as failed)
         __builtin_amdgcn_s_sleep(2);
     }
 }
@@ -1012,7 +1019,7 @@ __device__ __forceinline__ void flushA_blocking(const TableView& syn1neg, int* l
 #define LK_CHUNK 10          /* negatives per lock round: a multiple of NEG_BATCH, so no batch of a full chunk loads filler rows */
 #endif
 // 3 waves per SIMD is the measured optimum for D <= 128: 4 (128 VGPRs) spills 88 B per lane and runs 20 % slower, 2 runs 12 % slower
-template <int DCH, bool STRICT, bool BIG, bool HOTMIX, bool PART>
+template <int DCH, bool STRICT, bool BIG, bool HOTMIX, bool PART, bool WDOG = false>
 __global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HOTMIX ? (PART ? 2 : DGE_HOTMIX_WAVES) : (DCH == 1 ? 4 : DGE_LOCKED_WAVES)) : ((HOTMIX && DCH <= 4) ? 2 : 1))
 k_sgns_train_locked(TrainParams p) {
     __shared__ float s_exp[EXP_TABLE_SIZE];
@@ -1020,6 +1027,11 @@ k_sgns_train_locked(TrainParams p) {
     __shared__ __attribute__((aligned(16))) float s_mb[HOTMIX ? LK_MB_WORKERS * 2 * LkBox<DCH>::FLOATS : 4];     // the atomics wave's message boxes
     __shared__ int s_mb_flag[LK_MB_WORKERS * 2];
     __shared__ int s_mb_done;
+    __shared__ unsigned long long s_deadline;              // the watchdog's (TrainParams::wd_ticks)
+    // WDOG: its own instantiation, launched only where update_policy 5 / 6 was FORCED (p.wd_ticks != 0).  What auto picks the locks for — a flat vocabulary — cannot
+    // make them wait, and the headline kernel must not pay for the check: the extra control flow costs 4 registers and 22 spilled scalars, 1.5 % of a cfg3 launch
+    // (same box, A / B: 390.9 against 396.8 ms).  The mixed kernels never carry it: the rows that could make them wait are their head, which takes no lock.
+    constexpr bool WD = WDOG && !HOTMIX;
     __shared__ float s_acc[HOTMIX ? LK_ACC_ROWS(DCH) * DCH * 64 : 4];        // the atomics wave's accumulators of the hottest rows (lk_atomics_wave)
     __shared__ int s_acc_cnt[LK_ACC_ROWS(DCH)];
     // the negative-sampling table's run form (neg_row_by_runs), where the model has one (not in the mixed kernels: skewed vocabularies have none)
@@ -1035,7 +1047,7 @@ k_sgns_train_locked(TrainParams p) {
     }
     for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
     if (threadIdx.x < LK_MB_WORKERS * 2) s_mb_flag[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_mb_done = 0;
+    if (threadIdx.x == 0) { s_mb_done = 0; s_deadline = p.wd_ticks ? (unsigned long long)wall_clock64() + p.wd_ticks : ~0ull; }
     if (HOTMIX) {
         for (int i = threadIdx.x; i < LK_ACC_ROWS(DCH) * DCH * 64; i += blockDim.x) s_acc[i] = 0.f;
         if (threadIdx.x < LK_ACC_ROWS(DCH)) s_acc_cnt[threadIdx.x] = 0;
@@ -1108,13 +1120,19 @@ k_sgns_train_locked(TrainParams p) {
         }                                                                                                              \
         h_dirty = true;                                                                                                \
     } while (0)
+    // the watchdog fired while this worker waited for a lock (nothing is held any more): it counts itself and becomes a worker whose walks have run out — the state
+    // the main loop leaves through (no walk, no open centre, nothing parked)
+#define LK_GIVE_UP()                                                                                                   \
+    do {                                                                                                               \
+        if (lane == 0) atomicAdd(&p.counters[3], 1ull);                                                                \
+        w_next = p.n_rows; i = len; c = c_hi + 1; retry_pair = false; h_dirty = false; pend_row = -1;                  \
+    } while (0)
 #define LK_CLOSE_CENTRE()                                                                                              \
     do {                                                                                                               \
         if (h_dirty) {                                                                                                 \
             h_dirty = false;                                                                                           \
-            if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows); \
-            pend_row = word;                                                                                           \
-            cur_buf ^= 1;                                                                                              \
+            if (pend_row >= 0 && !flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows, WD ? &s_deadline : nullptr)) LK_GIVE_UP(); \
+            else { pend_row = word; cur_buf ^= 1; }                                                                    \
         }                                                                                                              \
     } while (0)
 
@@ -1126,6 +1144,8 @@ k_sgns_train_locked(TrainParams p) {
             while (i >= len) {
                 w = w_next;
                 if (w >= p.n_rows) { alive = false; break; }
+                // (past the watchdog's deadline no walk is begun: the workers that never had to wait must not train the whole rest of the launch alone)
+                if (WD && lk_timed_out(&s_deadline)) { if (lane == 0) atomicAdd(&p.counters[3], 1ull); alive = false; break; }
                 if (p.next_walk) {
                     unsigned long long t = 0;
                     if (lane == 0) t = atomicAdd(p.next_walk, 1ull);
@@ -1186,7 +1206,7 @@ k_sgns_train_locked(TrainParams p) {
             // the previous centre's delta is still parked in LDS; when it belongs to THIS row (the same token twice in a walk)
             // it goes out first, so that one worker alone reads exactly what the sequential loop would
             if (pend_row == word) {
-                flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows);
+                if (!flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows, WD ? &s_deadline : nullptr)) { LK_GIVE_UP(); continue; }
                 pend_row = -1;
             }
             rowA_load<DCH, 16, BIG>(h, syn1neg, word, lane);       // unlocked read: stale by at most the OTHER workers' updates in flight
@@ -1328,11 +1348,25 @@ k_sgns_train_locked(TrainParams p) {
                 }
                 pend13 &= ~got13;
                 if (gotf) { flush_pending = false; pend_row = -1; if (lane == 13) t = -1; }
-                if (pend13) __builtin_amdgcn_s_sleep(2);
+                if (pend13) {
+                    if (WD && lk_timed_out(&s_deadline)) {       // the watchdog: the round's locks have dropped; what is still held is the pair's syn0 row
+                        if (lane == 14 && !(HOTMIX && (last < hot_rows || p.syn0_free))) row_unlock<STRICT>(locks0, last);
+                        LK_GIVE_UP();
+                        kd = K;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
             }
             kd += LK_CHUNK;
         } while (kd < K && !abort_pair);
-        if (abort_pair) { retry_pair = true; __builtin_amdgcn_s_sleep(8); continue; }
+        if (WD && i >= len) continue;                      // (gave up inside a round)
+        if (abort_pair) {
+            if (WD && lk_timed_out(&s_deadline)) { LK_GIVE_UP(); continue; }      // (nothing is held here)
+            retry_pair = true;
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
         retry_pair = false;
 
 #pragma unroll
@@ -1357,10 +1391,11 @@ k_sgns_train_locked(TrainParams p) {
         }
     }
     LK_CLOSE_CENTRE();
-    if (pend_row >= 0) flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows);
+    if (pend_row >= 0 && !flushA_blocking<DCH, STRICT, BIG, HOTMIX>(syn1neg, locks1, pend_row, my_dh + (cur_buf ^ 1) * DCH * 64 + lane, lane, hot_rows, WD ? &s_deadline : nullptr)) LK_GIVE_UP();
 #undef LK_TOK
 #undef LK_POSITIVE
 #undef LK_CLOSE_CENTRE
+#undef LK_GIVE_UP
     if (lane == 0) {
         if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
         if (my_words) atomicAdd(&p.counters[1], my_words);
@@ -1735,15 +1770,24 @@ static inline void launch_train_b(const TrainParams& p, int pol, unsigned blocks
                 hipLaunchKernelGGL((k_sgns_train_hsw<DCH, true, 7>), dim3(blocks), dim3(threads), shmem, st, p);
             }
             break;
-        case 5: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
-        case 6: hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 5:
+            if (p.wd_ticks) hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, false, true>), dim3(blocks), dim3(threads), 0, st, p);      // (forced: with the watchdog)
+            else hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p);
+            break;
+        case 6:
+            if (p.wd_ticks) hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG, false, false, true>), dim3(blocks), dim3(threads), 0, st, p);
+            else hipLaunchKernelGGL((k_sgns_train_locked<DCH, true, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p);
+            break;
         case 7: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         // block schedule of the multi-GPU path (dge_model_set_partition): in-order, atomics, commit locks
         case 20: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 22: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 30: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, true, true>), dim3(blocks), dim3(threads), 0, st, p); break;      // ... with the hierarchical softmax
         case 32: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, true, true>), dim3(blocks), dim3(threads), shmem, st, p); break;
-        case 25: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p); break;
+        case 25:
+            if (p.wd_ticks) hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, true, true>), dim3(blocks), dim3(threads), 0, st, p);
+            else hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, false, true>), dim3(blocks), dim3(threads), 0, st, p);
+            break;
         case 27: hipLaunchKernelGGL((k_sgns_train_locked<DCH, false, BIG, true, true>), dim3(blocks), dim3(threads), 0, st, p); break;
         default: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
     }

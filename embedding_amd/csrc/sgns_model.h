@@ -1,7 +1,9 @@
 // sgns_model.h — the trainer's handle (vocabulary + tables + per-call work buffers), shared by sgns.hip (host side of the C ABI)
 // and sgns_sorted.hip (the owner-computes schedule).
 #pragma once
+#include <algorithm>
 #include <atomic>
+#include <string>
 #include <vector>
 
 #include "dge_internal.h"
@@ -65,11 +67,21 @@ struct dge_model {
     double kernel_ms = 0, walk_ms = 0;
     int64_t launches = 0;
     int last_policy = -1; int64_t last_workers = 0; int32_t last_hot_rows = 0;   // what the latest launch ran with
+    std::string last_kernel;                                                     // ... and the trainer kernel's name and form (dge_model_kernel)
     int32_t search_runs = 0, search_moved = 0; double search_ms_before = 0, search_ms_after = 0;      // dge_model_tune_placement's latest report
     int32_t part_n = 1, part_ctx = 0, part_tgt = 0;                              // block schedule (dge_model_set_partition)
     const int32_t* seen_rows = nullptr; int64_t seen_n = 0; int32_t seen_L = 0; uint64_t seen_gen = 0;   // what d_sen/d_len/d_wb were derived from
+    hipEvent_t ev_peer = nullptr;                                                // stream-ordered partition copies: the handshake with the caller's stream
     dge_sorted_work* sorted = nullptr;                                           // update_policy 8 (allocated on first use)
 };
+
+// pairs of a full-length walk under DL4J's window (radius uniform in 1 .. W): what a launch's size is estimated from without reading anything back
+static inline double dge_expected_pairs_per_walk(int L, int W) {
+    double e = 0.0;
+    for (int i = 0; i < L; i++)
+        for (int r = 1; r <= W; r++) e += (double)(std::min(L - 1, i + r) - std::max(0, i - r)) / (double)W;
+    return e;
+}
 
 // update_policy 8 (sgns_sorted.hip): one pass of the owner-computes schedule over compacted walks [0, n_rows) of m->d_sen
 struct TrainParams;

@@ -62,11 +62,15 @@ struct dge_sorted_work {
     uint64_t* st_it = nullptr; int64_t st_cap_items = 0;
     unsigned long long* st_words = nullptr;      // in-vocabulary tokens of the batch
     std::vector<int64_t> st_bucket0;             // first pair of every bucket (+ end)
+    // mini-batches of every bucket, laid out when the store is made (round 5: an episode reads nothing back — the host runs ahead of the device through all n episodes of a
+    // batch, and the next episode's first sort overlaps this episode's last phases and the partition's hand-off): walks per mini-batch, first pair of each mini-batch (+ end)
+    std::vector<int64_t> st_walks_per; std::vector<std::vector<int64_t>> st_marks;
+    hipEvent_t ev_store = nullptr;               // recorded behind k_block_emit on the model's stream: the second stream waits for it before it sorts the store's items
     bool st_valid = false;
-    struct Key { const int32_t* sen; int64_t n_rows; uint64_t gen; int32_t L, W, K, part_n, part_ctx; int64_t gidx_base, V, T; uint64_t seed;      // (items carry no learning rate)
+    struct Key { const int32_t* sen; int64_t n_rows; uint64_t gen; int32_t L, W, K, part_n, part_ctx; int64_t gidx_base, V, T; uint64_t seed; int64_t walks_knob;      // (items carry no learning rate)
                  bool operator==(const Key& o) const {
                      return sen == o.sen && n_rows == o.n_rows && gen == o.gen && L == o.L && W == o.W && K == o.K && part_n == o.part_n && part_ctx == o.part_ctx &&
-                            gidx_base == o.gidx_base && V == o.V && T == o.T && seed == o.seed;
+                            gidx_base == o.gidx_base && V == o.V && T == o.T && seed == o.seed && walks_knob == o.walks_knob;
                  } } st_key_of{};
 };
 
@@ -79,6 +83,7 @@ void dge_sorted_release(dge_model* m) {
         if (s->ev_ready[x]) (void)hipEventDestroy(s->ev_ready[x]);
         if (s->ev_done[x]) (void)hipEventDestroy(s->ev_done[x]);
     }
+    if (s->ev_store) (void)hipEventDestroy(s->ev_store);
     dge_dev_free(s->cnt); dge_dev_free(s->off); dge_dev_free(s->scan_tmp); dge_dev_free(s->seg); dge_dev_free(s->scratch); dge_dev_free(s->d_marks); dge_dev_free(s->shadow);
     dge_dev_free(s->st_cnt); dge_dev_free(s->st_off); dge_dev_free(s->st_scan_tmp); dge_dev_free(s->st_it); dge_dev_free(s->st_words);
     if (s->h_marks) (void)hipHostFree(s->h_marks);
@@ -753,8 +758,24 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     int obits = 1;
     while ((1ll << obits) < m->V) obits++;
     const int ks1 = 1 + obits, ks2 = 11 + obits;
+    // mini-batches of whole walks (dge_sorted_batch_items: ~128 items per live row, the hottest row bounded)
+    int64_t want_items = dge_sorted_batch_items(m, p.part_n);
+    if (want_items == 0) want_items = 1 << 20;         // asked for explicitly on a vocabulary the rule would not pick it for (train_rows has checked that it is safe)
+    auto walks_per_for = [&](double items_per_walk) -> int64_t {
+        int64_t wp = std::max<int64_t>(1, (int64_t)((double)want_items / std::max(items_per_walk, 1e-9)));
+        if (g_dge_tuning[DGE_TUNE_SORTED_WALKS] > 0) wp = g_dge_tuning[DGE_TUNE_SORTED_WALKS];
+        return std::min(wp, p.n_rows);
+    };
+    if (!s->aux) {
+        DGE_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+        for (int x = 0; x < 2; x++) {
+            DGE_HIP(hipEventCreateWithFlags(&s->ev_ready[x], hipEventDisableTiming));
+            DGE_HIP(hipEventCreateWithFlags(&s->ev_done[x], hipEventDisableTiming));
+        }
+        DGE_HIP(hipEventCreateWithFlags(&s->ev_store, hipEventDisableTiming));
+    }
     if (use_store) {
-        const dge_sorted_work::Key key{p.sen, p.n_rows, m->seen_gen, p.L, p.W, p.K, p.part_n, p.part_ctx, p.gidx_base, p.V, p.T, p.seed};
+        const dge_sorted_work::Key key{p.sen, p.n_rows, m->seen_gen, p.L, p.W, p.K, p.part_n, p.part_ctx, p.gidx_base, p.V, p.T, p.seed, (int64_t)g_dge_tuning[DGE_TUNE_SORTED_WALKS]};
         const int64_t n_cells = (int64_t)p.part_n * p.n_rows;
         if (!(s->st_valid && m->seen_gen != 0 && key == s->st_key_of)) {
             s->st_valid = false;
@@ -812,6 +833,41 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
                                             (int32_t)((m->V + p.part_n - 1) / p.part_n), (int32_t)ks1, run_nb);
                 }
                 DGE_HIP(hipGetLastError());
+                DGE_HIP(hipEventRecord(s->ev_store, st));
+                // the mini-batches of every bucket: the batch's second and last read-back
+                s->st_walks_per.assign((size_t)p.part_n, 1); s->st_marks.assign((size_t)p.part_n, std::vector<int64_t>());
+                int64_t n_marks = 0;
+                for (int t = 0; t < p.part_n; t++) {
+                    const int64_t tp = s->st_bucket0[(size_t)t + 1] - s->st_bucket0[(size_t)t];
+                    const int64_t wp = walks_per_for((double)tp * K1 / (double)p.n_rows);
+                    s->st_walks_per[(size_t)t] = wp;
+                    n_marks += (p.n_rows + wp - 1) / wp + 1;
+                }
+                if (n_marks > s->cap_marks) {
+                    dge_dev_free(s->d_marks); s->d_marks = nullptr; s->cap_marks = 0;
+                    if ((rc = dge_dev_alloc(&s->d_marks, 2 * (size_t)n_marks))) return rc;
+                    s->cap_marks = n_marks;
+                }
+                if (n_marks > s->cap_h_marks) {
+                    if (s->h_marks) (void)hipHostFree(s->h_marks);
+                    s->h_marks = nullptr; s->cap_h_marks = 0;
+                    DGE_HIP(hipHostMalloc((void**)&s->h_marks, ((size_t)n_marks + 64) * sizeof(int64_t), hipHostMallocDefault));
+                    s->cap_h_marks = n_marks + 64;
+                }
+                int64_t at = 0;
+                for (int t = 0; t < p.part_n; t++) {
+                    const int64_t wp = s->st_walks_per[(size_t)t], nm = (p.n_rows + wp - 1) / wp + 1;
+                    hipLaunchKernelGGL(k_sorted_marks_walks, dim3(grid_for(nm, 256)), dim3(256), 0, st, s->st_off, (int64_t)t * p.n_rows, (int64_t)1, wp, p.n_rows, (int)nm, s->d_marks + at);
+                    at += nm;
+                }
+                DGE_HIP(hipMemcpyAsync(s->h_marks, s->d_marks, (size_t)n_marks * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+                DGE_HIP(hipStreamSynchronize(st));
+                at = 0;
+                for (int t = 0; t < p.part_n; t++) {
+                    const int64_t wp = s->st_walks_per[(size_t)t], nm = (p.n_rows + wp - 1) / wp + 1;
+                    s->st_marks[(size_t)t].assign(s->h_marks + at, s->h_marks + at + nm);
+                    at += nm;
+                }
                 s->st_key_of = key; s->st_valid = true;
             }
         }
@@ -840,45 +896,46 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     { size_t b = s->scan_tmp_bytes; DGE_HIP(hipcub::DeviceScan::ExclusiveSum(s->scan_tmp, b, CountIter(s->cnt, CastI64()), s->off, n_units + 1, st)); }
 
     }
-    // mini-batches of whole walks (dge_sorted_batch_items: ~128 items per live row, the hottest row bounded).  How many walks make one: under the item store the
-    // bucket's pair count is on the host already; otherwise from the EXPECTED pairs of a full-length walk (DL4J's window: radius uniform in 1 .. W) — round 4: the
-    // launch's pair total used to be read back for this, one of two host round trips that cost a cfg2 launch ~8 % (shorter walks only make mini-batches smaller)
-    int64_t want_items = dge_sorted_batch_items(m, p.part_n);
-    if (want_items == 0) want_items = 1 << 20;         // asked for explicitly on a vocabulary the rule would not pick it for: smallest mini-batches
-    double items_per_walk;
-    if (use_store) items_per_walk = (double)total_pairs * K1 / (double)p.n_rows;
-    else {
-        double e = 0.0;
-        for (int i = 0; i < p.L; i++)
-            for (int r = 1; r <= p.W; r++) e += (double)(std::min(p.L - 1, i + r) - std::max(0, i - r)) / (double)p.W;
-        items_per_walk = e * K1;
-    }
-    int64_t walks_per = std::max<int64_t>(1, (int64_t)((double)want_items / std::max(items_per_walk, 1e-9)));
-    if (g_dge_tuning[DGE_TUNE_SORTED_WALKS] > 0) walks_per = g_dge_tuning[DGE_TUNE_SORTED_WALKS];
-    walks_per = std::min(walks_per, p.n_rows);
-    const int64_t n_sub = (p.n_rows + walks_per - 1) / walks_per;
-    std::vector<int64_t> marks((size_t)n_sub + 1);
-    // marks: the unit (per-episode path) or the (bucket, walk) cell (item store) at which every mini-batch begins -> its first pair
-    for (int64_t k = 0; k <= n_sub; k++) marks[(size_t)k] = use_store ? (int64_t)p.part_tgt * p.n_rows + std::min(k * walks_per, p.n_rows) : std::min(k * walks_per, p.n_rows) * p.L;
-    if (n_sub + 1 > s->cap_marks) {
+    // How many walks make a mini-batch: under the item store the bucket's mini-batches were laid out with the store (nothing is read back per episode); otherwise from
+    // the EXPECTED pairs of a full-length walk (DL4J's window: radius uniform in 1 .. W) — round 4: the launch's pair total used to be read back for this, one of two
+    // host round trips that cost a cfg2 launch ~8 % (shorter walks only make mini-batches smaller)
+    int64_t walks_per, n_sub;
+    const int64_t* h_off;
+    std::vector<int64_t> marks;
+    if (use_store) {
+        walks_per = s->st_walks_per[(size_t)p.part_tgt];
+        n_sub = (p.n_rows + walks_per - 1) / walks_per;
+        h_off = s->st_marks[(size_t)p.part_tgt].data();
+        DGE_HIP(hipStreamWaitEvent(s->aux, s->ev_store, 0));          // (the store's items were written on the model's stream)
+    } else {
+        double items_per_walk = dge_expected_pairs_per_walk(p.L, p.W) * K1;
+        // one block of an n-rank schedule holds the pairs (context in one partition, centre in another): 1 / n^2 of the walk's (without this a block
+        // that runs without the item store — more than 16 ranks, or a store that does not fit — cut its mini-batches n^2 times too small)
+        if (p.part_n > 1) items_per_walk /= (double)p.part_n * (double)p.part_n;
+        walks_per = walks_per_for(items_per_walk);
+        n_sub = (p.n_rows + walks_per - 1) / walks_per;
+        marks.resize((size_t)n_sub + 1);
+        // marks: the unit at which every mini-batch begins -> its first pair
+        for (int64_t k = 0; k <= n_sub; k++) marks[(size_t)k] = std::min(k * walks_per, p.n_rows) * p.L;
+        if (n_sub + 1 > s->cap_marks) {
+            DGE_HIP(hipStreamSynchronize(st));
+            dge_dev_free(s->d_marks); s->d_marks = nullptr;
+            if ((rc = dge_dev_alloc(&s->d_marks, 2 * ((size_t)n_sub + 1)))) return rc;
+            s->cap_marks = n_sub + 1;
+        }
+        if (n_sub + 1 > s->cap_h_marks) {
+            if (s->h_marks) (void)hipHostFree(s->h_marks);
+            s->h_marks = nullptr; s->cap_h_marks = 0;
+            DGE_HIP(hipHostMalloc((void**)&s->h_marks, ((size_t)n_sub + 1 + 64) * sizeof(int64_t), hipHostMallocDefault));
+            s->cap_h_marks = n_sub + 1 + 64;
+        }
+        // the launch's ONE read-back: the first pair of every mini-batch (the sorts take their item counts from the host), computed on the device, into pinned memory
+        hipLaunchKernelGGL(k_sorted_marks_walks, dim3(grid_for(n_sub + 1, 256)), dim3(256), 0, st, s->off, (int64_t)0, (int64_t)p.L, walks_per, p.n_rows, (int)(n_sub + 1), s->d_marks);
+        DGE_HIP(hipMemcpyAsync(s->h_marks, s->d_marks, ((size_t)n_sub + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         DGE_HIP(hipStreamSynchronize(st));
-        dge_dev_free(s->d_marks); s->d_marks = nullptr;
-        if ((rc = dge_dev_alloc(&s->d_marks, 2 * ((size_t)n_sub + 1)))) return rc;
-        s->cap_marks = n_sub + 1;
+        h_off = s->h_marks;
+        total_pairs = h_off[n_sub] - h_off[0]; if (total_pairs == 0) return DGE_OK;
     }
-    if (n_sub + 1 > s->cap_h_marks) {
-        if (s->h_marks) (void)hipHostFree(s->h_marks);
-        s->h_marks = nullptr; s->cap_h_marks = 0;
-        DGE_HIP(hipHostMalloc((void**)&s->h_marks, ((size_t)n_sub + 1 + 64) * sizeof(int64_t), hipHostMallocDefault));
-        s->cap_h_marks = n_sub + 1 + 64;
-    }
-    // the launch's ONE read-back: the first pair of every mini-batch (the sorts take their item counts from the host), computed on the device, into pinned memory
-    hipLaunchKernelGGL(k_sorted_marks_walks, dim3(grid_for(n_sub + 1, 256)), dim3(256), 0, st, use_store ? s->st_off : s->off,
-                       use_store ? (int64_t)p.part_tgt * p.n_rows : (int64_t)0, use_store ? (int64_t)1 : (int64_t)p.L, walks_per, p.n_rows, (int)(n_sub + 1), s->d_marks + s->cap_marks);
-    DGE_HIP(hipMemcpyAsync(s->h_marks, s->d_marks + s->cap_marks, ((size_t)n_sub + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    DGE_HIP(hipStreamSynchronize(st));
-    const int64_t* h_off = s->h_marks;
-    if (!use_store) { total_pairs = h_off[n_sub] - h_off[0]; if (total_pairs == 0) return DGE_OK; }
 
     int64_t max_slots = 0;
     for (int64_t k = 0; k < n_sub; k++) max_slots = std::max(max_slots, (h_off[k + 1] - h_off[k]) * K1);
@@ -890,13 +947,6 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     int key_bits = 1;
     while (key_bits < 31 && (1ll << key_bits) <= Vk) key_bits++;              // keys are 0 .. Vk (Vk = a skipped draw)
     if (ks2 + key_bits > 64) DGE_FAIL(DGE_ERR_ARG, "update_policy 8: %lld vocabulary rows do not fit the packed item", (long long)m->V);
-    if (!s->aux) {
-        DGE_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
-        for (int x = 0; x < 2; x++) {
-            DGE_HIP(hipEventCreateWithFlags(&s->ev_ready[x], hipEventDisableTiming));
-            DGE_HIP(hipEventCreateWithFlags(&s->ev_done[x], hipEventDisableTiming));
-        }
-    }
     if (max_slots > s->cap_items) {
         DGE_HIP(hipStreamSynchronize(s->aux));
         const int64_t cap = max_slots + max_slots / 8 + 1024;
@@ -946,7 +996,8 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         const int64_t n = (h_off[k + 1] - h_off[k]) * K1;
         if (n == 0) continue;
         const int x = (int)(live++ & 1);
-        q.unit0 = marks[(size_t)k]; q.unit1 = marks[(size_t)k + 1]; q.pair0 = h_off[k]; q.n_slots = n;      // (unit0, unit1, pair0: the per-episode emit only)
+        if (!use_store) { q.unit0 = marks[(size_t)k]; q.unit1 = marks[(size_t)k + 1]; }
+        q.pair0 = h_off[k]; q.n_slots = n;      // (unit0, unit1, pair0: the per-episode emit only)
         // second stream: items -> it0; sorted by target row -> it1; row segments
         if (s->set_used[x]) DGE_HIP(hipStreamWaitEvent(s->aux, s->ev_done[x], 0));         // the mini-batch that held this set has finished
         q.it_out = s->it0[x];

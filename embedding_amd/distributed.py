@@ -18,12 +18,24 @@ instead of averaging overshoots (AUC 0.53 at N=4).  The reference is single-host
 """
 
 
+HOST_WAITS = {"n": 0}      # blocking device waits made by this module (tests: an episode of the block schedule makes none)
+
+
 def _wait_device(t):
-    """torch.distributed enqueues collectives on torch's streams; libdge.so works on its own stream, so the host waits
-    for the tensor's device before handing the pointer over."""
+    """torch.distributed enqueues collectives on torch's streams; libdge.so works on its own stream.  Outside the block schedule's episodes (counts, delta
+    exchange, the final gather) the host simply waits for the tensor's device before handing the pointer over."""
     if getattr(t, "is_cuda", False):
         import torch
+        HOST_WAITS["n"] += 1
         torch.cuda.synchronize(t.device)
+
+
+def _stream_of(t):
+    """torch's current stream on the tensor's device as a hipStream_t integer (what libdge's stream-ordered entry points take); None for a host tensor."""
+    if getattr(t, "is_cuda", False):
+        import torch
+        return int(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
 
 
 def shard_plan(epoch_walks, world, rank):
@@ -147,7 +159,8 @@ def _ring_pass(send_buf, recv_buf, world, rank, d, transport):
         allb = torch.empty(send_buf.numel() * world, dtype=send_buf.dtype, device=send_buf.device)
         d.all_gather_into_tensor(allb, send_buf)
         recv_buf.copy_(allb[src * send_buf.numel():(src + 1) * send_buf.numel()])
-    _wait_device(recv_buf)             # the transfer runs on torch's streams; libdge reads recv_buf on its own stream
+    # (no host wait: under nccl `wait()` orders torch's current stream behind the transfer, and the import that follows makes libdge's stream wait for that
+    #  stream — embedding_amd.SgnsModel.import_partition_async; the staged gloo path has completed on the host already)
 
 
 def block_schedule_step(model, train_fn, world, rank, part_buf=None, recv_buf=None, dist_mod=None, transport=None):
@@ -179,14 +192,24 @@ def block_schedule_step(model, train_fn, world, rank, part_buf=None, recv_buf=No
     if not isinstance(transport, RingTransport):
         transport = RingTransport.choose(world, rank, d, device=part_buf.device, requested=transport)
     tables = (1, 2) if getattr(getattr(model, "cfg", None), "use_hs", 0) else (1,)     # with the hierarchical softmax the syn1 partition of the same number travels along
+    # The hand-off is STREAM-ORDERED (round 5): the pack kernel runs on libdge's stream and torch's current stream waits for it (an event), the transfer is ordered on
+    # torch's stream, and libdge's stream waits for that stream before it unpacks — the host waits for nothing inside an episode and runs ahead of the device, so the
+    # next episode's launches (its first sort runs on a second stream and needs neither table) are queued while this episode's last kernels and the transfer are
+    # still in flight.  Models without the stream-ordered entry points (the numpy stand-ins of the CPU tests) keep the blocking pair.
+    ordered = hasattr(model, "export_partition_async") and (getattr(part_buf, "is_cuda", False) or getattr(model, "stream_ordered", False))
     for e in range(world):
         tgt = (rank + e) % world
         model.set_partition(world, rank, tgt)
         train_fn()
         for table in tables:
-            model.export_partition(table, world, tgt, part_buf)        # what this rank just trained ...
-            _ring_pass(part_buf, recv_buf, world, rank, d, transport)  # ... goes to rank-1; rank+1's arrives:
-            model.import_partition(table, world, (rank + 1 + e) % world, recv_buf)     # the partition of the NEXT episode
+            if ordered:
+                model.export_partition_async(table, world, tgt, part_buf, _stream_of(part_buf))      # what this rank just trained ...
+                _ring_pass(part_buf, recv_buf, world, rank, d, transport)                            # ... goes to rank-1; rank+1's arrives:
+                model.import_partition_async(table, world, (rank + 1 + e) % world, recv_buf, _stream_of(recv_buf))      # the partition of the NEXT episode
+            else:
+                model.export_partition(table, world, tgt, part_buf)
+                _ring_pass(part_buf, recv_buf, world, rank, d, transport)
+                model.import_partition(table, world, (rank + 1 + e) % world, recv_buf)
     model.set_partition(1)
     return part_buf, recv_buf
 

@@ -373,6 +373,12 @@ class SgnsModel:
         check(lib.dge_model_schedule(self._h, C.byref(pol), C.byref(w), C.byref(hot)))
         return {"update_policy": pol.value, "workers": w.value, "hot_rows": hot.value}
 
+    def kernel(self):
+        """Name and form of the trainer kernel the latest launch ran (include/dge.h: dge_model_kernel)."""
+        buf = C.create_string_buffer(256)
+        check(lib.dge_model_kernel(self._h, buf, 256))
+        return buf.value.decode()
+
     # ---- multi-GPU block schedule (include/dge.h: dge_model_set_partition)
     def set_partition(self, n_parts, ctx_part=0, tgt_part=0):
         check(lib.dge_model_set_partition(self._h, int(n_parts), int(ctx_part), int(tgt_part)))
@@ -385,6 +391,19 @@ class SgnsModel:
 
     def import_partition(self, table, n_parts, part, d_buf):
         check(lib.dge_model_import_partition(self._h, int(table), int(n_parts), int(part), _dev_ptr(d_buf)))
+
+    def export_partition_async(self, table, n_parts, part, d_buf, consumer_stream=0):
+        """Stream-ordered export (include/dge.h): the pack kernel runs on the model's stream and `consumer_stream` (a hipStream_t as an integer, 0 = the
+        legacy default stream, e.g. torch.cuda.current_stream().cuda_stream) waits for it; the host does not."""
+        check(lib.dge_model_export_partition_async(self._h, int(table), int(n_parts), int(part), _dev_ptr(d_buf), C.c_void_p(int(consumer_stream))))
+
+    def import_partition_async(self, table, n_parts, part, d_buf, producer_stream=0):
+        """Stream-ordered import: the model's stream waits for what `producer_stream` holds now, then unpacks; the host does not wait."""
+        check(lib.dge_model_import_partition_async(self._h, int(table), int(n_parts), int(part), _dev_ptr(d_buf), C.c_void_p(int(producer_stream))))
+
+    def stream(self):
+        """The hipStream_t (as an integer) the model's launches are enqueued on."""
+        p = C.c_void_p(0); check(lib.dge_model_stream(self._h, C.byref(p))); return p.value or 0
 
     def sync_size(self):
         n = C.c_int64(0); check(lib.dge_model_sync_size(self._h, C.byref(n))); return n.value
@@ -399,12 +418,18 @@ class SgnsModel:
         check(lib.dge_model_import_delta(self._h, _dev_ptr(d_buf), float(scale)))
 
 
+def host_sync_count():
+    """Blocking waits (stream / device / event synchronisations, blocking copies) the library has made in this process so far (include/dge.h:
+    dge_host_sync_count): tests assert that an episode of the block schedule adds none."""
+    n = C.c_int64(0); check(lib.dge_host_sync_count(C.byref(n))); return n.value
+
+
 def build_stamp():
     """{"kernels": hash, "sorted": hash} of the trainer kernels' sources the loaded libdge.so was built from (include/dge.h: dge_build_stamp)."""
     return dict(kv.split("=") for kv in lib.dge_build_stamp().decode().split())
 
 
-TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7, "hs_cold": 8, "hs_wave": 9, "acc_rows": 10, "acc_drain": 11, "table_runs": 12, "block_syn0_free": 13, "hs_centre": 14, "hs_hot_kb": 15}      # include/dge.h: DGE_TUNE_*
+TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7, "hs_cold": 8, "hs_wave": 9, "acc_rows": 10, "acc_drain": 11, "table_runs": 12, "block_syn0_free": 13, "hs_centre": 14, "hs_hot_kb": 15, "allow_unsafe": 16, "watchdog_ms": 17, "hs_copies": 18}      # include/dge.h: DGE_TUNE_*
 
 
 class tuning:

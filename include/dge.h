@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define DGE_VERSION 104   /* 104: dge_build_stamp, dge_model_placement_search, DGE_TUNE_BLOCK_SYN0_FREE; the block schedule keeps a head / tail split on skewed vocabularies (additions only) */
+#define DGE_VERSION 105   /* 105: stream-ordered partition copies (dge_model_export/import_partition_async, dge_model_stream), dge_host_sync_count, the lock kernels' watchdog,
+                             forced schedules refused where they would diverge or spin (DGE_ERR_ARG), DGE_TUNE_ALLOW_UNSAFE / WATCHDOG_MS / HS_COPIES (additions only) */
 
 enum {
     DGE_OK = 0,
@@ -261,6 +262,12 @@ int  dge_model_placement_search(const dge_model* m, int32_t* runs, double* ms_be
 /* what the latest training launch resolved `update_policy` 0 / `workers` 0 to: the policy that ran (0 = in-order plain),
  * the concurrent workers, and for policy 7 the head rows kept out of the lock protocol */
 int  dge_model_schedule(const dge_model* m, int32_t* update_policy, int64_t* workers, int32_t* hot_rows);
+/* ... and the trainer kernel (name and form) that launch ran, as text: e.g. "k_sgns_train_locked<relaxed>", "k_sgns_train_hsw<negatives under commit locks, 7 waves> (...)",
+ * "k_sorted_phase (owner-computes: ...)".  The policy number alone does not say it (hierarchical softmax has three kernels). */
+int  dge_model_kernel(const dge_model* m, char* buf, int32_t cap);
+/* Blocking waits the library has made in this process so far — stream / device / event synchronisations and blocking copies, counted at every call site.  An episode
+ * of the multi-GPU block schedule makes none once its buffers exist (tests/test_gpu_distributed.py counts them); a global batch makes two (the item store's sizes). */
+int  dge_host_sync_count(int64_t* n);
 /* WordVectorSerializer.writeWordVectors(w2v, path)  J/DeepWalk.java:82: "name v1 .. vD\n" per vocabulary
  * row, no header (header != 0 writes the LINE-style "V D" first line of miscs/taxi_all.txt:1).
  * names[v] is the string of vertex id v; null -> the decimal id. */
@@ -286,6 +293,14 @@ int  dge_model_partition_floats(const dge_model* m, int32_t n_parts, int64_t* n_
 /* table: 0 = syn0, 1 = syn1neg, 2 = syn1 (use_hs); d_buf is device memory of dge_model_partition_floats floats */
 int  dge_model_export_partition(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf);
 int  dge_model_import_partition(dge_model* m, int table, int32_t n_parts, int32_t part, const float* d_buf);
+/* The same, STREAM-ORDERED: the host never waits.  export: the pack kernel runs on the model's stream and `consumer_stream` (a hipStream_t; NULL = the legacy default
+ * stream) is made to wait for it with an event — whatever the caller enqueues there afterwards (ncclSend, a copy) sees the packed buffer.  import: the model's stream
+ * is made to wait for everything `producer_stream` holds at the time of the call (the transfer that fills d_buf), then unpacks.  Passing the model's own stream
+ * (dge_model_stream) skips the handshake: a host that enqueues its RCCL calls on that stream needs no event at all (dge_model_ring_pass does exactly that).
+ * d_buf must stay untouched by the caller until the model's stream has passed the copy. */
+int  dge_model_export_partition_async(dge_model* m, int table, int32_t n_parts, int32_t part, float* d_buf, void* consumer_stream);
+int  dge_model_import_partition_async(dge_model* m, int table, int32_t n_parts, int32_t part, const float* d_buf, void* producer_stream);
+int  dge_model_stream(const dge_model* m, void** hip_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU exchange at epoch boundaries (new; the reference is single-host).  Each rank trains its
@@ -341,15 +356,18 @@ enum {
     DGE_TUNE_SORTED_WALKS = 5,    /* update_policy 8: walks per synchronous mini-batch (default: as many as the item buffers hold) */
     DGE_TUNE_WORKERS = 6,         /* workers = 0 (fill the device): this many concurrent walks instead of the count the library derives */
     DGE_TUNE_STATIC_WALKS = 7,    /* > 0: the lock kernels' worker w trains walks w, w + workers, ... instead of taking them from a launch-wide counter */
-    DGE_TUNE_HS_COLD = 8,         /* hierarchical softmax under atomics: inner nodes [0, value) take plain read-modify-write (default: those on < 2e-5 of the paths) */
+    DGE_TUNE_HS_COLD = 8,         /* hierarchical softmax under atomics: inner nodes [0, value) take plain read-modify-write (default: those on < 2e-5 of the paths — derived from the COUNTS the model was created with: they must describe the corpus that is trained, or updates of nodes that are busier than their count says are lost; 0 = every node by atomics) */
     DGE_TUNE_HS_WAVE = 9,         /* hierarchical softmax under atomics: 0 = the workers issue their atomics themselves, 1 = through the workgroup's atomics wave (default: the wave from 65 536 rows on) */
     DGE_TUNE_ACC_ROWS = 10,       /* update_policy 7: the hottest rows [0, value) add their syn1neg updates up in LDS (one set of atomics per DGE_TUNE_ACC_DRAIN updates; the kernel caps the value at what its LDS holds, 8 .. 16); default 0 = none: measured it buys 2-4 % and, from 16 updates a flush on, shifts the trained scores */
     DGE_TUNE_ACC_DRAIN = 11,      /* updates of such a row between two flushes (default 16) */
     DGE_TUNE_TABLE_RUNS = 12,     /* the negative-sampling table's run form (dge_model_table_runs): 0 = not built / not used (the lock kernels read the table), N > 0 = built from at most N runs of the vocabulary's tail (tests: the head rows in front stay on the table); default: up to 2 046 runs */
     DGE_TUNE_BLOCK_SYN0_FREE = 13, /* block schedule, mixed lock kernel: 1 = the pair's syn0 row is never locked (agent-scope read, atomics), 0 = it is locked unless it is a head row; default: the library's rule */
     DGE_TUNE_HS_CENTRE = 14,      /* hierarchical softmax under atomics: 0 = pair by pair (k_sgns_train), 1 = a wave per centre wherever it applies (rows of up to 128 floats, walks of up to 64 tokens; k_sgns_train_hsw); 2 = that kernel with the pair's negatives and the centre's gathered syn1neg update under the rows' commit locks instead of atomics, 3 = the same in workgroups of seven training waves (one a compute unit) that share their LDS accumulators; default: a wave per centre from 65 536 vocabulary rows on — form 3 where update_policy 0 would pick the commit locks for the negative-sampling kernels, form 1 elsewhere */
-    DGE_TUNE_HS_HOT_KB = 15,      /* k_sgns_train_hsw: > 0 = keep the inner nodes next to the root in that many KB of LDS accumulators per workgroup (drained every DGE_TUNE_HS_DRAIN additions; round 4's first form: faster by a tenth, staler) instead of the default, the busiest nodes in copies (nothing parked; DGE_TUNE_HS_DRAIN then = the root's number of copies, default 16) */
-    DGE_TUNE_COUNT = 16
+    DGE_TUNE_HS_HOT_KB = 15,      /* k_sgns_train_hsw: > 0 = keep the inner nodes next to the root in that many KB of LDS accumulators per workgroup (drained every DGE_TUNE_HS_DRAIN additions; round 4's first form: faster by a tenth, staler) instead of the default, the busiest nodes in copies (nothing parked; the root's number of copies: DGE_TUNE_HS_COPIES).  Capped at 100 (seven-wave workgroups) / 30 (three-wave) */
+    DGE_TUNE_ALLOW_UNSAFE = 16,   /* > 0: a FORCED update_policy runs even where the library would refuse it (8 on a vocabulary whose busiest row would take > 8192 terms of one mini-batch; 5 / 6 where workers x the busiest row's share > 2) — tests of the watchdog, reproductions of the failure */
+    DGE_TUNE_WATCHDOG_MS = 17,    /* the lock kernels' watchdog: a worker still waiting for a row lock after this many milliseconds of the launch gives up (dge_model_stats then returns DGE_ERR_STATE); 0 = no watchdog; default: 5 s + 100 x the launch's bytes at the 8 TB/s roofline */
+    DGE_TUNE_HS_COPIES = 18,      /* k_sgns_train_hsw, copies form: the root's number of copies (a node's copies = ceil(its share of the paths x value), at most 16); default 16 */
+    DGE_TUNE_COUNT = 19
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
 int  dge_get_tuning(int32_t knob, int64_t* value);   /* -1 = the library's own rule */

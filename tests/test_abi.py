@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(dge):
 
 def test_struct_layouts(dge):
     assert C.sizeof(dge.TrainConfig) == 64 and C.sizeof(dge.TrainStats) == 40
-    assert dge.lib.dge_version() == 104
+    assert dge.lib.dge_version() == 105
 
 
 def test_no_device_means_loud_failure(dge):
@@ -93,7 +93,7 @@ def test_bench_workloads_and_traffic_table():
     e = table["cfg3/policy5"]
     assert 6000 < e["bytes_per_pair"] < 7600                                              # the rows of a pair: 7168 algorithmic
     assert bench.measured_traffic("cfg3", "policy5", 1000.0) == e["bytes_per_pair"] * 1000.0
-    assert bench.measured_traffic("cfg5", "policy7", 1.0) > 45056 and bench.measured_traffic("cfg3", "hs", 1.0) > 0
+    assert bench.measured_traffic("cfg5", "policy7", 1.0) > 45056 and bench.measured_traffic("cfg3", "hs_centre", 1.0) > 0
     assert bench.measured_traffic("cfg3", "policy99", 1.0) is None
     # requests at the L2's memory side x the pair rate; None where no profile says
     assert abs(bench.measured_requests("cfg3", "policy5", 3.8e8, 400.0) - e["requests_per_pair"] * 3.8e8 / 0.4) < 1e3

@@ -29,7 +29,10 @@ def _rank(rank, world, port, out_dir, batch_walks, workers, hs=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = _graph(dge)
     cfg = dge.make_config(DIM, T, R * T, workers=workers, table_size=20011, use_hs=hs)
+    from embedding_amd import distributed as D
     m = fit_distributed(g, N_WALKS, T, cfg, world, rank, walk_seed=11, batch_walks=batch_walks)
+    # the module waited for the device after the count all-reduce and after each final gather — never inside an episode (the hand-off is stream-ordered)
+    assert D.HOST_WAITS["n"] == 1 + (3 if hs else 2), D.HOST_WAITS
     syn0, vid = m.vectors()
     np.savez(os.path.join(out_dir, "d%d.npz" % rank), syn0=syn0, syn1neg=m.syn1neg(), vid=vid, pairs=m.stats()["pairs"], syn1=m.syn1() if hs else np.zeros(0, np.float32))
     dist.barrier()
@@ -141,3 +144,36 @@ def test_two_gpus_over_rccl(dge, oracle, tmp_path):
         for r in range(2):
             d = np.load(str(tmp_path / ("%s%d.npz" % (tag, r))))
             assert np.array_equal(bits(d["syn0"]), bits(om.syn0)) and np.array_equal(bits(d["syn1neg"]), bits(om.syn1neg)), (tag, r)
+
+
+def test_an_episode_of_the_block_schedule_makes_no_blocking_wait_in_the_library(dge):
+    """dge_host_sync_count counts every blocking wait the library makes (stream / device / event synchronisations, blocking copies).  One rank's share of a 4-rank
+    schedule under the owner-computes kernels (what auto resolves to in a block of a flat vocabulary), the hand-off stream-ordered on the model's stream: a global batch
+    costs its item store's two read-backs in episode 0, and the episodes after it none — the host runs ahead of the device through the whole batch."""
+    import torch
+    rng = np.random.default_rng(5)
+    V, L, n, N = 40_000, 12, 60_000, 4
+    corpora = [dge.WalkCorpus.from_host(rng.integers(0, V, (n, L)).astype(np.int32), 0) for _ in range(2)]
+    counts = torch.zeros(V, dtype=torch.int64, device="cuda:0"); corpora[0].count_tokens(V, counts)
+    m = dge.SgnsModel.create(dge.make_config(64, L, V, negative=5, workers=0, epochs=1, seed=3, min_count=1), counts, 0)
+    buf = torch.empty(m.partition_floats(N), dtype=torch.float32, device="cuda:0")
+
+    def batch(corpus):
+        waits = []
+        for e in range(N):
+            m.set_partition(N, 0, e)
+            c0 = dge.host_sync_count()
+            m.train(corpus)
+            st = m.stream()
+            m.export_partition_async(1, N, e, buf, st); m.import_partition_async(1, N, e, buf, st)
+            waits.append(dge.host_sync_count() - c0)
+        m.set_partition(1)
+        return waits
+
+    batch(corpora[0])                                        # (first use: work buffers)
+    w1, w2 = batch(corpora[1]), batch(corpora[0])
+    pairs = m.stats()["pairs"]
+    assert m.schedule()["update_policy"] == 8 and "one block" in m.kernel()
+    assert w1[1:] == [0] * (N - 1) and w2[1:] == [0] * (N - 1), (w1, w2)
+    assert 0 < w1[0] <= 3 and 0 < w2[0] <= 3, (w1, w2)
+    assert pairs > 0 and np.isfinite(m.vectors()[0][:1000]).all()
