@@ -50,6 +50,8 @@ struct dge_sorted_work {
     hipStream_t aux = nullptr;
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool set_used[2] = {false, false};
+    int64_t live = 0;                            // mini-batches run so far: set live % 2 is the next one's, ACROSS launches — an episode's first mini-batch then takes the set its
+                                                 // predecessor's last one did not use, and its sort (second stream) starts while that last mini-batch's phases still run
     int64_t* seg = nullptr; int64_t cap_seg = 0; // first sorted position of every row (+ end): by target for set 0, set 1; by context
     float* shadow = nullptr; int64_t cap_shadow = 0;   // the target rows as phase A leaves them, committed after phase B
     float* scratch = nullptr; int64_t cap_scratch_rows = 0;
@@ -761,10 +763,15 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     // mini-batches of whole walks (dge_sorted_batch_items: ~128 items per live row, the hottest row bounded)
     int64_t want_items = dge_sorted_batch_items(m, p.part_n);
     if (want_items == 0) want_items = 1 << 20;         // asked for explicitly on a vocabulary the rule would not pick it for (train_rows has checked that it is safe)
+    // (walks per mini-batch: as many as give want_items — then EVENED OUT over the launch: with 36 M items and 11.4 M a mini-batch the fourth mini-batch was a 1.6 M-item
+    //  remainder that cost a tenth of a full one's kernels' fixed parts and went through rocPRIM's small-input merge sort, ~25 launches: 6 % of an 8-rank episode at the
+    //  1 M-walk global batch, profiles/r05_sim8_1M_timeline_before.txt)
     auto walks_per_for = [&](double items_per_walk) -> int64_t {
         int64_t wp = std::max<int64_t>(1, (int64_t)((double)want_items / std::max(items_per_walk, 1e-9)));
-        if (g_dge_tuning[DGE_TUNE_SORTED_WALKS] > 0) wp = g_dge_tuning[DGE_TUNE_SORTED_WALKS];
-        return std::min(wp, p.n_rows);
+        if (g_dge_tuning[DGE_TUNE_SORTED_WALKS] > 0) return std::min<int64_t>(g_dge_tuning[DGE_TUNE_SORTED_WALKS], p.n_rows);
+        wp = std::min(wp, p.n_rows);
+        const int64_t n_mb = (p.n_rows + wp - 1) / wp;
+        return (p.n_rows + n_mb - 1) / n_mb;
     };
     if (!s->aux) {
         DGE_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
@@ -947,15 +954,16 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     int key_bits = 1;
     while (key_bits < 31 && (1ll << key_bits) <= Vk) key_bits++;              // keys are 0 .. Vk (Vk = a skipped draw)
     if (ks2 + key_bits > 64) DGE_FAIL(DGE_ERR_ARG, "update_policy 8: %lld vocabulary rows do not fit the packed item", (long long)m->V);
+    // (growth of a work buffer: earlier launches may still be using the old one on either stream — since round 5 nothing else makes the host wait for them)
     if (max_slots > s->cap_items) {
-        DGE_HIP(hipStreamSynchronize(s->aux));
+        DGE_HIP(hipStreamSynchronize(st)); DGE_HIP(hipStreamSynchronize(s->aux));
         const int64_t cap = max_slots + max_slots / 8 + 1024;
         size_t b = 0;
         for (int x = 0; x < 2; x++) {
             dge_dev_free(s->it0[x]); dge_dev_free(s->it1[x]); dge_dev_free(s->sort_tmp[x]);
             s->it0[x] = s->it1[x] = nullptr; s->sort_tmp[x] = nullptr;
         }
-        s->cap_items = 0; s->set_used[0] = s->set_used[1] = false;
+        s->cap_items = 0; s->set_used[0] = s->set_used[1] = false; s->live = 0;
         for (int x = 0; x < 2; x++) {
             if ((rc = dge_dev_alloc(&s->it0[x], (size_t)cap))) return rc;
             if ((rc = dge_dev_alloc(&s->it1[x], (size_t)cap))) return rc;
@@ -966,18 +974,20 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         s->cap_items = cap;
     }
     if (Vk + 2 > s->cap_seg) {
-        DGE_HIP(hipStreamSynchronize(s->aux));
+        DGE_HIP(hipStreamSynchronize(st)); DGE_HIP(hipStreamSynchronize(s->aux));
         dge_dev_free(s->seg); s->seg = nullptr;
         if ((rc = dge_dev_alloc(&s->seg, 3 * ((size_t)Vk + 2)))) return rc;
         s->cap_seg = Vk + 2;
     }
     if (Vk > s->cap_shadow) {
+        DGE_HIP(hipStreamSynchronize(st));
         dge_dev_free(s->shadow); s->shadow = nullptr;
         if ((rc = dge_dev_alloc(&s->shadow, (size_t)Vk * (size_t)m->stride + 64))) return rc;
         s->cap_shadow = Vk;
     }
     const int64_t need_rows = 2 * ((s->cap_items + chunk - 1) / chunk) + 2;
     if (need_rows > s->cap_scratch_rows) {
+        DGE_HIP(hipStreamSynchronize(st));
         dge_dev_free(s->scratch); s->scratch = nullptr;
         if ((uint64_t)need_rows * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull) DGE_FAIL(DGE_ERR_ARG, "update_policy 8: chunk size %d too small for %lld items", chunk, (long long)s->cap_items);
         if ((rc = dge_dev_alloc(&s->scratch, (size_t)need_rows * (size_t)m->stride))) return rc;
@@ -991,11 +1001,10 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     int64_t* const seg_a[2] = {s->seg, s->seg + Vk + 2}; int64_t* const seg_b = s->seg + 2 * (Vk + 2);
     const int dch = m->stride / 64;
     // (the offsets were read back above: everything the second stream reads — counts, offsets, walks, the unigram table — is in place)
-    int64_t live = 0;
     for (int64_t k = 0; k < n_sub; k++) {
         const int64_t n = (h_off[k + 1] - h_off[k]) * K1;
         if (n == 0) continue;
-        const int x = (int)(live++ & 1);
+        const int x = (int)(s->live++ & 1);
         if (!use_store) { q.unit0 = marks[(size_t)k]; q.unit1 = marks[(size_t)k + 1]; }
         q.pair0 = h_off[k]; q.n_slots = n;      // (unit0, unit1, pair0: the per-episode emit only)
         // second stream: items -> it0; sorted by target row -> it1; row segments
