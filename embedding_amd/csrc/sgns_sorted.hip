@@ -25,7 +25,7 @@
 // bounded staleness Hogwild has anyway (DL4J itself gathers 512 pairs per thread into one libnd4j aggregate batch).
 // Work units are CHUNKS of a fixed number of sorted items, not rows, so a hot row costs no more than a cold one: a row whose items
 // straddle chunk borders is processed as independent segments from the same starting row and their deltas are added in chunk order
-// by the owner of the row's first chunk (k_sorted_fixup).
+// by the row's owner at the end of the mini-batch (k_sorted_finish).
 #include <hipcub/hipcub.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -54,7 +54,7 @@ struct dge_sorted_work {
                                                  // predecessor's last one did not use, and its sort (second stream) starts while that last mini-batch's phases still run
     int64_t* seg = nullptr; int64_t cap_seg = 0; // first sorted position of every row (+ end): by target for set 0, set 1; by context
     float* shadow = nullptr; int64_t cap_shadow = 0;   // the target rows as phase A leaves them, committed after phase B
-    float* scratch = nullptr; int64_t cap_scratch_rows = 0;
+    float* scratch = nullptr; float* scratch_b = nullptr; int64_t cap_scratch_rows = 0;      // the segments' deltas of phase A / of phase B (k_sorted_finish reads both)
     int64_t* d_marks = nullptr; int64_t cap_marks = 0;
     int64_t* h_marks = nullptr; int64_t cap_h_marks = 0;      // pinned: the one read-back of a launch (first pair of every mini-batch) lands here
     // Block schedule: the items of ALL n target partitions of a rank's context partition, made once per global batch (k_block_count /
@@ -86,7 +86,7 @@ void dge_sorted_release(dge_model* m) {
         if (s->ev_done[x]) (void)hipEventDestroy(s->ev_done[x]);
     }
     if (s->ev_store) (void)hipEventDestroy(s->ev_store);
-    dge_dev_free(s->cnt); dge_dev_free(s->off); dge_dev_free(s->scan_tmp); dge_dev_free(s->seg); dge_dev_free(s->scratch); dge_dev_free(s->d_marks); dge_dev_free(s->shadow);
+    dge_dev_free(s->cnt); dge_dev_free(s->off); dge_dev_free(s->scan_tmp); dge_dev_free(s->seg); dge_dev_free(s->scratch); dge_dev_free(s->scratch_b); dge_dev_free(s->d_marks); dge_dev_free(s->shadow);
     dge_dev_free(s->st_cnt); dge_dev_free(s->st_off); dge_dev_free(s->st_scan_tmp); dge_dev_free(s->st_it); dge_dev_free(s->st_words);
     if (s->h_marks) (void)hipHostFree(s->h_marks);
     delete s;
@@ -108,7 +108,9 @@ struct SortedParams {
     const int64_t* seg;                          // seg[k] = first sorted position with key >= k; seg[Vk] = valid items
     int64_t n_slots;                             // sorted array length (valid items first, then the skipped draws with key V)
     int32_t chunk;                               // items per work unit
-    float* scratch;                              // [2 * chunks][stride]: deltas of the rows a chunk shares with its neighbours
+    float* scratch;                              // [2 * chunks][stride]: deltas of the rows a chunk shares with its neighbours (the running phase's: A's or B's)
+    float* scratch_a; float* scratch_b;          // k_sorted_finish: both phases' deltas (phase A's must outlive phase B)
+    const int64_t* seg_tgt;                      // k_sorted_finish: the target-sorted segments (seg is then the context-sorted ones)
     float* shadow;                               // phase A writes the moved target rows here; phase B still reads the rows as they were
     // sort keys: row / kdiv.  Under the block schedule only rows = part (mod part_n) occur on either side, so the keys lose log2(part_n) bits
     // (the 125 k live rows of an 8-rank block: 17 bits instead of 20, two sort passes instead of three); row = key * kdiv + the side's part.
@@ -516,7 +518,7 @@ __global__ void k_sorted_segments(const uint64_t* __restrict__ items, int ks, in
 // the label; the row takes its updates in item order, the step of every item goes out as a code with (context, target) for phase B.
 // PB == true (phase B): key = context row (owned, syn0), the item carries the target row and the step's code; the row takes the sum of g * syn1neg[target].
 // A row that lies wholly inside the chunk is stored directly; a segment of a row shared with a neighbouring chunk leaves its DELTA in
-// scratch slot 2*chunk (the segment starts the chunk) or 2*chunk+1 (it ends the chunk), summed up by k_sorted_fixup.
+// scratch slot 2*chunk (the segment starts the chunk) or 2*chunk+1 (it ends the chunk), summed up by k_sorted_finish.
 #define SORTED_PIPE 4      /* rows of the other side in flight per worker (8 measured the same: cfg2 3.5 ms per launch either way, an 8-rank block 62.5 against 62.7 ms) */
 template <int DCH, bool PB>
 __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
@@ -620,61 +622,73 @@ __global__ void __launch_bounds__(256) k_sorted_phase(SortedParams q) {
 #undef OWN_ROW
 }
 
-// rows shared by several chunks: the worker of the chunk in which such a row BEGINS adds the deltas of all its segments, in chunk
-// order, to the row as it stood before the phase
+// End of a mini-batch, one 16-lane group per key (round 5: one kernel where there were three — a fix-up pass behind each phase and the commit; each was a launch of
+// tens of microseconds that mostly found nothing to do, 5 % of an 8-rank episode at the 1 M-walk global batch):
+//   target side (syn1neg, segments sorted by target): a row that lay wholly inside one chunk was left by phase A in the shadow table and is committed from there; a row
+//     whose items straddle chunks takes the deltas of its segments, in chunk order, on top of the row as it stood before the mini-batch (what phase B read);
+//   context side (syn0, segments sorted by context): whole rows were updated by phase B itself; a straddling row takes its segments' deltas in chunk order.
+// A segment's delta is in scratch slot 2 * chunk (the segment starts the chunk) or 2 * chunk + 1 (it begins inside it): k_sorted_phase.
 template <int DCH>
-__global__ void __launch_bounds__(256) k_sorted_fixup(SortedParams q, int phase_b) {
+__global__ void __launch_bounds__(256) k_sorted_finish(SortedParams q) {
     const TrainParams& p = q.t;
     const int lane = threadIdx.x & 15;
-    const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int64_t n_valid = q.seg[q.Vk];
-    const int64_t start = chunk * q.chunk;
-    if (start >= n_valid) return;
-    const int64_t end = min(start + (int64_t)q.chunk, n_valid);
-    const int32_t kr = (int32_t)(q.it_in[end - 1] >> (phase_b ? q.ks2 : q.ks1));      // the key of the chunk's last item, its row
-    const int32_t r = kr * q.kdiv + (phase_b ? q.kpart_ctx : q.kpart_tgt);
-    const int64_t r0 = q.seg[kr], r1 = q.seg[kr + 1];
-    if (r1 <= end || r0 < start) return;                              // it ends here, or it began in an earlier chunk
-    const TableView own = make_view(phase_b ? p.syn0 : p.syn1neg, p.V, p.stride);
-    const TableView scr = make_view(q.scratch, 2 * ((q.n_slots + q.chunk - 1) / q.chunk), p.stride);
-    Row<DCH> row;
-    rowA_load<DCH, 0, false>(row, own, r, lane);
-    const int64_t c_hi = (r1 - 1) / q.chunk;
-    for (int64_t c = chunk; c <= c_hi; c++) {
-        Row<DCH> dd;
-        rowA_load<DCH, 0, false>(dd, scr, (int32_t)(2 * c + (r0 <= c * q.chunk ? 0 : 1)), lane);
-#pragma unroll
-        for (int x = 0; x < DCH; x++) { row.v[x].x += dd.v[x].x; row.v[x].y += dd.v[x].y; row.v[x].z += dd.v[x].z; row.v[x].w += dd.v[x].w; }
-    }
-    if (phase_b) rowA_store<DCH, 0, false>(row, own, r, lane);
-    else rowA_store<DCH, 0, false>(row, make_view(q.shadow, q.Vk, p.stride), kr, lane);
-}
-
-// end of a mini-batch: the target rows that had items take the value phase A left in the shadow table
-template <int DCH>
-__global__ void __launch_bounds__(256) k_sorted_commit(SortedParams q, const int64_t* seg_a) {
-    const TrainParams& p = q.t;
-    const int lane = threadIdx.x & 15;
-    // (under the block schedule only the rows of the target partition have keys)
     const int64_t kr = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    if (kr >= q.Vk || seg_a[kr + 1] == seg_a[kr]) return;
-    const int64_t r = kr * q.kdiv + q.kpart_tgt;
-    Row<DCH> row;
-    rowA_load<DCH, 0, false>(row, make_view(q.shadow, q.Vk, p.stride), (int32_t)kr, lane);
-    rowA_store<DCH, 0, false>(row, make_view(p.syn1neg, p.V, p.stride), (int32_t)r, lane);
+    if (kr >= q.Vk) return;
+    const int64_t n_chunks = (q.n_slots + q.chunk - 1) / q.chunk;
+    {   // target side
+        const int64_t r0 = q.seg_tgt[kr], r1 = q.seg_tgt[kr + 1];
+        if (r1 > r0) {
+            const int64_t c0 = r0 / q.chunk, c1 = (r1 - 1) / q.chunk;
+            const TableView own = make_view(p.syn1neg, p.V, p.stride);
+            const int32_t r = (int32_t)(kr * q.kdiv + q.kpart_tgt);
+            Row<DCH> row;
+            if (c0 == c1) rowA_load<DCH, 0, false>(row, make_view(q.shadow, q.Vk, p.stride), (int32_t)kr, lane);
+            else {
+                const TableView scr = make_view(q.scratch_a, 2 * n_chunks, p.stride);
+                rowA_load<DCH, 0, false>(row, own, r, lane);
+                for (int64_t c = c0; c <= c1; c++) {
+                    Row<DCH> dd;
+                    rowA_load<DCH, 0, false>(dd, scr, (int32_t)(2 * c + (r0 <= c * q.chunk ? 0 : 1)), lane);
+#pragma unroll
+                    for (int x = 0; x < DCH; x++) { row.v[x].x += dd.v[x].x; row.v[x].y += dd.v[x].y; row.v[x].z += dd.v[x].z; row.v[x].w += dd.v[x].w; }
+                }
+            }
+            rowA_store<DCH, 0, false>(row, own, r, lane);
+        }
+    }
+    {   // context side
+        const int64_t r0 = q.seg[kr], r1 = q.seg[kr + 1];
+        if (r1 > r0) {
+            const int64_t c0 = r0 / q.chunk, c1 = (r1 - 1) / q.chunk;
+            if (c0 != c1) {
+                const TableView own = make_view(p.syn0, p.V, p.stride);
+                const TableView scr = make_view(q.scratch_b, 2 * n_chunks, p.stride);
+                const int32_t r = (int32_t)(kr * q.kdiv + q.kpart_ctx);
+                Row<DCH> row;
+                rowA_load<DCH, 0, false>(row, own, r, lane);
+                for (int64_t c = c0; c <= c1; c++) {
+                    Row<DCH> dd;
+                    rowA_load<DCH, 0, false>(dd, scr, (int32_t)(2 * c + (r0 <= c * q.chunk ? 0 : 1)), lane);
+#pragma unroll
+                    for (int x = 0; x < DCH; x++) { row.v[x].x += dd.v[x].x; row.v[x].y += dd.v[x].y; row.v[x].z += dd.v[x].z; row.v[x].w += dd.v[x].w; }
+                }
+                rowA_store<DCH, 0, false>(row, own, r, lane);
+            }
+        }
+    }
 }
 template <int DCH>
-static void launch_commit(const SortedParams& q, const int64_t* seg_a, hipStream_t st) {
-    hipLaunchKernelGGL((k_sorted_commit<DCH>), dim3((unsigned)(((int64_t)q.Vk * 16 + 255) / 256)), dim3(256), 0, st, q, seg_a);
+static void launch_finish(const SortedParams& q, hipStream_t st) {
+    hipLaunchKernelGGL((k_sorted_finish<DCH>), dim3((unsigned)(((int64_t)q.Vk * 16 + 255) / 256)), dim3(256), 0, st, q);
 }
-static void launch_commit_any(int dch, const SortedParams& q, const int64_t* seg_a, hipStream_t st) {
+static void launch_finish_any(int dch, const SortedParams& q, hipStream_t st) {
     switch (dch) {
-        case 1: launch_commit<1>(q, seg_a, st); break;
-        case 2: launch_commit<2>(q, seg_a, st); break;
-        case 3: launch_commit<3>(q, seg_a, st); break;
-        case 4: launch_commit<4>(q, seg_a, st); break;
-        case 6: launch_commit<6>(q, seg_a, st); break;
-        default: launch_commit<8>(q, seg_a, st); break;
+        case 1: launch_finish<1>(q, st); break;
+        case 2: launch_finish<2>(q, st); break;
+        case 3: launch_finish<3>(q, st); break;
+        case 4: launch_finish<4>(q, st); break;
+        case 6: launch_finish<6>(q, st); break;
+        default: launch_finish<8>(q, st); break;
     }
 }
 
@@ -729,7 +743,6 @@ static void launch_phase(const SortedParams& q, bool phase_b, hipStream_t st) {
     const unsigned blocks = grid_for(chunks * 16, 256);
     if (phase_b) hipLaunchKernelGGL((k_sorted_phase<DCH, true>), dim3(blocks), dim3(256), 0, st, q);
     else hipLaunchKernelGGL((k_sorted_phase<DCH, false>), dim3(blocks), dim3(256), 0, st, q);
-    hipLaunchKernelGGL((k_sorted_fixup<DCH>), dim3(blocks), dim3(256), 0, st, q, phase_b ? 1 : 0);
 }
 static void launch_phase_any(int dch, const SortedParams& q, bool phase_b, hipStream_t st) {
     switch (dch) {
@@ -988,14 +1001,16 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
     const int64_t need_rows = 2 * ((s->cap_items + chunk - 1) / chunk) + 2;
     if (need_rows > s->cap_scratch_rows) {
         DGE_HIP(hipStreamSynchronize(st));
-        dge_dev_free(s->scratch); s->scratch = nullptr;
+        dge_dev_free(s->scratch); dge_dev_free(s->scratch_b); s->scratch = nullptr; s->scratch_b = nullptr;
         if ((uint64_t)need_rows * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull) DGE_FAIL(DGE_ERR_ARG, "update_policy 8: chunk size %d too small for %lld items", chunk, (long long)s->cap_items);
         if ((rc = dge_dev_alloc(&s->scratch, (size_t)need_rows * (size_t)m->stride))) return rc;
+        if ((rc = dge_dev_alloc(&s->scratch_b, (size_t)need_rows * (size_t)m->stride))) return rc;
         s->cap_scratch_rows = need_rows;
     }
 
     SortedParams q;
     q.t = p; q.cnt = s->cnt; q.off = s->off; q.seg = s->seg; q.chunk = chunk; q.scratch = s->scratch; q.shadow = s->shadow;
+    q.scratch_a = s->scratch; q.scratch_b = s->scratch_b; q.seg_tgt = s->seg;
     q.kdiv = kdiv; q.kpart_tgt = p.part_n > 1 ? p.part_tgt : 0; q.kpart_ctx = p.part_n > 1 ? p.part_ctx : 0; q.Vk = (int32_t)Vk;
     q.ks1 = ks1; q.ks2 = ks2; q.omask = (uint32_t)((1ull << obits) - 1ull); q.mb_walk0 = 0; q.it_in = nullptr; q.it_out = nullptr;
     int64_t* const seg_a[2] = {s->seg, s->seg + Vk + 2}; int64_t* const seg_b = s->seg + 2 * (Vk + 2);
@@ -1031,15 +1046,15 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         DGE_HIP(hipEventRecord(s->ev_ready[x], s->aux));
         // model's stream — phase A: target rows move (into the shadow table); context key | target row | step code -> it0
         DGE_HIP(hipStreamWaitEvent(st, s->ev_ready[x], 0));
-        q.it_in = s->it1[x]; q.it_out = s->it0[x]; q.seg = seg_a[x];
+        q.it_in = s->it1[x]; q.it_out = s->it0[x]; q.seg = seg_a[x]; q.seg_tgt = seg_a[x]; q.scratch = s->scratch;
         launch_phase_any(dch, q, false, st);
         // sorted by context row -> it1; phase B: context rows take their sums
         b = s->sort_tmp_bytes;
         DGE_HIP(sort_items(s->sort_tmp[1], b, s->it0[x], s->it1[x], n, ks2, key_bits, st));
         hipLaunchKernelGGL(k_sorted_segments, dim3(grid_for(Vk + 2, 256)), dim3(256), 0, st, s->it1[x], ks2, n, Vk, seg_b);
-        q.seg = seg_b;
+        q.seg = seg_b; q.scratch = s->scratch_b;
         launch_phase_any(dch, q, true, st);            // reads the target rows as they stood BEFORE the mini-batch
-        launch_commit_any(dch, q, seg_a[x], st);
+        launch_finish_any(dch, q, st);                 // straddling rows of both sides take their segments' deltas, the target rows are committed
         DGE_HIP(hipEventRecord(s->ev_done[x], st));
         s->set_used[x] = true;
     }
