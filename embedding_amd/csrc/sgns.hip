@@ -984,7 +984,12 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         const bool auto_locked = auto_pol == 5, auto_mixed = auto_pol == 7;
         const int blocks_per_cu = (m->cfg.update_policy == 5 || m->cfg.update_policy == 6 || m->cfg.update_policy == 7 || auto_locked || auto_mixed) ? ((m->cfg.update_policy == 7 || auto_mixed) ? (m->stride <= 128 ? DGE_HOTMIX_WAVES : 2) : (m->stride == 64 ? 4 : DGE_LOCKED_WAVES)) : 4;   // (rows of one chunk leave room for a 4th wave per SIMD in the lock kernel; a 5th under atomics gains nothing: cfg2 7.6e8 either way)   // what the kernel's VGPR budget keeps resident
         workers = (int64_t)m->n_cus * blocks_per_cu * 16;
-        workers = std::min(workers, std::max<int64_t>(64, m->V / 2));
+        // Round 5 (scripts/small_vocab_workers.py, profiles/r05_small_vocab_workers*.txt): measured again on the reference's own tract size — 6 408 rows, D = 20, a graph with
+        // community structure — with what matters downstream instead of the cosine to the in-order result: held-out link AUC and loss.  Negative sampling: AUC 0.9295 at
+        // 3 204 ... 16 384 workers alike (sequential oracle 0.9294, its 8 Hogwild threads 0.9274), loss 0.6928 -> 0.6942 at 9 612 (sequential 0.6924, 8 threads 0.7111);
+        // with the hierarchical softmax 9 612 workers keep AUC 0.9213 / loss 0.737 (8 CPU threads: 0.9207 / 0.741) and 12 816 lose it (0.915 / 0.81).  So from 4 096
+        // rows on the cap is 1.5 workers a row: cfg1 7.2e8 -> 1.28e9 edges/s, with the tree term 1.64e8 -> 5.1e8.  Below 4 096 rows the round-1 cap stays.
+        workers = std::min(workers, std::max<int64_t>(64, m->V >= 4096 ? m->V * 3 / 2 : m->V / 2));
         // ... nor so many that ONE row has dozens of its updates in flight at once: every one of them is computed from the same stale row, and their
         // sum — along the direction the contexts share — is a gradient step M times too long.  A vocabulary whose busiest row takes 9 % of the tokens
         // (Zipf(1) over 50 000 words: text without sub-sampling, not a flow graph) went to NaN within one launch of 16 384 workers
