@@ -870,7 +870,7 @@ static int64_t block_head(dge_model* m, int n, int64_t W) {
 //     >= 131 072 rows (round 3: 0.25 and 262 144 — a flat 200 000-row vocabulary runs 1.46e9 edges/s under locks against 1.19e9 owner-computes);
 //   * a skewed vocabulary keeps the locks for its tail when the head that has to leave them is at most a quarter of the rows (round 3: an eighth — rank^-0.5
 //     popularity over 300 000 rows: 9.5e8 against 7.3e8 owner-computes);
-//   * when the busiest row's share caps the workers below a quarter of the device (train_rows: at most 48 of a row's updates in flight), the lock protocol has
+//   * when the busiest row's share caps the workers below a quarter of the device (48 / its share of the tokens < 4096 workers; train_rows then caps the workers at 96 in flight), the lock protocol has
 //     nothing to win over atomics (rank^-1 over 300 000 words: 1.37e8 against 5.9e7).
 // (the first two conditions alone: a try-lock on a syn1neg row rarely fails — what the hierarchical-softmax kernel's lock form needs; it never locks a context row,
 //  so a vocabulary with a handful of rows whose OWN pairs would serialise under a syn0 lock, policy 7 with a tiny head, takes it as well)
@@ -994,7 +994,11 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // sum — along the direction the contexts share — is a gradient step M times too long.  A vocabulary whose busiest row takes 9 % of the tokens
         // (Zipf(1) over 50 000 words: text without sub-sampling, not a flow graph) went to NaN within one launch of 16 384 workers
         // (scripts/policy_sweep.py, round 4); cfg3 with Zipf destinations and cfg5 keep 34 and 18 in flight and train to the atomics-free AUC.
-        workers = std::min(workers, std::max<int64_t>(64, (int64_t)(48.0 / std::max(m->row_share_max, 1e-12))));
+        // Round 5 swept that bound on a graph WITH structure whose busiest vertex holds 2.8 % of the tokens (scripts/hot_row_inflight.py, profiles/r05_hot_row_inflight.txt;
+        // sequential oracle AUC 0.7472 / loss 1.988, its 8 Hogwild threads 0.7346 / 2.044): 24 / 48 / 96 in flight 0.7469 / 0.7464 / 0.7454 at loss 1.97, 192: 0.7402 / 2.00,
+        // 384: 0.7333 / 2.08 — and the SPEED peaks at 96 (3.2e8 edges/s; 2.7e8 at 48, 3.0e8 at 192: beyond, the busiest rows' atomics queue at the memory side).  So: 96.
+        // Copies of the hottest rows (what k_sgns_train_hsw does for the Huffman root) would lift the atomic wall, not this one: staleness caps the in-flight count first.
+        workers = std::min(workers, std::max<int64_t>(64, (int64_t)(96.0 / std::max(m->row_share_max, 1e-12))));
         workers = std::min(workers, (n_rows + 15) / 16 * 16);
     } else workers = m->cfg.workers;
     if (m->cfg.workers == 0 && g_dge_tuning[DGE_TUNE_WORKERS] > 0) workers = std::min<int64_t>(g_dge_tuning[DGE_TUNE_WORKERS], (n_rows + 15) / 16 * 16);     // ablation knob

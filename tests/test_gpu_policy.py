@@ -38,7 +38,7 @@ def _rate(dge, cfg, counts, corpus, n):
     (200_000, 0.0, 128, 5),      # a flat vocabulary below round 3's 262 144-row bar: commit locks beat owner-computes by a fifth
     (300_000, 0.5, 64, 7),       # a head between an eighth and a quarter of the rows: locks on the tail beat owner-computes by a quarter
     (50_000, 0.5, 256, 8),       # owner-computes 8 % below its old 1e6-item bar, on wide rows: 1.4x the atomics it was left with
-    (300_000, 1.0, 128, 2),      # one row with 9 % of the tokens: device-filling Hogwild diverged (NaN); now at most 48 of a row's updates in flight, by atomics
+    (300_000, 1.0, 128, 2),      # one row with 9 % of the tokens: device-filling Hogwild diverged (NaN); now at most 96 of a row's updates in flight (round 5: swept on a graph with structure), by atomics
 ])
 def test_auto_policy_is_fast_and_finite_off_the_bench_graphs(dge, V, s, D, expect):
     import torch
