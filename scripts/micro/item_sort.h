@@ -1,9 +1,12 @@
 // item_sort.h — EXPERIMENT, NOT PART OF libdge.so (round 5; verdict item "replace the generic radix sort").  Built, bit-identical to rocPRIM's output on 780 edge cases and
-// on every size / key width the schedule sorts, and SLOWER in isolation: 0.66 - 0.99x (profiles/r05_item_sort.txt: 7.2 M items of 17 key bits 0.203 ms against 0.155; 48 M
-// 0.909 against 0.729).  Half of a pass is the decoupled look-back's status traffic (agent-scope 8-byte words, one per tile and digit: with 512 digits and 8 192-item tiles
-// an eighth of the payload, at memory latency; without the look-back the same kernel runs 1.5x rocPRIM's speed) — the same design as rocPRIM's, without its tuning.  What it
-// would save in the pipeline (five fills, a scan kernel: ~35 us a sort) is less than what its passes lose (~45 us at 7.2 M items), so the schedule keeps rocPRIM's sort.
-// Kept with its harness (item_sort_bench.hip) for whoever takes the look-back further.
+// on every size / key width the schedule sorts, and SLOWER in isolation: 0.75 - 0.86x at 17 key bits, 0.4 - 0.7x at 20 (profiles/r05_item_sort.txt: 7.2 M items of 17 key
+// bits 0.214 ms against 0.161; 48 M 0.930 against 0.729).  Ablations (same file's history): with the look-back's LOADS removed (stores kept) the same kernels run 1.0 - 1.6x
+// rocPRIM's speed — the cost is the walk: every workgroup slot of the device holds a tile of the same "wave" of tiles, all of them publish their AGGREGATE at about the same
+// time and none has a PREFIX yet, so tile t of the wave walks back through ~t aggregates (8 per round trip) for each of its 512 digits: two orders of magnitude more status
+// loads than items.  Overlapping the first look-back load with the LDS reorder, tiles of 8 192 items and an adaptive window bought 10 % together.  What would fix it is a
+// bounded walk (aggregates over power-of-two spans of tiles published level by level: ~5 + t / 32 loads instead of t) — not built: even without any look-back the rank-and-
+// scatter kernel alone (~60 us a pass at 7.2 M items) only matches rocPRIM's pass, so the ceiling of this design is parity, and what it would save in the pipeline (five fills
+// and a scan kernel: ~35 us a sort) does not pay for the risk.  The schedule keeps rocPRIM's sort.  Kept with its harness (item_sort_bench.hip) for whoever takes it further.
 //
 // The owner-computes schedule's item sort (gfx950): a stable LSD radix sort of packed 64-bit items on a bit range [shift, shift + key_bits) of at most
 // 31 bits, the low bits riding along.  Round 5: written for this one use in place of rocPRIM's generic onesweep, which was a third of an 8-rank episode's kernel time
@@ -24,7 +27,7 @@
 
 #include "../../embedding_amd/csrc/dge_internal.h"
 
-#define RS_THREADS 512
+#define RS_THREADS 256
 #define RS_IPT 16
 #define RS_TILE (RS_THREADS * RS_IPT)
 #define RS_WAVES (RS_THREADS / 64)
@@ -67,6 +70,10 @@ __global__ void __launch_bounds__(256) k_rs_hist(RsHistParams q) {
         if (v) atomicAdd(&q.hist[i], v);
     }
 }
+
+// a workgroup barrier that waits for this wave's LDS operations only — __syncthreads() also drains the wave's outstanding GLOBAL loads (its fence), which is
+// exactly what the pass must not do while the look-back's answer is in flight
+__device__ __forceinline__ void rs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // exclusive scan over the workgroup of per-thread values held DPT to a thread (thread t: entries t * DPT .. + DPT - 1, in order); returns the exclusive prefix of the thread's first entry
 template <int DPT>
@@ -154,6 +161,37 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_pass(RsPassParams q) {
     }
     const uint32_t tile_excl = rs_block_excl<DPT>(cnt, s_wave);        // position of the thread's first digit in the tile's order
     const uint32_t glob_excl = rs_block_excl<DPT>(gh, s_wave);         // ... and in the whole output
+    // ---- publish the tile's counts and ASK for the word of the tile in front — then put the items in digit order in LDS while that answer travels (a barrier that
+    //      only waits for LDS: rs_lds_barrier), and only then look at it: the look-back's round trip to memory was half of a pass when the workgroup sat on it
+    unsigned long long w1[DPT];
+    {
+        uint32_t ts = tile_excl;
+#pragma unroll
+        for (int j = 0; j < DPT; j++) {
+            const int d = threadIdx.x * DPT + j;
+            w1[j] = 0;
+            if (d < ND) {
+#ifndef RS_DBG_NOSTORE
+                __hip_atomic_store(q.status + (uint64_t)tile * ND + d, (q.epoch << 34) | ((tile == 0 ? RS_FLAG_PREFIX : RS_FLAG_AGG) << 32) | (unsigned long long)cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+#ifdef RS_DBG_NOLOAD
+                if (false)
+#endif
+                if (tile > 0) w1[j] = __hip_atomic_load(q.status + (uint64_t)(tile - 1) * ND + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_start[d] = ts;
+            }
+            ts += cnt[j];
+        }
+    }
+    rs_lds_barrier();
+#pragma unroll
+    for (int i = 0; i < RS_IPT; i++) {
+        const int j = wv * RS_WAVE_ITEMS + i * 64 + lane;
+        if (j < n_here) {
+            const uint32_t d = meta[i] >> 16;
+            s_items[s_start[d] + s_cnt[wv][d] + (meta[i] & 0xFFFFu)] = item[i];
+        }
+    }
     // ---- decoupled look-back, a digit at a time: how many items of the digit lie in the tiles in front
     {
         uint32_t ts = tile_excl, gs = glob_excl;
@@ -163,20 +201,14 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_pass(RsPassParams q) {
             if (d < ND) {
                 unsigned long long* my = q.status + (uint64_t)tile * ND + d;
                 uint32_t excl = 0;
-#ifdef RS_DBG_NOLOOK
-                if (true) {}
-                else
+#ifdef RS_DBG_NOLOAD
+                if (false)
 #endif
-                if (tile == 0) __hip_atomic_store(my, (q.epoch << 34) | (RS_FLAG_PREFIX << 32) | (unsigned long long)cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else {
-                    __hip_atomic_store(my, (q.epoch << 34) | (RS_FLAG_AGG << 32) | (unsigned long long)cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // (a window of RS_LOOK tiles per step: their words are asked for together — the loads do not depend on each other — and taken in order; a word
-                    //  of another pass means "not written yet": the window is asked for again from there)
+                if (tile > 0) {
                     int64_t tp = tile - 1;
-                    {   // (first the tile in front alone: once the pipeline runs, its PREFIX is there and that is all there is to read)
-                        const unsigned long long w1 = __hip_atomic_load(q.status + (uint64_t)tp * ND + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((w1 >> 34) == q.epoch) { excl += (uint32_t)w1; tp = ((w1 >> 32) & 3ull) == RS_FLAG_PREFIX ? -1 : tp - 1; }
-                    }
+                    if ((w1[j] >> 34) == q.epoch) { excl += (uint32_t)w1[j]; tp = ((w1[j] >> 32) & 3ull) == RS_FLAG_PREFIX ? -1 : tp - 1; }
+                    // (then a window of RS_LOOK tiles per step: their words are asked for together — the loads do not depend on each other — and taken in order; a word
+                    //  of another pass means "not written yet": the window is asked for again from there)
                     for (; tp >= 0;) {
                         unsigned long long w[RS_LOOK];
 #pragma unroll
@@ -192,25 +224,16 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_pass(RsPassParams q) {
                         }
                         if (done) break;
                     }
+#ifndef RS_DBG_NOSTORE
                     __hip_atomic_store(my, (q.epoch << 34) | (RS_FLAG_PREFIX << 32) | (unsigned long long)(excl + cnt[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                 }
-                s_start[d] = ts;
                 s_gbase[d] = gs + excl - ts;
             }
             ts += cnt[j]; gs += gh[j];
         }
     }
-    __syncthreads();
-    // ---- into digit order in LDS, out in runs of consecutive addresses
-#pragma unroll
-    for (int i = 0; i < RS_IPT; i++) {
-        const int j = wv * RS_WAVE_ITEMS + i * 64 + lane;
-        if (j < n_here) {
-            const uint32_t d = meta[i] >> 16;
-            s_items[s_start[d] + s_cnt[wv][d] + (meta[i] & 0xFFFFu)] = item[i];
-        }
-    }
-    __syncthreads();
+    rs_lds_barrier();
 #pragma unroll
     for (int i = 0; i < RS_IPT; i++) {
         const int j = i * RS_THREADS + threadIdx.x;
@@ -291,8 +314,9 @@ struct ItemSorter {
             q.hist = hist[parity] + (size_t)ps * RS_MAX_DIGITS;
             q.status = status; q.ticket = ticket; q.ticket_base = tickets_used; q.epoch = ++epoch;
             q.clear = ps == 0 ? hist[parity ^ 1] : nullptr; q.n_clear = RS_MAX_PASSES * RS_MAX_DIGITS;
-            if (q.dbits <= 9) hipLaunchKernelGGL((k_rs_pass<1>), dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, q);
-            else hipLaunchKernelGGL((k_rs_pass<2>), dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, q);
+            if (q.dbits <= 8) hipLaunchKernelGGL((k_rs_pass<1>), dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, q);
+            else if (q.dbits == 9) hipLaunchKernelGGL((k_rs_pass<2>), dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, q);
+            else hipLaunchKernelGGL((k_rs_pass<4>), dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, q);
             tickets_used += (unsigned long long)tiles;
             src = q.out;
         }
