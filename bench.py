@@ -360,6 +360,7 @@ def main():
                        "lr_horizon_epochs": 1000, "ring_transport": ring and ring.mode, "update_policy": args.policy, "use_hs": bool(args.hs), "parallelism": ("block schedule x%d: rows split by row %% N, N episodes per global batch, syn1neg partitions passed round a ring" % N if blocks and N > 1
                                        else "SIMULATED rank 0 of a %d-rank block schedule on one GPU (value = this rank's share only)" % NB if blocks
                                        else "walk-shard x%d, RCCL all-reduce of deltas per step (comparison mode)" % N if N > 1 else "1 GPU"),
+                       "lock_stats": model.lock_stats() if blocks else None,      # one block under the lock kernels: pairs put back / rounds that left rows unwon / rounds
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None if (args.dim or args.negative >= 0 or NB > 1) else measured_traffic(args.workload, ("hs_centre" if "hsw" in kernel_name else "hs_pairs") if args.hs else "policy%d" % sched["update_policy"], pairs_per_launch, stamp),

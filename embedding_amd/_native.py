@@ -84,6 +84,7 @@ SIGNATURES = {
     "dge_model_reset_stats": (_int, [_vp]),
     "dge_model_schedule": (_int, [_vp, _P(_i32), _P(_i64), _P(_i32)]),
     "dge_model_kernel": (_int, [_vp, C.c_char_p, _i32]),
+    "dge_model_lock_stats": (_int, [_vp, _P(_i64), _P(_i64), _P(_i64)]),
     "dge_write_vec": (_int, [_vp, _vp, C.c_char_p, _int]),
     "dge_model_free": (None, [_vp]),
     "dge_model_set_partition": (_int, [_vp, _i32, _i32, _i32]),

@@ -773,8 +773,8 @@ extern "C" int dge_model_create(int device, const dge_train_config* cfg, const i
         if (V) MH(hipMemcpyAsync(m->d_hs_codes, m->h_hs_codes.data(), (size_t)V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     }
     MH(hipMemsetAsync(m->d_locks, 0, 2 * ((size_t)V + 1) * sizeof(int), st));
-    MC(dge_dev_alloc(&m->d_counters, 4));       // pairs, words, the lock kernels' walk counter, the lock kernels' watchdog flag
-    MH(hipMemsetAsync(m->d_counters, 0, 4 * sizeof(unsigned long long), st));
+    MC(dge_dev_alloc(&m->d_counters, 8));       // pairs, words, the lock kernels' walk counter, their watchdog flag; the block kernels' lock statistics: pairs put back, rounds that left rows unwon, rounds
+    MH(hipMemsetAsync(m->d_counters, 0, 8 * sizeof(unsigned long long), st));
     MH(hipStreamSynchronize(st));
     MH(hipGetLastError());
 #undef MC
@@ -1629,6 +1629,19 @@ extern "C" int dge_model_schedule(const dge_model* m, int32_t* update_policy, in
     return DGE_OK;
 }
 
+extern "C" int dge_model_lock_stats(const dge_model* mc, int64_t* pairs_put_back, int64_t* rounds_short, int64_t* rounds) {
+    dge_model* m = const_cast<dge_model*>(mc);
+    if (!m) DGE_FAIL(DGE_ERR_ARG, "dge_model_lock_stats: null model");
+    DGE_HIP(hipSetDevice(m->device));
+    DGE_HIP(hipStreamSynchronize(m->stream));
+    unsigned long long c[3] = {0, 0, 0};
+    DGE_HIP(hipMemcpy(c, m->d_counters + 4, sizeof(c), hipMemcpyDeviceToHost));
+    if (pairs_put_back) *pairs_put_back = (int64_t)c[0];
+    if (rounds_short) *rounds_short = (int64_t)c[1];
+    if (rounds) *rounds = (int64_t)c[2];
+    return DGE_OK;
+}
+
 extern "C" int dge_model_kernel(const dge_model* m, char* buf, int32_t cap) {
     if (!m || !buf || cap <= 0) DGE_FAIL(DGE_ERR_ARG, "dge_model_kernel: bad argument");
     if (m->last_policy < 0) DGE_FAIL(DGE_ERR_STATE, "dge_model_kernel: nothing has been trained yet");
@@ -1643,6 +1656,7 @@ extern "C" int dge_model_reset_stats(dge_model* m) {
     // on the model's own stream (a non-blocking one: a null-stream memset is not ordered against it — a short launch right behind reset_stats lost a tenth of
     // its pair count to the memset landing late: tests/test_gpu_quality.py, round 4)
     DGE_HIP(hipMemsetAsync(m->d_counters, 0, 2 * sizeof(unsigned long long), m->stream));
+    DGE_HIP(hipMemsetAsync(m->d_counters + 4, 0, 3 * sizeof(unsigned long long), m->stream));
     DGE_HIP(hipStreamSynchronize(m->stream));
     m->kernel_ms = 0; m->walk_ms = 0; m->launches = 0;
     return DGE_OK;

@@ -1075,6 +1075,9 @@ k_sgns_train_locked(TrainParams p) {
     int* const locks1 = p.locks;
     int* const locks0 = p.locks + p.V + 1;
     const int32_t hot_rows = HOTMIX ? p.hot_rows : 0;
+    // one block of the multi-GPU schedule: how often the lock protocol made this worker wait (dge_model_lock_stats; the block kernels run two waves a SIMD and have the
+    // registers to spare — the one-GPU kernels do not count)
+    unsigned n_aborted = 0, n_short = 0, n_rounds = 0;
 
     uint64_t mA = 1, cA = 0;
     for (int j = 0; j <= lane; j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
@@ -1348,6 +1351,7 @@ k_sgns_train_locked(TrainParams p) {
                 }
                 pend13 &= ~got13;
                 if (gotf) { flush_pending = false; pend_row = -1; if (lane == 13) t = -1; }
+                if (PART) { n_rounds++; if (pend13) n_short++; }
                 if (pend13) {
                     if (WD && lk_timed_out(&s_deadline)) {       // the watchdog: the round's locks have dropped; what is still held is the pair's syn0 row
                         if (lane == 14 && !(HOTMIX && (last < hot_rows || p.syn0_free))) row_unlock<STRICT>(locks0, last);
@@ -1362,6 +1366,7 @@ k_sgns_train_locked(TrainParams p) {
         } while (kd < K && !abort_pair);
         if (WD && i >= len) continue;                      // (gave up inside a round)
         if (abort_pair) {
+            if (PART) n_aborted++;
             if (WD && lk_timed_out(&s_deadline)) { LK_GIVE_UP(); continue; }      // (nothing is held here)
             retry_pair = true;
             __builtin_amdgcn_s_sleep(8);
@@ -1399,6 +1404,7 @@ k_sgns_train_locked(TrainParams p) {
     if (lane == 0) {
         if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
         if (my_words) atomicAdd(&p.counters[1], my_words);
+        if (PART) { atomicAdd(&p.counters[4], (unsigned long long)n_aborted); atomicAdd(&p.counters[5], (unsigned long long)n_short); atomicAdd(&p.counters[6], (unsigned long long)n_rounds); }
         if (use_mb) __hip_atomic_fetch_add(&s_mb_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // (behind this worker's last post)
     }
 }

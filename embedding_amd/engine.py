@@ -373,6 +373,12 @@ class SgnsModel:
         check(lib.dge_model_schedule(self._h, C.byref(pol), C.byref(w), C.byref(hot)))
         return {"update_policy": pol.value, "workers": w.value, "hot_rows": hot.value}
 
+    def lock_stats(self):
+        """{"pairs_put_back", "rounds_short", "rounds"} of the block schedule's lock kernels since reset_stats (include/dge.h: dge_model_lock_stats)."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib.dge_model_lock_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"pairs_put_back": a.value, "rounds_short": b.value, "rounds": c.value}
+
     def kernel(self):
         """Name and form of the trainer kernel the latest launch ran (include/dge.h: dge_model_kernel)."""
         buf = C.create_string_buffer(256)

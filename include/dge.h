@@ -265,6 +265,10 @@ int  dge_model_schedule(const dge_model* m, int32_t* update_policy, int64_t* wor
 /* ... and the trainer kernel (name and form) that launch ran, as text: e.g. "k_sgns_train_locked<relaxed>", "k_sgns_train_hsw<negatives under commit locks, 7 waves> (...)",
  * "k_sorted_phase (owner-computes: ...)".  The policy number alone does not say it (hierarchical softmax has three kernels). */
 int  dge_model_kernel(const dge_model* m, char* buf, int32_t cap);
+/* One block of the multi-GPU schedule under the lock kernels (k_sgns_train_locked<.., PART>), since the last dge_model_reset_stats: pairs that were put back because
+ * their context row's lock was taken, lock rounds that left some wanted row unwon, and lock rounds in all — what a block's speed runs against (a block's live rows are
+ * V / N per table: locks collide N times as often as on one GPU).  The one-GPU kernels do not count (they have no register to spare). */
+int  dge_model_lock_stats(const dge_model* m, int64_t* pairs_put_back, int64_t* rounds_short, int64_t* rounds);
 /* Blocking waits the library has made in this process so far — stream / device / event synchronisations and blocking copies, counted at every call site.  An episode
  * of the multi-GPU block schedule makes none once its buffers exist (tests/test_gpu_distributed.py counts them); a global batch makes two (the item store's sizes). */
 int  dge_host_sync_count(int64_t* n);
