@@ -855,6 +855,9 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
                                             (int32_t)((m->V + p.part_n - 1) / p.part_n), (int32_t)ks1, run_nb);
                 }
                 DGE_HIP(hipGetLastError());
+                // (tried in round 5 and dropped: the store filled on a third stream in eight chunks of walks with an event behind each, so that the batch's first episode starts
+                //  behind the first chunk and the rest is generated beside its phases — same box, A / B: 8.03e8 edges/s per rank of 8 against 8.17 - 8.22e8 with the one
+                //  generator launch in front: as with the sorts, every kernel fills the device and what runs beside the phases slows them by what it takes)
                 DGE_HIP(hipEventRecord(s->ev_store, st));
                 // the mini-batches of every bucket: the batch's second and last read-back
                 s->st_walks_per.assign((size_t)p.part_n, 1); s->st_marks.assign((size_t)p.part_n, std::vector<int64_t>());
