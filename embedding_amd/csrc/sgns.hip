@@ -1101,7 +1101,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     const bool big_tables = (uint64_t)m->V * (uint64_t)m->stride * 4ull >= 0xFFFFFFFFull || g_dge_tuning[DGE_TUNE_FORCE_SEGMENTS] > 0;
     // (from 65 536 vocabulary rows on, like the atomics wave below: on the reference's own 6 408-row tract vocabulary the walks in flight are capped by the
     //  vocabulary — 801 waves — and the pair-by-pair kernel's 3 204 groups are faster: 1.64e8 against 1.22e8 edges/s; DGE_TUNE_HS_CENTRE = 1 forces it)
-    if (pol == 12 && workers > 1 && m->stride <= 128 && L <= 64 && !big_tables &&
+    if (pol == 12 && workers > 1 && m->stride <= 256 && L <= 64 && !big_tables &&
         (g_dge_tuning[DGE_TUNE_HS_CENTRE] > 0 || (g_dge_tuning[DGE_TUNE_HS_CENTRE] < 0 && m->V >= 65536))) {
         // Hierarchical softmax, a wave per centre (k_sgns_train_hsw, round 4): the centre's path nodes stay in the registers of a wave's four groups for all
         // its contexts and their gathered updates leave once per centre.  `workers` = walks in flight = waves that train: two resident workgroups of three
@@ -1112,12 +1112,18 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // gathered syn1neg update go under the rows' locks instead of out as atomics (k_sgns_train_hsw<.., NLOCK>) — in ONE workgroup of seven training waves a
         // compute unit, which share their LDS accumulators (DGE_TUNE_HS_CENTRE: 1 keeps atomics, 2 = locks in workgroups of three waves, 3 = of seven)
         const int64_t centre_knob = g_dge_tuning[DGE_TUNE_HS_CENTRE];
-        if (centre_knob == 2 || centre_knob == 3 || (centre_knob < 0 && m->cfg.update_policy == 0 && syn1neg_locks_work(m))) {
-            pol = centre_knob == 2 ? 14 : 15;
+        // ... and on a SKEWED vocabulary whose head the mixed policy 7 would take out of the lock protocol (round 5): the same kernel with that head by atomics, the tail's
+        // negatives under locks (p.hot_rows; DGE_TUNE_HOT_ROWS sets it by hand)
+        const bool mixed_ok = m->V >= 131072 && (int64_t)(48.0 / std::max(m->row_share_max, 1e-12)) >= 4096 && std::max(m->hot_rows_auto, m->hot_rows_serial) <= m->V / 4;
+        if (centre_knob == 2 || centre_knob == 3 || (centre_knob < 0 && m->cfg.update_policy == 0 && (syn1neg_locks_work(m) || mixed_ok))) {
+            const bool mixed = !syn1neg_locks_work(m) && mixed_ok && centre_knob < 0;
+            pol = (centre_knob == 2 || m->stride > 128 || mixed) ? 14 : 15;      // (rows of more than 128 floats: three-wave workgroups only — seven waves' message boxes do not fit the LDS; a head by atomics: three waves to an atomics wave, not seven)
             if (pol == 15) nw = 7;
+            if (!syn1neg_locks_work(m) && mixed_ok) p.hot_rows = (int32_t)std::min<int64_t>(std::max(m->hot_rows_auto, m->hot_rows_serial), m->V);
+            if (g_dge_tuning[DGE_TUNE_HOT_ROWS] >= 0) p.hot_rows = (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_HOT_ROWS], m->V);
         }
         if (m->cfg.workers == 0 && !(g_dge_tuning[DGE_TUNE_WORKERS] > 0))
-            workers = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)m->n_cus * (nw == 3 ? 6 : 7), std::max<int64_t>(1, m->V / 8)), std::max<int64_t>(16, (int64_t)(12.0 / std::max(m->row_share_max, 1e-12)))));
+            workers = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)m->n_cus * (nw == 3 ? (m->stride <= 128 ? 6 : 3) : 7), std::max<int64_t>(1, m->V / 8)), std::max<int64_t>(16, (int64_t)(12.0 / std::max(m->row_share_max, 1e-12)))));      // (wide rows: one three-wave workgroup a compute unit)
         workers = std::max<int64_t>(1, std::min<int64_t>(workers, n_rows));
         p.n_workers = workers;
         blocks = (unsigned)((workers + nw - 1) / nw);
@@ -1214,13 +1220,13 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         const bool blk = pol >= 20;
         std::string k;
         if (pol == 13) k = "k_sgns_train_hsw<atomics, 3 waves> (hierarchical softmax, a wave per centre)";
-        else if (pol == 14) k = "k_sgns_train_hsw<negatives under commit locks, 3 waves> (hierarchical softmax, a wave per centre)";
-        else if (pol == 15) k = "k_sgns_train_hsw<negatives under commit locks, 7 waves> (hierarchical softmax, a wave per centre)";
+        else if (pol == 14) k = std::string("k_sgns_train_hsw<negatives under commit locks") + (p.hot_rows > 0 ? ", head rows by atomics" : "") + ", 3 waves> (hierarchical softmax, a wave per centre)";
+        else if (pol == 15) k = std::string("k_sgns_train_hsw<negatives under commit locks") + (p.hot_rows > 0 ? ", head rows by atomics" : "") + ", 7 waves> (hierarchical softmax, a wave per centre)";
         else if (base == 5 || base == 6 || base == 7) k = std::string("k_sgns_train_locked<") + (base == 6 ? "strict" : "relaxed") + (base == 7 ? ", head rows by atomics" : "") + (blk ? ", one block" : "") + ">";
         else k = std::string("k_sgns_train<") + (base == 2 ? "atomics" : (base == 1 ? "row rmw" : "in-order")) + (hs ? ", hierarchical softmax pair by pair" : "") + (blk ? ", one block" : "") + ">";
         m->last_kernel = k;
     }
-    m->last_policy = pol >= 30 ? pol - 30 : (pol >= 20 ? pol - 20 : (pol == 13 ? 2 : (pol == 14 || pol == 15 ? 5 : (pol >= 10 ? pol - 10 : pol)))); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
+    m->last_policy = pol >= 30 ? pol - 30 : (pol >= 20 ? pol - 20 : (pol == 13 ? 2 : (pol == 14 || pol == 15 ? (p.hot_rows > 0 ? 7 : 5) : (pol >= 10 ? pol - 10 : pol)))); m->last_workers = workers; m->last_hot_rows = p.hot_rows;
     DGE_HIP(hipGetLastError());
     return DGE_OK;
 }

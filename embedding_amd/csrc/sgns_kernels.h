@@ -1422,7 +1422,8 @@ k_sgns_train_locked(TrainParams p) {
 // waves do to a node meanwhile is seen at the next centre: Hogwild staleness of one centre's pairs.  The negative-sampling half (positive target in
 // registers per group, K negatives by atomics through the atomics wave, the context row by atomics) is that of k_sgns_train<.., 2, .., HS>, draw for draw.
 // Rows move 16 bytes per lane.  Walks of up to 64 tokens, rows of up to 128 floats, more than one worker; everything else runs k_sgns_train.
-#define HSW_NQ 6                 /* path nodes a group holds in registers: 4 x 6 = the 24 nodes nearest the root; deeper ones (rare, cold) go pair by pair */
+#define HSW_NQ (DCH <= 2 ? 6 : 3) /* path nodes a group holds in registers: 4 x 6 = the 24 nodes nearest the root on rows of up to 128 floats, 4 x 3 = 12 on rows of up to 256 (round 5: the
+                                    same 96 registers); deeper ones go pair by pair */
 template <int DCH>
 __device__ __forceinline__ void hot_addA(float* s_hot, int* s_cnt, int slot, int drain, const TableView& t, int32_t row, int lane, const Row<DCH>& x) {
     float* a = s_hot + slot * (DCH * 64) + 4 * lane;
@@ -1484,9 +1485,10 @@ __device__ __forceinline__ void hsw_add_copies(Row<DCH>& r, int32_t nd, const Ta
 // additions parked device-wide (workgroups x hs_drain) each is drained half as often — the root's row takes every centre's update and its atomics complete one
 // 64-byte request per ~12 ns: at 3.3e8 edges/s and a drain every 4 additions that row alone was busy half the time —, 7 of a compute unit's 8 waves train instead
 // of 6.  (How many accumulators: sgns.hip — fewer than the small workgroups hold turned out better.)
-template <int DCH, bool NLOCK, int NW>
-__global__ void __launch_bounds__((NW + 1) * 64, NW == 3 ? 2 : 1)
+template <int DCH, bool NLOCK, int NW, bool HEAD = false>      // HEAD (with NLOCK): the vocabulary's head [0, p.hot_rows) takes atomics, only the tail's negatives go under locks
+__global__ void __launch_bounds__((NW + 1) * 64, (NW == 3 && DCH <= 2) ? 2 : 1)
 k_sgns_train_hsw(TrainParams p) {
+    const int32_t hot_rows = (NLOCK && HEAD) ? p.hot_rows : 0;
     constexpr int NBOX = NW * 4 * 2;                       // two message boxes per 16-lane group that trains
     __shared__ float s_exp[EXP_TABLE_SIZE];
     __shared__ __attribute__((aligned(16))) float s_mb[NBOX * LkBox<DCH>::FLOATS];
@@ -1604,10 +1606,13 @@ k_sgns_train_hsw(TrainParams p) {
                         if (t == word) t = -1;
                     }
                     sg = shfl16_u64(sl, kc - 1);
+                    // NLOCK: the negatives of the vocabulary's tail under their rows' commit locks; the head rows [0, p.hot_rows) — a skewed vocabulary's, which many
+                    // workers want at once — take atomics like everything does without NLOCK (round 5: the head / tail split of update_policy 7 inside this kernel)
+                    const int32_t t_at = NLOCK ? ((HEAD && t >= 0 && t < hot_rows) ? t : -1) : t;
                     if (NLOCK) {
                         // try-lock rounds over this pair's negatives: the rows won are trained NEG_BATCH at a time under their locks and released before the next
                         // round; nothing is ever waited for while a lock is held (the four groups of the wave loop independently)
-                        unsigned pend = (unsigned)(__ballot(t >= 0) >> (threadIdx.x & 48)) & 0xFFFFu;
+                        unsigned pend = (unsigned)(__ballot(t >= 0 && t >= hot_rows) >> (threadIdx.x & 48)) & 0xFFFFu;
                         while (pend) {
                             const bool want = lane < kc && ((pend >> lane) & 1u);
                             const bool won = want ? row_trylock(p.locks, t) : false;
@@ -1636,13 +1641,15 @@ k_sgns_train_hsw(TrainParams p) {
                             pend &= ~got;
                             if (pend) __builtin_amdgcn_s_sleep(2);
                         }
-                    } else {
+                    }
+                    if ((!NLOCK || HEAD) && ((unsigned)(__ballot(t_at >= 0) >> (threadIdx.x & 48)) & 0xFFFFu)) {
                     float mb_g = 0.f;
                     for (int b0 = 0; b0 < kc; b0 += NEG_BATCH) {
                         int32_t tg[NEG_BATCH];
                         Row<DCH> rr[NEG_BATCH];
 #pragma unroll
-                        for (int q = 0; q < NEG_BATCH; q++) { const int32_t v = __shfl(t, (b0 + q) & 15, 16); tg[q] = (b0 + q < kc) ? v : -1; }
+                        for (int q = 0; q < NEG_BATCH; q++) { const int32_t v = __shfl(t_at, (b0 + q) & 15, 16); tg[q] = (b0 + q < kc) ? v : -1; }
+                        if (NLOCK) { bool any = false; _Pragma("unroll") for (int q = 0; q < NEG_BATCH; q++) any |= tg[q] >= 0; if (!any) continue; }
 #pragma unroll
                         for (int q = 0; q < NEG_BATCH; q++) rowA_load<DCH, 16, false>(rr[q], syn1neg, tg[q] >= 0 ? tg[q] : p.filler_row, lane);
 #pragma unroll
@@ -1654,7 +1661,7 @@ k_sgns_train_hsw(TrainParams p) {
                                 if (lane == b0 + q) mb_g = g;
                             }
                     }
-                    if ((unsigned)(__ballot(t >= 0) >> (threadIdx.x & 48)) & 0xFFFFu) lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, t, mb_g, l1, lane);
+                    lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, t_at, mb_g, l1, lane);
                     }
                 }
                 for (int z = 0; z < n_here; z++) s = s * mK + cK;         // the centre's stream behind this round's pairs
@@ -1678,7 +1685,7 @@ k_sgns_train_hsw(TrainParams p) {
                                 row_axpy(part, g, S[q]); row_axpy(S[q], g, lj); row_axpy(dS[q], g, lj);
                             }
                         }
-                    for (int k = 4 * HSW_NQ + grp; k < P; k += 4) {        // beyond the 24 nodes in registers: the deepest nodes of a long path, pair by pair —
+                    for (int k = 4 * HSW_NQ + grp; k < P; k += 4) {        // beyond the 24 (12) nodes in registers: the deepest nodes of a long path, pair by pair —
                         const int32_t nd = p.hs_points[hs_o + k];          // cold ones as a rule, but a chain-like tree (very skewed counts) has busy nodes down there too:
                         Row<DCH> r;                                        // each node is updated the way its class is updated everywhere else
                         rowA_load<DCH, 16, false>(r, syn1, nd, lane);
@@ -1719,7 +1726,8 @@ k_sgns_train_hsw(TrainParams p) {
                     dh.v[cc].x += __shfl_xor(dh.v[cc].x, 32, 64); dh.v[cc].y += __shfl_xor(dh.v[cc].y, 32, 64);
                     dh.v[cc].z += __shfl_xor(dh.v[cc].z, 32, 64); dh.v[cc].w += __shfl_xor(dh.v[cc].w, 32, 64);
                 }
-                if (grp == 0)
+                if (HEAD && grp == 0 && word < hot_rows) lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, lane == 0 ? word : -1, 1.0f, dh, lane);      // (a head row: never locked)
+                else if (grp == 0)
                     for (;;) {
                         const bool won = lane == 0 ? row_trylock(p.locks, word) : false;
                         if (__shfl((int)won, 0, 16)) {
@@ -1767,13 +1775,23 @@ static inline void launch_train_b(const TrainParams& p, int pol, unsigned blocks
         case 1: hipLaunchKernelGGL((k_sgns_train<DCH, 1, BIG, false, false>), dim3(blocks), dim3(threads), 0, st, p); break;
         case 10: hipLaunchKernelGGL((k_sgns_train<DCH, 0, BIG, true, false>), dim3(blocks), dim3(threads), 0, st, p); break;    // + hierarchical softmax
         case 12: hipLaunchKernelGGL((k_sgns_train<DCH, 2, BIG, true, false>), dim3(blocks), dim3(threads), shmem, st, p); break;
-        case 13: if constexpr (DCH <= 2 && !BIG) hipLaunchKernelGGL((k_sgns_train_hsw<DCH, false, 3>), dim3(blocks), dim3(threads), shmem, st, p); break;   // hierarchical softmax, a wave per centre
-        case 14: if constexpr (DCH <= 2 && !BIG) hipLaunchKernelGGL((k_sgns_train_hsw<DCH, true, 3>), dim3(blocks), dim3(threads), shmem, st, p); break;    // ... the negatives under commit locks
+        case 13: if constexpr (DCH <= 4 && !BIG) hipLaunchKernelGGL((k_sgns_train_hsw<DCH, false, 3>), dim3(blocks), dim3(threads), shmem, st, p); break;   // hierarchical softmax, a wave per centre
+        case 14:                                                                                                                                             // ... the negatives under commit locks
+            if constexpr (DCH <= 4 && !BIG) {
+                if (p.hot_rows > 0) hipLaunchKernelGGL((k_sgns_train_hsw<DCH, true, 3, true>), dim3(blocks), dim3(threads), shmem, st, p);                   // (a skewed vocabulary: its head by atomics)
+                else hipLaunchKernelGGL((k_sgns_train_hsw<DCH, true, 3>), dim3(blocks), dim3(threads), shmem, st, p);
+            }
+            break;
         case 15:                                                                                                                                             // ... seven such waves a workgroup
             if constexpr (DCH <= 2 && !BIG) {
                 // (the workgroup's 41 KB of static LDS and these up to 60 KB together pass 64 KB: asked for per kernel; an error comes back from the launch)
-                (void)hipFuncSetAttribute((const void*)k_sgns_train_hsw<DCH, true, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-                hipLaunchKernelGGL((k_sgns_train_hsw<DCH, true, 7>), dim3(blocks), dim3(threads), shmem, st, p);
+                if (p.hot_rows > 0) {
+                    (void)hipFuncSetAttribute((const void*)k_sgns_train_hsw<DCH, true, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                    hipLaunchKernelGGL((k_sgns_train_hsw<DCH, true, 7, true>), dim3(blocks), dim3(threads), shmem, st, p);
+                } else {
+                    (void)hipFuncSetAttribute((const void*)k_sgns_train_hsw<DCH, true, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                    hipLaunchKernelGGL((k_sgns_train_hsw<DCH, true, 7>), dim3(blocks), dim3(threads), shmem, st, p);
+                }
             }
             break;
         case 5:
