@@ -41,17 +41,17 @@ def test_cfg1_reference_sized_graph_tables_and_walks_bit_exact(cfg1):
 
 def test_cfg1_full_replay_one_worker_bit_exact_and_hogwild(cfg1, dge, oracle):
     """w2v.fit() with the reference's builder values (J/DeepWalk.java:73-76: layerSize 20, windowSize 8, negativeSample 5,
-    minWordFrequency 2, one iteration) on all 156 k walks: one in-order worker reproduces the oracle's tables bit for bit; the
+    minWordFrequency 2, one iteration) on 110 k walks (1/140 of the reference's 15.6 M; round 4 ran 156 k: 25 s of the suite): one in-order worker reproduces the oracle's tables bit for bit; the
     device-filling Hogwild run trains the same pairs and stays at least as close to the sequential result as the oracle's own
     8-thread Hogwild (.workers(8), :75) does."""
     G, og, dg = cfg1
-    walks = dg.sample_walks(156_000, 8, seed=2013, rng_mode=0)
+    walks = dg.sample_walks(110_000, 8, seed=2013, rng_mode=0)
     NV = 801 * 8
     kw = dict(negative=5, min_count=2, epochs=1, seed=7, table_size=1_000_003)
     o1 = oracle.train_sgns(walks, NV, 20, 8, threads=1, arith=1, **kw)
     d1 = dge.SgnsModel.fit(walks, dge.make_config(20, 8, NV, workers=1, **kw), 0)
     s0, vid = d1.vectors()
-    assert o1.V == NV and np.array_equal(vid, o1.vocab_ids) and d1.stats()["pairs"] == o1.pairs and 6.0e6 < o1.pairs < 7.2e6
+    assert o1.V >= NV - 3 and np.array_equal(vid, o1.vocab_ids) and d1.stats()["pairs"] == o1.pairs and 4.2e6 < o1.pairs < 5.1e6
     assert np.array_equal(bits(s0), bits(o1.syn0)) and np.array_equal(bits(d1.syn1neg()), bits(o1.syn1neg))
     # Hogwild: the device (auto schedule on a 6 408-row vocabulary) against the oracle's 8 threads
     dh = dge.SgnsModel.fit(walks, dge.make_config(20, 8, NV, workers=0, **kw), 0)
@@ -92,7 +92,7 @@ def test_cfg5_shaped_graph_and_one_worker_mixed_policy(cfg5_small, dge, oracle):
         a, b = og.get_alias(v), dg.get_alias(v)
         assert np.array_equal(a["alias"], b["alias"]) and np.array_equal(bits(a["prob"]), bits(b["prob"])), v
     assert np.array_equal(og.sample_walks(20_000, 24, seed=5, rng_mode=1), dg.sample_walks(20_000, 24, seed=5, rng_mode=1))
-    walks = dg.sample_walks(2500, 24, seed=5, rng_mode=1)
+    walks = dg.sample_walks(1500, 24, seed=5, rng_mode=1)
     NV = 4166 * 24
     kw = dict(negative=20, min_count=2, epochs=1, seed=3, table_size=1_000_003)
     om = oracle.train_sgns(walks, NV, 256, 24, threads=1, arith=0, **kw)

@@ -31,7 +31,7 @@ pytestmark = pytest.mark.gpu
 
 T, L, D, K = 24, 24, 128, 5
 N_SLICE = 30_000
-N_HS = 8_000          # walks of the hierarchical-softmax leg (the sequential oracle trains ~20 inner nodes a pair on top of the 6 rows)
+N_HS = 5_000          # walks of the hierarchical-softmax leg (the sequential oracle trains ~20 inner nodes a pair on top of the 6 rows)
 
 
 def _host_loss(syn0, syn1neg, vocab_ids, test_walks, R, seed=3):
@@ -89,7 +89,7 @@ def runs(dge, oracle):
         st, sch = m.stats(), m.schedule()
         s0_d = m.vectors()[0]; s1_d = m.syn1neg()
         # The slice is 1/33 of a bench launch (30 000 of 1 000 008 walks).  Device-filling workers (~12 000) then hold a THIRD of the slice in flight at any
-        # moment (3 walks each), a bench launch 1 %.  On the flat graph that changes nothing measurable; on the Zipf graph the head rows take a third of
+        # moment (3 walks each), a bench launch 1 %.  (Round 5 tried a 15 000-walk slice to save suite time: two thirds in flight, the device-filling Zipf leg lost 0.02 of AUC.)  On the flat graph that changes nothing measurable; on the Zipf graph the head rows take a third of
         # the slice's updates from one stale value.  So the slice is also trained with 1/33 of the workers — the same ~100 walks per worker as a launch:
         prop = None
         if name == "zipf":
@@ -188,7 +188,7 @@ def test_hierarchical_softmax_launch_against_the_sequential_oracle(runs):
     seq, cpu8 = h["seq"], h["cpu8"]
     b0, b1, b2 = h["before"]
     R, vid, test = o["R"], o["vid"], o["test"]
-    assert seq.pairs == cpu8.pairs > 2.0e6 and np.array_equal(seq.vocab_ids, o["vid"])
+    assert seq.pairs == cpu8.pairs > 1.5e6 and np.array_equal(seq.vocab_ids, o["vid"])
     # the long training ran the kernel auto picks at device-filling concurrency: a wave per centre, negatives under commit locks (reported as the locks, 5)
     assert h["sch_long"]["update_policy"] == 5 and h["sch_long"]["workers"] >= 1000 and h["pairs_long"] == o["st_long_pairs"], h["sch_long"]
     res = {}

@@ -591,7 +591,7 @@ def test_hierarchical_softmax_lds_combining_conserves_updates(dge, oracle, monke
         assert np.abs(na[busy] / nb[busy] - 1).max() < tol, drain
 
 
-@pytest.mark.parametrize("dim,negative,window", [(20, 5, 8), (128, 5, 24), (64, 20, 5), (100, 0, 24), (256, 5, 24), (160, 3, 12)])      # (rows of 129 .. 256 floats: 12 path nodes in registers, round 5)
+@pytest.mark.parametrize("dim,negative,window", [(20, 5, 8), (128, 5, 24), (64, 20, 5), (100, 0, 24), (256, 5, 24)])      # (256: rows of 129 .. 256 floats keep 12 path nodes in registers, round 5)
 def test_hierarchical_softmax_wave_per_centre_linear_regime(dge, oracle, dim, negative, window):
     """k_sgns_train_hsw (a wave per centre; the centre's path nodes in the registers of its four groups, their gathered updates leaving once per centre)
     with Huffman paths that reach beyond the 24 nodes a wave holds (geometric counts: the rare words sit ~35 levels deep, the deeper nodes go pair by
@@ -614,7 +614,10 @@ def test_hierarchical_softmax_wave_per_centre_linear_regime(dge, oracle, dim, ne
     d_counts = torch.from_numpy(counts).to("cuda:0")
     # (the wave-per-centre kernel keeps the busiest inner nodes in copies; hs_hot_kb > 0 = its first form, LDS accumulators, kept for comparison)
     # (hot_rows: the lock forms with the vocabulary's head — here the 40 most frequent rows — by atomics, what auto takes on a skewed vocabulary: round 5)
-    for centre, extra in ((3, {}), (3, {"hs_hot_kb": 15}), (2, {}), (1, {}), (1, {"hs_hot_kb": 30}), (0, {}), (2, {"hot_rows": 40}), (3, {"hot_rows": 40})):
+    forms = ((3, {}), (3, {"hs_hot_kb": 15}), (2, {}), (1, {}), (1, {"hs_hot_kb": 30}), (0, {}), (2, {"hot_rows": 40}), (3, {"hot_rows": 40}))
+    if dim > 128 or negative >= 20:        # (the LDS-accumulator comparison forms on the other cases only; wide rows have no seven-wave form: 3 = 2 there)
+        forms = ((2, {}), (1, {}), (0, {}), (2, {"hot_rows": 40})) + (((3, {"hot_rows": 40}),) if dim <= 128 else ())
+    for centre, extra in forms:
         # (hs_cold = 0: the "cold" class — plain read-modify-write for inner nodes on < 2e-5 of the paths BY THE COUNTS — assumes the corpus follows the
         #  counts; these artificial counts do not, the bushy tail is visited all the time)
         with dge.tuning(hs_centre=centre, hs_cold=0, **extra):
