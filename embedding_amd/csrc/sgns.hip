@@ -1287,6 +1287,7 @@ extern "C" int dge_train_sgns_device(const dge_walks* w, const dge_train_config*
     }
     for (int ep = 0; ep < cfg->epochs && !rc; ep++) rc = dge_model_train(m, w, 0, w->n, 0, ep, 0, 1.0, w->n);
     if (!rc) { hipError_t e = hipStreamSynchronize(m->stream); if (e != hipSuccess) { dge_set_error("training failed: %s", hipGetErrorName(e)); rc = DGE_ERR_DEVICE; } }
+    if (!rc) { dge_train_stats st; rc = dge_model_stats(m, &st); }      // (a launch ended by the lock kernels' watchdog is an error of the fit, not a model)
     if (rc) { dge_model_free(m); return rc; }
     *out = m;
     return DGE_OK;

@@ -49,7 +49,7 @@ typedef struct dge_model dge_model;   /* vocabulary + syn0/syn1neg tables, resid
 
 const char* dge_last_error(void);
 int  dge_version(void);
-/* "kernels=<hash> sorted=<hash>": 12 hex digits of the SHA-1 of the trainer kernels' sources this library was built from (sgns_kernels.h + dge_algos.h;
+/* "kernels=<hash> sorted=<hash>": 12 hex digits of the SHA-1 of the trainer kernels' sources this library was built from (sgns_kernels.h + dge_algos.h + sgns.hip — the kernels and the host file that picks their launch geometry and policy;
    the same + sgns_sorted.hip).  The committed counter profiles (profiles/traffic.json) carry the stamp of the build they were collected with; bench.py
    quotes a profile's bytes per pair only when the stamp matches the loaded library. */
 const char* dge_build_stamp(void);
