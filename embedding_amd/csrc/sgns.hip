@@ -965,7 +965,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
             const double mb_items = std::min((double)(1 << 20), launch_pairs * (double)(m->cfg.negative + 1));
             if (hottest * mb_items > 8192.0)
                 DGE_FAIL(DGE_ERR_ARG, "update_policy 8 (owner-computes) on this vocabulary: its busiest row holds %.2g of the terms, ~%.0f of one synchronous mini-batch "
-                         "with no feedback between them (the schedule keeps that below 2048; beyond, the tables diverge): use update_policy 0 (auto), 2 or 7", hottest, hottest * mb_items);
+                         "with no feedback between them (the schedule keeps that below 4096; far beyond, the tables diverge): use update_policy 0 (auto), 2 or 7", hottest, hottest * mb_items);
         }
         EventPair ev;
         if ((rc = timing_begin(m, ev, 0))) return rc;

@@ -697,14 +697,18 @@ static void launch_finish_any(int dch, const SortedParams& q, hipStream_t st) {
 // the link-prediction AUC equals the atomics schedule's up to ~120 items per row and mini-batch, slips by 0.001 per ~70 items beyond and
 // collapses between 320 and 390 (8 ranks: 73 ms per episode at 128 items per row, 69 at 256 — not worth the margin) —
 // and the HOTTEST row counts, not the average one: on a Zipf-popular graph a head row took > 1e5 terms of a 96-per-row mini-batch and
-// the tables went to NaN within an epoch.  Hence: 128 items per live row, at most 2048 for the hottest row, and no mini-batch below 5e5
+// the tables went to NaN within an epoch.  Hence: 128 items per live row, at most 4096 for the hottest row, and no mini-batch below 5e5
 // items (the two sorts and ~16 launches per mini-batch need that much to pay): 0 = this vocabulary is too skewed or too small.
 int64_t dge_sorted_batch_items(const dge_model* m, int part_n) {
     const int n = std::max(part_n, 1);
     const int64_t live_rows = std::max<int64_t>(1, m->V / n);
     const double hottest = std::min(1.0, m->row_share_max * (double)n);      // its share of one block's terms
     int64_t items = std::min<int64_t>(96ll << 20, 128 * live_rows);
-    items = std::min<int64_t>(items, (int64_t)(2048.0 / std::max(hottest, 1e-12)));
+    // (round 5: 4 096 for the busiest row, was 2 048 — on cfg3 that bound was the one that bound (its busiest vertex holds 30x the mean count: 8.8 M items where the
+    //  128-a-row rule allows 16 M) and an epoch of the cfg3-sized community graph on 8 ranks ends at the same AUC 0.9596 / loss 0.474 with 18 M-item mini-batches — the
+    //  busiest row at ~4 200 terms — as with 9 M, 10 % faster; 36 M (a whole episode, 288 a row) loses it: 0.9565 / 0.497.  scripts/blocks_minibatch_quality.py,
+    //  profiles/r05_blocks_minibatch_quality.txt)
+    items = std::min<int64_t>(items, (int64_t)(4096.0 / std::max(hottest, 1e-12)));
     // (wide rows: from half a million items on — round 4: a 50 000-row vocabulary with rank^-0.5 popularity lands at 0.9 M and ran 3.4e8 edges/s at D = 256 under this
     //  schedule against 2.1e8 under the atomics the rule used to leave it with: scripts/policy_sweep.py)
     //  — on rows of more than 128 floats: with D = 64 the same vocabulary runs 7.9e8 under atomics against 4.2e8 here; the sorts do not shrink with the row)
@@ -783,8 +787,8 @@ int dge_sorted_train(dge_model* m, const TrainParams& p) {
         int64_t wp = std::max<int64_t>(1, (int64_t)((double)want_items / std::max(items_per_walk, 1e-9)));
         if (g_dge_tuning[DGE_TUNE_SORTED_WALKS] > 0) return std::min<int64_t>(g_dge_tuning[DGE_TUNE_SORTED_WALKS], p.n_rows);
         wp = std::min(wp, p.n_rows);
-        // (an eighth over the target is allowed where it saves a mini-batch — the target's constants, 128 items a row and 2 048 for the busiest, are not that sharp:
-        //  one rank of 8 on cfg3 trains an episode's 36 M items in four mini-batches of 9.0 M instead of five of 7.2 M against a target of 8.8 M)
+        // (an eighth over the target is allowed where it saves a mini-batch — the target's constants, 128 items a row and 4 096 for the busiest, are not that sharp:
+        //  one rank of 8 on cfg3 trains an episode's 36 M items in (as measured with the round's first bound of 2 048 for the busiest row) four mini-batches of 9.0 M instead of five of 7.2 M against a target of 8.8 M)
         const int64_t n_mb = std::max<int64_t>(1, (p.n_rows * 8 + wp * 9 - 1) / (wp * 9));
         return (p.n_rows + n_mb - 1) / n_mb;
     };

@@ -160,7 +160,7 @@ typedef struct dge_train_config {
                                     (workers x p_row <= 0.5: such rows alone leave the locks, 7); 7 when a head of at most V/4 rows carries
                                     the skew; otherwise (a small vocabulary, a head too large, a block of a schedule of
                                     >= 2 ranks on a flat vocabulary) 8 when the tables are below 4 GiB and a synchronous mini-batch of >= 1e6 items
-                                    (5e5 on rows of > 128 floats) keeps the busiest row below 2048 terms; else 2.  A vocabulary whose busiest row
+                                    (5e5 on rows of > 128 floats) keeps the busiest row below 4096 terms; else 2.  A vocabulary whose busiest row
                                     caps the workers below a quarter of the device (48 / its share of the tokens < 4096) runs under 2; the workers of any Hogwild launch are capped so that at most 96 of one row's updates are in flight (profiles/r05_hot_row_inflight.txt).
                                     The constants come from scripts/policy_sweep.py (profiles/r04_policy_sweep.txt);
                                 1 = agent-scope row read-modify-write, write-through (last writer of a row wins);
