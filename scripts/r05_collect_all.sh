@@ -2,7 +2,7 @@
 # round 5: every committed profile of the round in one go, with the round's final build (the stamps of profiles/traffic.json follow the loaded library)
 set -x
 TRAFFIC_KEY=cfg3/policy5 TRAFFIC_X2="k_sgns_train_locked" bash scripts/collect_profiles.sh r05_cfg3 k_sgns_train_locked > /dev/null 2>&1
-TRAFFIC_KEY=cfg2/policy8 bash scripts/collect_profiles.sh r05_cfg2 "k_sorted\|rocprim\|k_block" --workload cfg2 > /dev/null 2>&1
+TRAFFIC_KEY=cfg2/policy8 TRAFFIC_X2="k_sorted_phase|k_sorted_finish" bash scripts/collect_profiles.sh r05_cfg2 "k_sorted|rocprim|k_block" --workload cfg2 > /dev/null 2>&1
 TRAFFIC_KEY=cfg3/hs_centre TRAFFIC_X2="k_sgns_train_hsw" bash scripts/collect_profiles.sh r05_hs k_sgns_train_hsw --hs > /dev/null 2>&1
 TRAFFIC_KEY=cfg3_zipf/policy7 TRAFFIC_X2="k_sgns_train_locked" bash scripts/collect_profiles.sh r05_cfg3_zipf k_sgns_train_locked --workload cfg3_zipf > /dev/null 2>&1
 TRAFFIC_KEY=cfg5/policy7 TRAFFIC_X2="k_sgns_train_locked" bash scripts/collect_profiles.sh r05_cfg5 k_sgns_train_locked --workload cfg5 > /dev/null 2>&1
