@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--sim-ranks", type=int, default=0,
                     help="single process: run rank 0's share of an N-rank block-schedule step (its N episodes over the N-fold batch, "
                          "partition pack/unpack included, no network) to estimate per-rank throughput at N ranks")
+    ap.add_argument("--sim-rank", type=int, default=0, help="with --sim-ranks: which rank's episodes to run (its syn0 partition; default 0, the busiest rows' owner)")
+    ap.add_argument("--sim-episode-times", action="store_true",
+                    help="with --sim-ranks: after the timed steps, one more step with a host wait per episode; kernel ms and pairs of every block go to stderr (diagnostic)")
     ap.add_argument("--dim", type=int, default=0, help="override the workload's embedding dimension (experiments)")
     ap.add_argument("--negative", type=int, default=-1, help="override the workload's negative count (experiments)")
     ap.add_argument("--hs", action="store_true", help="train the hierarchical-softmax term as well (dge_train_config.use_hs; not the headline path)")
@@ -260,6 +263,8 @@ def main():
         row_rates = model.row_rates()        # this model's own tables: random rows read / read + written back (GB/s), lock exchanges, table look-ups per s
     setup_s = time.time() - t0
 
+    episode_log = None
+
     def step_blocks(i):
         first = (i * BG) % max(epoch_walks - BG + 1, 1)        # global index of the batch's first walk
         state = {"sampled": False}
@@ -275,12 +280,19 @@ def main():
         if N > 1:
             block_schedule_step(model, train_fn, N, rank, part_buf, recv_buf, transport=ring)
         else:                                                  # --sim-ranks: rank 0's episodes, exchange replaced by a local pack/unpack
+            r0 = args.sim_rank % NB
             for e in range(NB):
-                model.set_partition(NB, 0, e % NB)
+                t_part = (r0 + e) % NB
+                model.set_partition(NB, r0, t_part)
+                if episode_log is not None:
+                    before = model.stats()
                 train_fn()
+                if episode_log is not None:
+                    after = model.stats()
+                    episode_log.append((r0, t_part, after["kernel_ms"] - before["kernel_ms"], after["pairs"] - before["pairs"]))
                 ms = model.stream()                          # (pack and unpack stay on the library's stream, as a hand-off's would; no host wait)
-                model.export_partition_async(1, NB, e % NB, part_buf, ms)
-                model.import_partition_async(1, NB, e % NB, part_buf, ms)
+                model.export_partition_async(1, NB, t_part, part_buf, ms)
+                model.import_partition_async(1, NB, t_part, part_buf, ms)
             model.set_partition(1)
 
     def step(i):
@@ -309,6 +321,13 @@ def main():
     sync()
     dt = time.perf_counter() - t1
     st = model.stats()
+    if blocks and N == 1 and args.sim_episode_times:
+        episode_log = []
+        step(args.warmup + args.steps)
+        for r0, t_part, ms_e, pairs_e in episode_log:
+            print("[bench] block (syn0 partition %d, syn1neg partition %d): %8.2f ms  %10d pairs  %.3e pairs/s" % (r0, t_part, ms_e, pairs_e, pairs_e / max(ms_e, 1e-9) * 1e3),
+                  file=sys.stderr, flush=True)
+        episode_log = None
 
     pairs = torch.tensor([float(st["pairs"])], dtype=torch.float64, device=dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)

@@ -111,6 +111,7 @@ SIGNATURES = {
     "dge_knn_cosine": (_int, [_int, _vp, _i32, _i32, _i32, _vp, _vp, _P(_dbl)]),
     "dge_selftest_locked_rows": (_int, [_int, _i32, _i64, _i32, C.c_uint64, _i32, _P(_i64), _P(_dbl)]),
     "dge_selftest_atomics_wave": (_int, [_int, _i32, _i32, _i32, _i32, _i32, C.c_uint64, _P(_i64), _P(_dbl)]),
+    "dge_selftest_atomics_wave_block": (_int, [_int, _i32, _i32, _i32, _i32, _i32, _i32, C.c_uint64, _P(_i64), _P(_dbl)]),
     "dge_selftest_fmt_g9": (_int, [_i64, C.c_uint64, _P(_i64), _P(_i64)]),
     "dge_selftest_hot_add": (_int, [_int, _i32, _i64, _i32, _i32, C.c_uint64, _P(_i64), _P(_dbl)]),
 }

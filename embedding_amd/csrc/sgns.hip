@@ -381,22 +381,29 @@ extern "C" int dge_selftest_locked_rows(int device, int32_t n_rows, int64_t n_wo
 // The atomics wave in isolation (lk_post / lk_atomics_wave with its LDS accumulators of the hottest rows): the 12 workers of every workgroup post
 // messages "add 1.0 to every element of these rows" — half of the rows among the n_acc hottest — and afterwards every element of row r must equal
 // the number of times r was posted (counted with integer atomics; integers < 2^24 are exact in float): nothing parked in LDS may be lost or added twice.
-__global__ void __launch_bounds__(256) k_selftest_atomics_wave(float* table, unsigned long long* counts, int32_t n_rows, int stride, int iters, uint64_t seed, int n_acc, int drain) {
+// Messages alternate between kind 1 (syn1neg: bank 0) and kind 2 (syn0: bank 1); with div > 1 the rows are those of one block of a div-rank schedule:
+// kind 1 rows = 1 (mod div), kind 2 rows = div - 1 (mod div), a slot = the row's rank inside its partition.
+__global__ void __launch_bounds__(256) k_selftest_atomics_wave(float* table, unsigned long long* counts, int32_t n_rows, int stride, int iters, uint64_t seed, int n_acc, int drain, int div) {
     constexpr int DCH = 2;
     __shared__ __attribute__((aligned(16))) float s_mb[LK_MB_WORKERS * 2 * LkBox<DCH>::FLOATS];
     __shared__ int s_mb_flag[LK_MB_WORKERS * 2];
     __shared__ int s_mb_done;
-    __shared__ float s_acc[LK_ACC_ROWS(DCH) * DCH * 64];
-    __shared__ int s_acc_cnt[LK_ACC_ROWS(DCH)];
+    __shared__ float s_acc[2 * LK_ACC_ROWS(DCH) * DCH * 64];
+    __shared__ int s_acc_cnt[2 * LK_ACC_ROWS(DCH)];
     if (threadIdx.x < LK_MB_WORKERS * 2) s_mb_flag[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_mb_done = 0;
-    for (int i = threadIdx.x; i < LK_ACC_ROWS(DCH) * DCH * 64; i += blockDim.x) s_acc[i] = 0.f;
-    if (threadIdx.x < LK_ACC_ROWS(DCH)) s_acc_cnt[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 2 * LK_ACC_ROWS(DCH) * DCH * 64; i += blockDim.x) s_acc[i] = 0.f;
+    if (threadIdx.x < 2 * LK_ACC_ROWS(DCH)) s_acc_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 15, wk = threadIdx.x >> 4;
     TableView tv = make_view(table, n_rows, stride);
     tv.valid = (uint32_t)stride;
-    if (wk >= LK_MB_WORKERS) { lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, LK_MB_WORKERS, tv, tv, tv, s_acc, s_acc_cnt, min(n_acc, LK_ACC_ROWS(DCH)), max(drain, 1)); return; }
+    const int part_tgt = 1 % div, part_ctx = div - 1, n_part = n_rows / div;       // (rows of a partition: part, part + div, ... — n_rows >= div)
+    if (wk >= LK_MB_WORKERS) {
+        const int n = min(n_acc, LK_ACC_ROWS(DCH));
+        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, LK_MB_WORKERS, tv, tv, tv, LkAcc{s_acc, s_acc_cnt, n, n, max(drain, 1), div, part_tgt, part_ctx});
+        return;
+    }
     unsigned n_posts = 0;
     Row<DCH> ones;
 #pragma unroll
@@ -406,17 +413,23 @@ __global__ void __launch_bounds__(256) k_selftest_atomics_wave(float* table, uns
         int32_t row = -1;
         if (lane < NEG_BATCH) {
             const uint64_t hsh = dge_mix64(seed + (uint64_t)((worker * iters + it) * 16 + lane));
-            row = (int32_t)((hsh & 1ull) ? (hsh >> 1) % (uint64_t)min(8, n_rows) : (hsh >> 1) % (uint64_t)n_rows);
+            const int32_t rank = (int32_t)((hsh & 1ull) ? (hsh >> 1) % (uint64_t)min(8, n_part) : (hsh >> 1) % (uint64_t)n_part);
+            row = rank * div + ((it & 1) ? part_ctx : part_tgt);
             atomicAdd(&counts[row], 1ULL);
         }
-        lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, 1, row, 1.0f, ones, lane);
+        lk_post<DCH>(s_mb, s_mb_flag, wk, n_posts, (it & 1) ? 2 : 1, row, 1.0f, ones, lane);
     }
     if (lane == 0) __hip_atomic_fetch_add(&s_mb_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 extern "C" int dge_selftest_atomics_wave(int device, int32_t n_rows, int32_t n_acc, int32_t drain, int32_t blocks, int32_t iters, uint64_t seed,
                                          int64_t* total_updates, double* max_abs_error) {
-    if (n_rows <= 0 || blocks <= 0 || iters <= 0 || n_acc < 0 || drain <= 0 || !total_updates || !max_abs_error) DGE_FAIL(DGE_ERR_ARG, "dge_selftest_atomics_wave: bad argument");
+    return dge_selftest_atomics_wave_block(device, n_rows, n_acc, drain, 1, blocks, iters, seed, total_updates, max_abs_error);
+}
+extern "C" int dge_selftest_atomics_wave_block(int device, int32_t n_rows, int32_t n_acc, int32_t drain, int32_t div, int32_t blocks, int32_t iters, uint64_t seed,
+                                               int64_t* total_updates, double* max_abs_error) {
+    if (n_rows <= 0 || blocks <= 0 || iters <= 0 || n_acc < 0 || drain <= 0 || div <= 0 || n_rows < div || !total_updates || !max_abs_error)
+        DGE_FAIL(DGE_ERR_ARG, "dge_selftest_atomics_wave: bad argument");
     int rc = dge_require_device(device);
     if (rc) return rc;
     const int stride = 128;
@@ -425,7 +438,7 @@ extern "C" int dge_selftest_atomics_wave(int device, int32_t n_rows, int32_t n_a
     if ((rc = dge_dev_alloc(&d_cnt, (size_t)n_rows))) return rc;
     DGE_HIP(hipMemset(d_tab, 0, (size_t)n_rows * stride * sizeof(float)));
     DGE_HIP(hipMemset(d_cnt, 0, (size_t)n_rows * sizeof(unsigned long long)));
-    hipLaunchKernelGGL(k_selftest_atomics_wave, dim3((unsigned)blocks), dim3(256), 0, 0, d_tab, d_cnt, n_rows, stride, iters, seed, n_acc, drain);
+    hipLaunchKernelGGL(k_selftest_atomics_wave, dim3((unsigned)blocks), dim3(256), 0, 0, d_tab, d_cnt, n_rows, stride, iters, seed, n_acc, drain, div);
     DGE_HIP(hipGetLastError());
     DGE_HIP(hipDeviceSynchronize());
     std::vector<float> tab((size_t)n_rows * stride); std::vector<unsigned long long> cnt((size_t)n_rows);
@@ -1078,6 +1091,15 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         if (pol == 27) {
             if (head_knob >= 0) p.hot_rows = (int32_t)std::min<int64_t>(head_knob, m->V);                                       // ablation knobs
             if (g_dge_tuning[DGE_TUNE_BLOCK_SYN0_FREE] >= 0) p.syn0_free = g_dge_tuning[DGE_TUNE_BLOCK_SYN0_FREE] > 0 ? 1 : 0;
+            // the partition's hottest rows of BOTH tables add up in the atomics wave's LDS accumulators (lk_atomics_wave, LkAcc): in a block one row's atomics are the
+            // longest chain of the launch
+            // longest chain of the launch (cfg3_zipf at 8 ranks: 22.6 -> 15.2 ms a block).  Updates a flush: what keeps a row's parked updates — at most one flush short
+            // in every workgroup — under 2 048, half of what the owner-computes schedule lets a row take from one stale value (dge_sorted_batch_items); measured on the
+            // cfg3-sized Zipf graph at 8 ranks with 512 workgroups: 4 a flush AUC 0.826 / loss 1.280 (banks off 0.817 / 1.285), 8 a flush 0.825 / 1.296, 16 a flush
+            // diverges (profiles/r05_blocks_acc_quality_zipf.txt).  (the kernel caps the rows at what its LDS holds: 16 a bank, 8 from 129 floats a row on)
+            const int64_t wgs = std::max<int64_t>((workers + 11) / 12, 1);
+            p.acc_rows = g_dge_tuning[DGE_TUNE_ACC_ROWS] >= 0 ? (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_ACC_ROWS], 64) : 16;
+            p.acc_drain = g_dge_tuning[DGE_TUNE_ACC_DRAIN] > 0 ? (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_ACC_DRAIN], 1 << 20) : (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, 2048 / wgs));
         }
     }
     size_t shmem = 0;
@@ -1201,8 +1223,13 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
     // k_sgns_train_hsw's copies of the busiest inner nodes must be zero when the launch starts.  k_hs_rep_fold leaves them so behind every launch; an abandoned launch
     // (an error between the two) would not — so they are cleared here as well (hs_rep_n x 15 rows, < 1 MB)
     if (p.hs_rep_n > 0) DGE_HIP(hipMemsetAsync(m->d_syn1 + (size_t)m->V * m->stride, 0, (size_t)(HS_REP - 1) * (size_t)p.hs_rep_n * (size_t)m->stride * sizeof(float), st));
+    // rows of 17 .. 32 floats under the atomics policy (the reference's own layerSize 20): half a wave a worker, a row = one request each way (k_sgns_train_small)
+    const bool small_rows = pol == 2 && (workers > 1 || g_dge_tuning[DGE_TUNE_SMALL_ROWS] > 0) && m->cfg.dim > 16 && m->cfg.dim <= 32 && m->stride == 64 && L <= 64 && !big && g_dge_tuning[DGE_TUNE_SMALL_ROWS] != 0;
+    if (small_rows) { threads = 256u; blocks = (unsigned)((workers * 32 + 255) / 256); }
     EventPair ev;
     if ((rc = timing_begin(m, ev, 0))) return rc;
+    if (small_rows) hipLaunchKernelGGL((k_sgns_train_small<32>), dim3(blocks), dim3(threads), 0, st, p);
+    else
     switch (m->stride / 64) {
         case 1: dge_launch_train_dch1(p, pol, big, blocks, threads, shmem, st); break;
         case 2: dge_launch_train_dch2(p, pol, big, blocks, threads, shmem, st); break;
@@ -1223,6 +1250,7 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         else if (pol == 14) k = std::string("k_sgns_train_hsw<negatives under commit locks") + (p.hot_rows > 0 ? ", head rows by atomics" : "") + ", 3 waves> (hierarchical softmax, a wave per centre)";
         else if (pol == 15) k = std::string("k_sgns_train_hsw<negatives under commit locks") + (p.hot_rows > 0 ? ", head rows by atomics" : "") + ", 7 waves> (hierarchical softmax, a wave per centre)";
         else if (base == 5 || base == 6 || base == 7) k = std::string("k_sgns_train_locked<") + (base == 6 ? "strict" : "relaxed") + (base == 7 ? ", head rows by atomics" : "") + (blk ? ", one block" : "") + ">";
+        else if (small_rows) k = "k_sgns_train_small<atomics, 32 lanes a worker>";
         else k = std::string("k_sgns_train<") + (base == 2 ? "atomics" : (base == 1 ? "row rmw" : "in-order")) + (hs ? ", hierarchical softmax pair by pair" : "") + (blk ? ", one block" : "") + ">";
         m->last_kernel = k;
     }

@@ -514,10 +514,17 @@ __device__ __forceinline__ void lk_post4(float* boxes, int* flags, int wk, unsig
 // launch, profiles/r03_zipf_ablation.txt).  Readers still read memory: they see this workgroup's parked updates of such a row at most `drain` late.
 // OFF by default (dge_set_tuning DGE_TUNE_ACC_ROWS): cfg3_zipf gains 2-4 % with 16 rows whatever the drain (4 .. 64), cfg5 nothing, and with 16 updates a
 // flush the hottest rows lag enough to move the trained scores (mean score of linked pairs 2.45 against 1.34, AUC unchanged; 1.37 with 4 a flush).
-#define LK_ACC_ROWS(DCH) ((DCH) <= 2 ? 16 : ((DCH) <= 4 ? 12 : 8))
+#define LK_ACC_ROWS(DCH) ((DCH) <= 2 ? 16 : 8) /* rows a bank */
+// Round 5: two banks of LK_ACC_ROWS accumulators — bank 0 for syn1neg rows (messages of kind 1), bank 1 for syn0 rows (kind 2) — and a slot is the row's rank INSIDE THE
+// BLOCK'S PARTITION (row / div: a block of an n-rank schedule only ever meets rows = part (mod n), LkAcc::div = n, ::part_* = the block's partitions; one GPU: div 1).
+// One block of the multi-GPU schedule is where the banks pay: a partition's hottest row takes n rows' worth of negative draws and the owner of a busy vertex trains ALL
+// its pairs as context, so per episode ONE row takes ~2e5 updates on cfg3_zipf at 8 ranks — and a row's memory-side atomics complete one after the other (~78 ns an
+// update: 14 of the episode's 22 ms whatever the head size, the worker count or the syn0 rule, profiles/r05_skewed_knobs_cfg3_zipf.txt).  Summed up `drain` at a time
+// in every workgroup, that chain is 1/drain as long.
+struct LkAcc { float* acc; int* cnt; int n_tgt, n_ctx, drain, div, part_tgt, part_ctx; };
 template <int DCH>
-__device__ __forceinline__ void lk_acc_flush(float* acc, int row, const TableView& t, int wl) {
-    float* a = acc + row * (DCH * 64) + wl;
+__device__ __forceinline__ void lk_acc_flush(float* acc, int slot, const TableView& t, int32_t row, int wl) {
+    float* a = acc + slot * (DCH * 64) + wl;
     float* pr = t.base + (size_t)row * (t.row_bytes / 4) + wl;
 #pragma unroll
     for (int c = 0; c < DCH; c++) {
@@ -528,7 +535,7 @@ __device__ __forceinline__ void lk_acc_flush(float* acc, int row, const TableVie
 }
 template <int DCH, int NBOX = LK_MB_WORKERS * 2>
 __device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* done, int n_workers_here, const TableView& syn0, const TableView& syn1neg, const TableView& syn1,
-                                                float* acc = nullptr, int* acc_cnt = nullptr, int n_acc = 0, int drain = 1) {
+                                                const LkAcc A = LkAcc{nullptr, nullptr, 0, 0, 1, 1, 0, 0}) {
     const int wl = threadIdx.x & 63;
     static_assert(NBOX <= 64, "one flag per lane");
     for (;;) {
@@ -554,13 +561,15 @@ __device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* d
                 const int j = __builtin_ctz(left);
                 const int32_t row = __builtin_amdgcn_readlane(my_row, j);
                 const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_step), j));
-                if (f == 1 && row < n_acc) {                // one of the hottest rows: into its accumulator
-                    float* a = acc + row * (DCH * 64) + wl;
+                const int n_here = f == 1 ? A.n_tgt : (f == 2 ? A.n_ctx : 0);
+                if (row < n_here * A.div) {                 // one of the partition's hottest rows: into its accumulator
+                    const int slot = (A.div == 1 ? row : row / A.div) + (f == 2 ? LK_ACC_ROWS(DCH) : 0);
+                    float* a = A.acc + slot * (DCH * 64) + wl;
 #pragma unroll
                     for (int c = 0; c < DCH; c++) a[c * 64] = fmaf(g, v[c], a[c * 64]);
-                    const int n = __builtin_amdgcn_readfirstlane(acc_cnt[row]) + 1;
-                    if (n >= drain) lk_acc_flush<DCH>(acc, row, syn1neg, wl);
-                    if (wl == 0) acc_cnt[row] = n >= drain ? 0 : n;
+                    const int n = __builtin_amdgcn_readfirstlane(A.cnt[slot]) + 1;
+                    if (n >= A.drain) lk_acc_flush<DCH>(A.acc, slot, t, row, wl);
+                    if (wl == 0) A.cnt[slot] = n >= A.drain ? 0 : n;
                     continue;
                 }
                 float* pr = t.base + (size_t)row * (t.row_bytes / 4) + wl;
@@ -575,8 +584,10 @@ __device__ __forceinline__ void lk_atomics_wave(float* boxes, int* flags, int* d
                 bool left_over = false;
                 for (int b = 0; b < NBOX; b++) left_over |= __builtin_amdgcn_readfirstlane(lk_flag_load(&flags[b])) != 0;
                 if (!left_over) {
-                    for (int r = 0; r < n_acc; r++)         // what is still parked goes out
-                        if (__builtin_amdgcn_readfirstlane(acc_cnt[r]) > 0) lk_acc_flush<DCH>(acc, r, syn1neg, wl);
+                    for (int r = 0; r < A.n_tgt; r++)       // what is still parked goes out
+                        if (__builtin_amdgcn_readfirstlane(A.cnt[r]) > 0) lk_acc_flush<DCH>(A.acc, r, syn1neg, r * A.div + A.part_tgt, wl);
+                    for (int r = 0; r < A.n_ctx; r++)
+                        if (__builtin_amdgcn_readfirstlane(A.cnt[LK_ACC_ROWS(DCH) + r]) > 0) lk_acc_flush<DCH>(A.acc, LK_ACC_ROWS(DCH) + r, syn0, r * A.div + A.part_ctx, wl);
                     return;
                 }
             } else __builtin_amdgcn_s_sleep(2);
@@ -1023,7 +1034,7 @@ template <int DCH, bool STRICT, bool BIG, bool HOTMIX, bool PART, bool WDOG = fa
 __global__ void __launch_bounds__(256, (DCH <= 2 && !BIG) ? (HOTMIX ? (PART ? 2 : DGE_HOTMIX_WAVES) : (DCH == 1 ? 4 : DGE_LOCKED_WAVES)) : ((HOTMIX && DCH <= 4) ? 2 : 1))
 k_sgns_train_locked(TrainParams p) {
     __shared__ float s_exp[EXP_TABLE_SIZE];
-    __shared__ float s_dh[16 * 2 * DCH * 64];
+    __shared__ float s_dh[(HOTMIX ? LK_MB_WORKERS : 16) * 2 * DCH * 64];     // (a mixed workgroup has 12 workers: its fourth wave is the atomics wave)
     __shared__ __attribute__((aligned(16))) float s_mb[HOTMIX ? LK_MB_WORKERS * 2 * LkBox<DCH>::FLOATS : 4];     // the atomics wave's message boxes
     __shared__ int s_mb_flag[LK_MB_WORKERS * 2];
     __shared__ int s_mb_done;
@@ -1032,8 +1043,8 @@ k_sgns_train_locked(TrainParams p) {
     // make them wait, and the headline kernel must not pay for the check: the extra control flow costs 4 registers and 22 spilled scalars, 1.5 % of a cfg3 launch
     // (same box, A / B: 390.9 against 396.8 ms).  The mixed kernels never carry it: the rows that could make them wait are their head, which takes no lock.
     constexpr bool WD = WDOG && !HOTMIX;
-    __shared__ float s_acc[HOTMIX ? LK_ACC_ROWS(DCH) * DCH * 64 : 4];        // the atomics wave's accumulators of the hottest rows (lk_atomics_wave)
-    __shared__ int s_acc_cnt[LK_ACC_ROWS(DCH)];
+    __shared__ float s_acc[HOTMIX ? 2 * LK_ACC_ROWS(DCH) * DCH * 64 : 4];    // the atomics wave's accumulators of the hottest rows, a bank per table (lk_atomics_wave)
+    __shared__ int s_acc_cnt[2 * LK_ACC_ROWS(DCH)];
     // the negative-sampling table's run form (neg_row_by_runs), where the model has one (not in the mixed kernels: skewed vocabularies have none)
     __shared__ double s_run_base[HOTMIX ? 1 : DGE_RUN_MAX];
     __shared__ uint32_t s_run_row[HOTMIX ? 1 : DGE_RUN_MAX + 1];
@@ -1049,8 +1060,8 @@ k_sgns_train_locked(TrainParams p) {
     if (threadIdx.x < LK_MB_WORKERS * 2) s_mb_flag[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_mb_done = 0; s_deadline = p.wd_ticks ? (unsigned long long)wall_clock64() + p.wd_ticks : ~0ull; }
     if (HOTMIX) {
-        for (int i = threadIdx.x; i < LK_ACC_ROWS(DCH) * DCH * 64; i += blockDim.x) s_acc[i] = 0.f;
-        if (threadIdx.x < LK_ACC_ROWS(DCH)) s_acc_cnt[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < 2 * LK_ACC_ROWS(DCH) * DCH * 64; i += blockDim.x) s_acc[i] = 0.f;
+        if (threadIdx.x < 2 * LK_ACC_ROWS(DCH)) s_acc_cnt[threadIdx.x] = 0;
     }
     __syncthreads();
 
@@ -1066,8 +1077,11 @@ k_sgns_train_locked(TrainParams p) {
     syn0.valid = syn1neg.valid = (uint32_t)p.D;
     if (use_mb && wk >= LK_MB_WORKERS) {
         const int64_t here = min((int64_t)LK_MB_WORKERS, p.n_workers - (int64_t)blockIdx.x * LK_MB_WORKERS);
-        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(here, (int64_t)0), syn0, syn1neg, syn1neg, s_acc, s_acc_cnt,
-                             min(min(p.acc_rows, p.hot_rows), LK_ACC_ROWS(DCH)), max(p.acc_drain, 1));
+        // (accumulators only for rows of the head: the tail's rows never reach this wave.  A block's head holds hot_rows / part_n rows of each partition.)
+        const int div = PART ? max(p.part_n, 1) : 1;
+        const int n_acc = min(min(p.acc_rows, p.hot_rows / div), LK_ACC_ROWS(DCH));
+        lk_atomics_wave<DCH>(s_mb, s_mb_flag, &s_mb_done, (int)max(here, (int64_t)0), syn0, syn1neg, syn1neg,
+                             LkAcc{s_acc, s_acc_cnt, n_acc, PART ? n_acc : 0, max(p.acc_drain, 1), div, PART ? p.part_tgt : 0, PART ? p.part_ctx : 0});
         return;
     }
     if (worker >= p.n_workers) return;
@@ -1766,6 +1780,162 @@ k_sgns_train_hsw(TrainParams p) {
         if (lane == 0 && wave < p.n_workers) __hip_atomic_fetch_add(&s_mb_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // (behind this group's last post)
     }
     hot_drain_block(s_hot, p.hs_n_hot * DCH * 64, p.syn1 + (size_t)p.hs_hot0 * (DCH * 64));
+}
+
+// ------------------------------------------------------------------------------------------ small rows: 32 lanes a worker, a float a lane (round 5)
+// The reference's own layer size is 20 (tract level, J/DeepWalk.java:62-66) on a vocabulary of 6 408 rows: 1.6 MB of tables, nothing for the HBM to do.  What such
+// a launch runs against is the REQUEST rate of the memory-side atomics on a handful of lines: k_sgns_train's 16-lane groups move a 20-float row as 16 + 4 lanes — two
+// load requests and two atomic requests a row — and scripts/micro/small_row_atomics.hip (profiles/r05_small_row_atomics.txt) measures 9.3e9 row updates/s for ONE
+// request of 20 contiguous lanes against 5.1e9 for the 16 + 4 form at saturation (and the same factor on the one busiest row's chain).  So rows of 17 .. 32 floats under
+// the atomics policy get this kernel: a worker is HALF A WAVE, lane j holds element j of every row it touches, a row is one 128-byte request each way.  The
+// schedule is k_sgns_train<.., atomics>'s, draw for draw (same window draws, same negatives from the same per-pair stream, positive first, the centre's syn1neg row
+// and its gathered update in registers for all its contexts); only the lane that holds an element differs, so one worker alone trains what that kernel trains
+// up to the order of the 32 products inside a dot product.  No hierarchical softmax, no block schedule, walks of up to 64 tokens: everything else stays with k_sgns_train.
+__device__ __forceinline__ float small_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float group32_sum(float v) { v += __shfl_xor(v, 16); return group16_sum(v); }
+__device__ __forceinline__ uint64_t shfl32_u64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = (uint32_t)__shfl((int)lo, src, 32);
+    hi = (uint32_t)__shfl((int)hi, src, 32);
+    return ((uint64_t)hi << 32) | lo;
+}
+#define SMALL_NEG_BATCH 8
+template <int LG>      // lanes a worker (32)
+__global__ void __launch_bounds__(256, 8)
+k_sgns_train_small(TrainParams p) {
+    static_assert(LG == 32, "half a wave a worker");
+    __shared__ float s_exp[EXP_TABLE_SIZE];
+    for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) s_exp[i] = p.exp_table[i];
+    __syncthreads();
+    const int lane = threadIdx.x & (LG - 1);
+    const int64_t worker = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LG;
+    if (worker >= p.n_workers) return;
+    const bool on = lane < p.D;                           // this lane holds an element
+    // ONE worker (DGE_TUNE_SMALL_ROWS = 1 forces the kernel for it: parity tests) runs the sequential schedule, as in k_sgns_train: it waits for its own atomics before
+    // it reads rows again, and trains a batch's negatives in turn
+    const bool solo = p.n_workers == 1;
+#define SMALL_SOLO_WAIT() do { if (solo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+    float* const syn0 = p.syn0 + lane;
+    float* const syn1neg = p.syn1neg + lane;
+    const int64_t stride = p.stride;
+
+    // lane j (and j + 16) turns the pair's LCG state s into the state after (j & 15) + 1 draws: negatives are drawn sixteen at a time, as in k_sgns_train
+    uint64_t mA = 1, cA = 0;
+    for (int j = 0; j <= (lane & 15); j++) { mA *= DGE_W2V_MULT; cA = cA * DGE_W2V_MULT + 11; }
+
+    const int L = p.L, W = p.W, K = p.K;
+    unsigned long long my_pairs = 0, my_words = 0;
+    int64_t w = -1, w_next = worker;
+    int len = 0, i = 0, c = 1, c_hi = 0;
+    int32_t tk0 = -1, tk1 = -1;                           // the walk's tokens: lane j holds tokens j and j + 32
+    int32_t word = 0;
+    float alpha = 0.f;
+    uint64_t s = 0;
+    int64_t gbase = 0;
+    float h = 0.f, dh = 0.f;                              // syn1neg[word] and its gathered update (this lane's element)
+    bool h_dirty = false;
+#define SMALL_TOK(idx) ((idx) < 32 ? __shfl(tk0, (idx), 32) : __shfl(tk1, (idx) - 32, 32))
+
+    for (;;) {
+        bool new_centre = false, alive = true;
+        while (c > c_hi) {
+            if (h_dirty) { h_dirty = false; if (on) atomicAdd(syn1neg + (int64_t)word * stride, dh); }
+            i++;
+            while (i >= len) {                             // next walk of this worker (empty walks are skipped)
+                w = w_next;
+                if (w >= p.n_rows) { alive = false; break; }
+                if (p.next_walk) {
+                    unsigned long long t = 0;
+                    if (lane == 0) t = atomicAdd(p.next_walk, 1ull);
+                    w_next = (int64_t)shfl32_u64(t, 0) + p.n_workers;
+                } else w_next = w + p.n_workers;
+                len = (int)p.len[w];
+                i = 0;
+                if (len > 0) {
+                    my_words += (unsigned long long)len;
+                    const int32_t* sen = p.sen + w * L;
+                    tk0 = lane < L ? sen[lane] : -1;
+                    tk1 = lane + 32 < L ? sen[lane + 32] : -1;
+                    const int64_t wbw = p.wb[w];
+                    const int64_t done = p.words_done_base + (p.words_scale == 1.0 ? wbw : (int64_t)((double)wbw * p.words_scale));
+                    alpha = (float)((double)p.alpha0 * (1.0 - (double)done / (double)(p.all_words + 1)));
+                    if (alpha < p.min_alpha) alpha = p.min_alpha;
+                    gbase = (p.gidx_base + w) * (int64_t)L;
+                }
+            }
+            if (!alive) break;
+            word = SMALL_TOK(i);
+            s = dge_mix64(p.seed + (uint64_t)(gbase + i));
+            s = s * DGE_W2V_MULT + 11;
+            const int radius = W - (int)dge_fast_mod(s, (uint64_t)W, p.W_magic);
+            c = max(0, i - radius);
+            c_hi = min(len - 1, i + radius);
+            if (c_hi == i) c_hi--;
+            if (c == i) c++;
+            new_centre = true;
+        }
+        if (!alive) break;
+        const int32_t last = SMALL_TOK(c);
+
+        // ---- one pair: l1 = syn0[last], targets in syn1neg: the centre (label 1) first, then K negatives
+        SMALL_SOLO_WAIT();
+        const float l1 = on ? small_ld(syn0 + (int64_t)last * stride) : 0.f;
+        if (new_centre) { h = on ? small_ld(syn1neg + (int64_t)word * stride) : 0.f; dh = 0.f; }
+        float neu;
+        {
+            const float f = group32_sum(l1 * h);
+            const float g = sgns_g(f, 1.0f, alpha, s_exp);
+            neu = g * h;
+            h = fmaf(g, l1, h);
+            dh = fmaf(g, l1, dh);
+            h_dirty = true;
+        }
+        for (int kd = 0; kd < K; kd += 16) {
+            const int kc = min(16, K - kd);
+            const uint64_t sl = s * mA + cA;
+            int32_t t = -1;
+            if (lane < kc) {
+                t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                if (t == word) t = -1;
+            }
+            s = shfl32_u64(sl, kc - 1);
+            for (int base = 0; base < kc; base += SMALL_NEG_BATCH) {
+                int32_t tg[SMALL_NEG_BATCH];
+                float rr[SMALL_NEG_BATCH];
+#pragma unroll
+                for (int q = 0; q < SMALL_NEG_BATCH; q++) {
+                    const int32_t v = __shfl(t, (base + q) & 15, 32);
+                    tg[q] = (base + q < kc) ? v : -1;
+                }
+                // all rows of the batch in flight together (a skipped slot loads nothing); one worker alone: row after row, each behind the last one's atomics
+                if (!solo) {
+#pragma unroll
+                    for (int q = 0; q < SMALL_NEG_BATCH; q++) rr[q] = (on && tg[q] >= 0) ? small_ld(syn1neg + (int64_t)tg[q] * stride) : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < SMALL_NEG_BATCH; q++)
+                    if (tg[q] >= 0) {
+                        if (solo) { SMALL_SOLO_WAIT(); rr[q] = on ? small_ld(syn1neg + (int64_t)tg[q] * stride) : 0.f; }
+                        const float f = group32_sum(l1 * rr[q]);
+                        const float g = sgns_g(f, 0.0f, alpha, s_exp);
+                        neu = fmaf(g, rr[q], neu);
+                        if (on) atomicAdd(syn1neg + (int64_t)tg[q] * stride, g * l1);
+                    }
+            }
+        }
+        if (on) atomicAdd(syn0 + (int64_t)last * stride, neu);
+        my_pairs++;
+        c++;
+        if (c == i) c++;
+    }
+    if (h_dirty && on) atomicAdd(syn1neg + (int64_t)word * stride, dh);
+#undef SMALL_TOK
+#undef SMALL_SOLO_WAIT
+    if (lane == 0) {
+        if (my_pairs) atomicAdd(&p.counters[0], my_pairs);
+        if (my_words) atomicAdd(&p.counters[1], my_words);
+    }
 }
 
 template <int DCH, bool BIG>

@@ -435,7 +435,7 @@ def build_stamp():
     return dict(kv.split("=") for kv in lib.dge_build_stamp().decode().split())
 
 
-TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7, "hs_cold": 8, "hs_wave": 9, "acc_rows": 10, "acc_drain": 11, "table_runs": 12, "block_syn0_free": 13, "hs_centre": 14, "hs_hot_kb": 15, "allow_unsafe": 16, "watchdog_ms": 17, "hs_copies": 18}      # include/dge.h: DGE_TUNE_*
+TUNING_KNOBS = {"hot_rows": 0, "hs_drain": 1, "force_segments": 2, "segment_shift": 3, "sorted_chunk": 4, "sorted_walks": 5, "workers": 6, "static_walks": 7, "hs_cold": 8, "hs_wave": 9, "acc_rows": 10, "acc_drain": 11, "table_runs": 12, "block_syn0_free": 13, "hs_centre": 14, "hs_hot_kb": 15, "allow_unsafe": 16, "watchdog_ms": 17, "hs_copies": 18, "small_rows": 19}      # include/dge.h: DGE_TUNE_*
 
 
 class tuning:

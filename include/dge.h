@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define DGE_VERSION 105   /* 105: stream-ordered partition copies (dge_model_export/import_partition_async, dge_model_stream), dge_host_sync_count, the lock kernels' watchdog,
+#define DGE_VERSION 106   /* 106: dge_selftest_atomics_wave_block; the block kernels' accumulator banks (DGE_TUNE_ACC_ROWS / ACC_DRAIN apply to both tables of a block); k_sgns_train_small and DGE_TUNE_SMALL_ROWS.
+                             105: stream-ordered partition copies (dge_model_export/import_partition_async, dge_model_stream), dge_host_sync_count, the lock kernels' watchdog,
                              forced schedules refused where they would diverge or spin (DGE_ERR_ARG), DGE_TUNE_ALLOW_UNSAFE / WATCHDOG_MS / HS_COPIES (additions only) */
 
 enum {
@@ -371,7 +372,8 @@ enum {
     DGE_TUNE_ALLOW_UNSAFE = 16,   /* > 0: a FORCED update_policy runs even where the library would refuse it (8 on a vocabulary whose busiest row would take > 8192 terms of one mini-batch; 5 / 6 where workers x the busiest row's share > 2) — tests of the watchdog, reproductions of the failure */
     DGE_TUNE_WATCHDOG_MS = 17,    /* the lock kernels' watchdog: a worker still waiting for a row lock after this many milliseconds of the launch gives up (dge_model_stats then returns DGE_ERR_STATE); 0 = no watchdog; default: 5 s + 100 x the launch's bytes at the 8 TB/s roofline */
     DGE_TUNE_HS_COPIES = 18,      /* k_sgns_train_hsw, copies form: the root's number of copies (a node's copies = ceil(its share of the paths x value), at most 16); default 16 */
-    DGE_TUNE_COUNT = 19
+    DGE_TUNE_SMALL_ROWS = 19,     /* rows of 17 .. 32 floats under the atomics policy: 1 = k_sgns_train_small (32 lanes a worker, a row = one request), 0 = k_sgns_train's 16-lane groups; default: the small-row kernel wherever it applies (v106) */
+    DGE_TUNE_COUNT = 20
 };
 int  dge_set_tuning(int32_t knob, int64_t value);
 int  dge_get_tuning(int32_t knob, int64_t* value);   /* -1 = the library's own rule */
@@ -389,6 +391,10 @@ int  dge_selftest_locked_rows(int device, int32_t n_rows, int64_t n_workers, int
    messages of 5 rows each, half of them among the 8 hottest; every element of a row must end at the number of times the row was posted. */
 int  dge_selftest_atomics_wave(int device, int32_t n_rows, int32_t n_acc, int32_t drain, int32_t blocks, int32_t iters, uint64_t seed,
                                int64_t* total_updates, double* max_abs_error);
+/* the same with the rows of ONE BLOCK of a div-rank schedule (v106): messages alternate between the two tables' accumulator banks, a row's slot is its rank
+   inside its partition (row / div); div = 1 is the call above */
+int  dge_selftest_atomics_wave_block(int device, int32_t n_rows, int32_t n_acc, int32_t drain, int32_t div, int32_t blocks, int32_t iters, uint64_t seed,
+                                     int64_t* total_updates, double* max_abs_error);
 /* the LDS combining of the hierarchical-softmax updates near the root (hot_add) in isolation: n_workers workers add 1.0
  * to skewed pseudo-random rows `iters` times with the given drain period; max_abs_error = worst |row element - additions
  * that row received| (0 when no addition is lost or doubled). */

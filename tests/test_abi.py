@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(dge):
 
 def test_struct_layouts(dge):
     assert C.sizeof(dge.TrainConfig) == 64 and C.sizeof(dge.TrainStats) == 40
-    assert dge.lib.dge_version() == 105
+    assert dge.lib.dge_version() == 106
 
 
 def test_no_device_means_loud_failure(dge):

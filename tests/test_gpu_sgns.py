@@ -215,6 +215,11 @@ def test_atomics_wave_conserves_every_update(dge):
         total = C.c_int64(0); err = C.c_double(-1)
         assert dge.lib.dge_selftest_atomics_wave(0, n_rows, n_acc, drain, blocks, iters, 11, C.byref(total), C.byref(err)) == 0
         assert total.value == blocks * 12 * iters * 5 and err.value == 0.0, (n_rows, n_acc, drain, total.value, err.value)
+    # one block of an n-rank schedule (round 5): a bank of accumulators per table, a row's slot = its rank inside the block's partition
+    for n_rows, n_acc, drain, div, blocks, iters in ((1000, 16, 4, 8, 128, 80), (64, 16, 16, 8, 64, 50), (4096, 5, 3, 3, 64, 60), (100000, 16, 1 << 20, 8, 128, 60)):
+        total = C.c_int64(0); err = C.c_double(-1)
+        assert dge.lib.dge_selftest_atomics_wave_block(0, n_rows, n_acc, drain, div, blocks, iters, 13, C.byref(total), C.byref(err)) == 0
+        assert total.value == blocks * 12 * iters * 5 and err.value == 0.0, (n_rows, n_acc, drain, div, total.value, err.value)
 
 
 def test_negative_table_run_form_draws_the_tables_rows(dge, oracle):

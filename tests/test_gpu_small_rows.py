@@ -1,0 +1,98 @@
+"""k_sgns_train_small — the trainer for rows of 17 .. 32 floats (the reference's layerSize 20, J/DeepWalk.java:62-66): half a wave a worker, a float a lane, a row = one
+request each way.  Its schedule is k_sgns_train<atomics>'s draw for draw; tested here: one worker alone IS the sequential word2vec schedule (against the oracle in word2vec.c's
+arithmetic order, north_star's 1e-4 cosine on every row, exact pair count; SGNS half of the oracle: a restatement, parity unpinned — DESIGN.md §3), it is what auto runs
+for such rows under the atomics policy and nothing else, and at device-filling concurrency it learns what the sequential oracle learns (held-out AUC and loss)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, dim):
+    rng = np.random.default_rng(seed)
+    NV = int(rng.integers(8, 400))
+    L = int(rng.choice([2, 3, 5, 8, 16, 17, 24, 33, 40, 64]))
+    n = int(rng.integers(20, 300))
+    ids = (np.minimum(rng.zipf(1.4, size=(n, L)) - 1, NV - 1) if rng.random() < 0.5 else rng.integers(0, NV, (n, L))).astype(np.int32)
+    lens = rng.integers(0, L + 1, n)
+    ids[np.arange(L)[None, :] >= lens[:, None]] = -1                       # ragged walks, empty walks
+    if rng.random() < 0.3:
+        ids[rng.random(ids.shape) < 0.1] = -1                              # holes inside walks
+    cfg = dict(dim=dim, window=int(rng.integers(1, L + 3)), negative=int(rng.choice([0, 1, 5, 13, 16, 17, 30])), min_count=int(rng.choice([1, 2, 3])),
+               epochs=int(rng.choice([1, 2])), table_size=int(rng.choice([64, 997, 20011])), seed=int(rng.integers(1, 1 << 30)))
+    return ids, NV, cfg
+
+
+@pytest.mark.parametrize("seed,dim", [(s, d) for s in range(200, 208) for d in (17, 20, 32)])
+def test_one_worker_is_the_sequential_schedule(dge, oracle, seed, dim):
+    from helpers import cosine_rows
+    ids, NV, cfg = _case(seed, dim)
+    kw = dict(negative=cfg["negative"], min_count=cfg["min_count"], epochs=cfg["epochs"], seed=cfg["seed"], table_size=cfg["table_size"])
+    om = oracle.train_sgns(ids, NV, dim, cfg["window"], arith=0, **kw)
+    c = dge.make_config(dim, cfg["window"], NV, workers=1, update_policy=2, **kw)
+    out = {}
+    for small in (1, 0):
+        with dge.tuning(small_rows=small):
+            dm = dge.SgnsModel.fit(ids, c, 0)
+        assert ("k_sgns_train_small" in dm.kernel()) == bool(small) or om.pairs == 0, dm.kernel()
+        syn0, vid = dm.vectors()
+        assert np.array_equal(vid, om.vocab_ids) and dm.stats()["pairs"] == om.pairs, (seed, dim, small, cfg)
+        out[small] = (syn0, dm.syn1neg())
+        if om.V:
+            assert np.isfinite(syn0).all()
+            c0 = cosine_rows(syn0, om.syn0); c1 = cosine_rows(out[small][1] + 1e-30, om.syn1neg + 1e-30)
+            assert c0.min() > 1 - 1e-4 and c1.min() > 1 - 1e-4, ("1 - cosine: syn0 %.3g, syn1neg %.3g" % (1 - c0.min(), 1 - c1.min()), seed, dim, small, cfg)
+    if om.V:      # the two kernels differ only in the order of the products inside a dot product
+        assert np.abs(out[1][0] - out[0][0]).max() <= 1e-3 * max(1.0, np.abs(out[0][0]).max()), (seed, dim)
+
+
+def test_auto_takes_the_small_row_kernel_only_where_it_applies(dge):
+    rng = np.random.default_rng(5)
+    NV, L = 600, 8
+    ids = rng.integers(0, NV, (4000, L)).astype(np.int32)
+    for dim, hs, want in ((20, False, True), (32, False, True), (17, False, True), (16, False, False), (33, False, False), (20, True, False)):
+        dm = dge.SgnsModel.fit(ids, dge.make_config(dim, L, NV, negative=5, min_count=1, workers=0, seed=3, use_hs=hs), 0)
+        sch = dm.schedule()
+        assert ("k_sgns_train_small" in dm.kernel()) == (want and sch["update_policy"] == 2 and sch["workers"] > 1), (dim, hs, dm.kernel(), sch)
+        assert np.isfinite(dm.vectors()[0]).all()
+    with dge.tuning(small_rows=0):
+        dm = dge.SgnsModel.fit(ids, dge.make_config(20, L, NV, negative=5, min_count=1, workers=0, seed=3), 0)
+        assert "k_sgns_train_small" not in dm.kernel()
+
+
+def test_tract_sized_graph_learns_what_the_sequential_oracle_learns(dge, oracle):
+    """The reference's tract configuration (801 regions x 8 slices = 6 408 rows, D = 20, K = 5, L = W = 8) on a graph with structure (communities of 9 regions, 80 % of
+    a vertex's flow inside), the device-filling launch auto picks (9 612 workers of k_sgns_train_small): held-out link AUC within 0.005 and loss within 1 % of the
+    sequential oracle's, and the pair count exact."""
+    R, T, L, D, K = 801, 8, 8, 20, 5
+    NV = R * T
+    rng = np.random.default_rng(1)
+    deg = rng.integers(60, 200, NV)
+    src = np.repeat(np.arange(NV), deg)
+    s_reg = src % R
+    inside = rng.random(len(src)) < 0.8
+    d_reg = np.where(inside, (s_reg // 9) * 9 + rng.integers(0, 9, len(src)), rng.integers(0, R, len(src))).clip(max=R - 1)
+    dst = ((src // R + 1) % T) * R + d_reg
+    w = 1.0 + np.floor(-20.0 * np.log(rng.random(len(src)).clip(1e-12)))
+    g = dge.DeviceGraph(0); g.add_edges(src.astype(np.int32), dst.astype(np.int32), w); g.set_sources(np.arange(R, dtype=np.int32)); g.build_alias(False)
+    walks = g.sample_walks(400_000, L, seed=5, rng_mode=1)
+    test = g.sample_walks(50_000, L, seed=99, rng_mode=1)
+
+    def score(syn0, syn1, vid):
+        remap = -np.ones(NV, np.int64); remap[vid] = np.arange(len(vid))
+        a = test[:, :-1].reshape(-1); b = test[:, 1:].reshape(-1)
+        rb = (b // R) * R + np.random.default_rng(3).integers(0, R, len(b))
+        a, b, rb = remap[a], remap[b], remap[rb]
+        ok = (a >= 0) & (b >= 0) & (rb >= 0); a, b, rb = a[ok], b[ok], rb[ok]
+        pos = (syn0[b].astype(np.float64) * syn1[a]).sum(1); neg = (syn0[rb].astype(np.float64) * syn1[a]).sum(1)
+        return float((pos > neg).mean() + 0.5 * (pos == neg).mean()), float(np.log1p(np.exp(-pos)).mean() + np.log1p(np.exp(neg)).mean())
+
+    kw = dict(negative=K, min_count=2, epochs=1, seed=1, table_size=10_000_000)
+    om = oracle.train_sgns(walks, NV, D, L, arith=0, **kw)
+    auc_o, loss_o = score(om.syn0, om.syn1neg, om.vocab_ids)
+    dm = dge.SgnsModel.fit(walks, dge.make_config(D, L, NV, workers=0, **kw), 0)
+    assert "k_sgns_train_small" in dm.kernel() and dm.schedule()["workers"] > 4096, (dm.kernel(), dm.schedule())
+    syn0, vid = dm.vectors()
+    auc, loss = score(syn0, dm.syn1neg(), vid)
+    assert dm.stats()["pairs"] == om.pairs and np.array_equal(vid, om.vocab_ids)
+    assert auc_o > 0.85 and abs(auc - auc_o) < 0.005 and abs(loss - loss_o) < 0.01 * loss_o, (auc, auc_o, loss, loss_o)
