@@ -1002,7 +1002,10 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // 3 204 ... 16 384 workers alike (sequential oracle 0.9294, its 8 Hogwild threads 0.9274), loss 0.6928 -> 0.6942 at 9 612 (sequential 0.6924, 8 threads 0.7111);
         // with the hierarchical softmax 9 612 workers keep AUC 0.9213 / loss 0.737 (8 CPU threads: 0.9207 / 0.741) and 12 816 lose it (0.915 / 0.81).  So from 4 096
         // rows on the cap is 1.5 workers a row: cfg1 7.2e8 -> 1.28e9 edges/s, with the tree term 1.64e8 -> 5.1e8.  Below 4 096 rows the round-1 cap stays.
-        workers = std::min(workers, std::max<int64_t>(64, m->V >= 4096 ? m->V * 3 / 2 : m->V / 2));
+        // The small-row kernel (rows of 17 .. 32 floats without the tree term: k_sgns_train_small) reaches its request-rate ceiling with ONE worker a row — 1.41e9 edges/s
+        // at 6 408, 9 612 and 16 384 workers alike, loss 0.6935 / 0.6943 / 0.716 (profiles/r05_small_row_kernel.txt) — so it runs one a row.
+        const bool small_kernel = !hs && m->part_n <= 1 && m->cfg.dim > 16 && m->cfg.dim <= 32 && m->stride == 64 && g_dge_tuning[DGE_TUNE_SMALL_ROWS] != 0;
+        workers = std::min(workers, std::max<int64_t>(64, m->V >= 4096 ? (small_kernel ? m->V : m->V * 3 / 2) : m->V / 2));
         // ... nor so many that ONE row has dozens of its updates in flight at once: every one of them is computed from the same stale row, and their
         // sum — along the direction the contexts share — is a gradient step M times too long.  A vocabulary whose busiest row takes 9 % of the tokens
         // (Zipf(1) over 50 000 words: text without sub-sampling, not a flow graph) went to NaN within one launch of 16 384 workers

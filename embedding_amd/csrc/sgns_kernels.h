@@ -1792,7 +1792,18 @@ k_sgns_train_hsw(TrainParams p) {
 // and its gathered update in registers for all its contexts); only the lane that holds an element differs, so one worker alone trains what that kernel trains
 // up to the order of the 32 products inside a dot product.  No hierarchical softmax, no block schedule, walks of up to 64 tokens: everything else stays with k_sgns_train.
 __device__ __forceinline__ float small_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float group32_sum(float v) { v += __shfl_xor(v, 16); return group16_sum(v); }
+// sum over the 32 lanes of a half wave, in every lane: four DPP steps inside a row of 16 (quad swaps, half-row mirror, row mirror), then the two rows of the half wave
+// meet through gfx950's v_permlane16_swap (odd rows of one operand <-> even rows of the other: with both operands = v the results are {row0, row0, row2, row2} and
+// {row1, row1, row3, row3}).  All VALU, no trip through the LDS crossbar: a pair's six dot products are on its latency chain.
+#define SMALL_DPP_ADD(v, CTRL) ((v) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (CTRL), 0xF, 0xF, true)))
+__device__ __forceinline__ float group32_sum(float v) {
+    v = SMALL_DPP_ADD(v, 0xB1);      // quad_perm [1, 0, 3, 2]
+    v = SMALL_DPP_ADD(v, 0x4E);      // quad_perm [2, 3, 0, 1]
+    v = SMALL_DPP_ADD(v, 0x141);     // row_half_mirror
+    v = SMALL_DPP_ADD(v, 0x140);     // row_mirror
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)__float_as_int(v), (unsigned)__float_as_int(v), false, false);
+    return __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+}
 __device__ __forceinline__ uint64_t shfl32_u64(uint64_t v, int src) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = (uint32_t)__shfl((int)lo, src, 32);
@@ -1801,7 +1812,7 @@ __device__ __forceinline__ uint64_t shfl32_u64(uint64_t v, int src) {
 }
 #define SMALL_NEG_BATCH 8
 template <int LG>      // lanes a worker (32)
-__global__ void __launch_bounds__(256, 8)
+__global__ void __launch_bounds__(256, 5)      // (five workgroups a compute unit: 10 240 workers resident, 96 registers)
 k_sgns_train_small(TrainParams p) {
     static_assert(LG == 32, "half a wave a worker");
     __shared__ float s_exp[EXP_TABLE_SIZE];
@@ -1834,6 +1845,7 @@ k_sgns_train_small(TrainParams p) {
     int64_t gbase = 0;
     float h = 0.f, dh = 0.f;                              // syn1neg[word] and its gathered update (this lane's element)
     bool h_dirty = false;
+    bool pre_ok = false; float l1_pre = 0.f; int32_t t_pre = -1; uint64_t s_pre = 0;     // the centre's next pair, asked for one pair ahead
 #define SMALL_TOK(idx) ((idx) < 32 ? __shfl(tk0, (idx), 32) : __shfl(tk1, (idx) - 32, 32))
 
     for (;;) {
@@ -1879,7 +1891,9 @@ k_sgns_train_small(TrainParams p) {
 
         // ---- one pair: l1 = syn0[last], targets in syn1neg: the centre (label 1) first, then K negatives
         SMALL_SOLO_WAIT();
-        const float l1 = on ? small_ld(syn0 + (int64_t)last * stride) : 0.f;
+        // (the context row and the negatives' table look-ups of a centre's NEXT pair are asked for one pair ahead — see below; a new centre starts afresh)
+        const bool have_pre = pre_ok && !new_centre;
+        const float l1 = have_pre ? l1_pre : (on ? small_ld(syn0 + (int64_t)last * stride) : 0.f);
         if (new_centre) { h = on ? small_ld(syn1neg + (int64_t)word * stride) : 0.f; dh = 0.f; }
         float neu;
         {
@@ -1892,14 +1906,38 @@ k_sgns_train_small(TrainParams p) {
         }
         for (int kd = 0; kd < K; kd += 16) {
             const int kc = min(16, K - kd);
-            const uint64_t sl = s * mA + cA;
             int32_t t = -1;
-            if (lane < kc) {
-                t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
-                if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
-                if (t == word) t = -1;
+            if (have_pre) { t = t_pre; s = s_pre; }        // (K <= 16: one chunk)
+            else {
+                const uint64_t sl = s * mA + cA;
+                if (lane < kc) {
+                    t = neg_table_row(p.ctab, dge_fast_mod(sl >> 16, (uint64_t)p.T, p.T_magic));
+                    if (t == 0 && p.V > 1) t = (int32_t)(sl % (uint64_t)(p.V - 1)) + 1;
+                    if (t == word) t = -1;
+                }
+                s = shfl32_u64(sl, kc - 1);
             }
-            s = shfl32_u64(sl, kc - 1);
+            // One pair ahead (several workers, K <= 16): the next context row of this centre and the table look-ups of its negatives leave NOW, in front of this
+            // pair's row loads — a pair is a latency chain (look-up -> rows -> atomics) and this takes two of its three trips off it.  The prefetched context row
+            // misses this pair's own update when a token stands twice in a centre's window: Hogwild staleness of one pair, as between workers.
+            pre_ok = false;
+            if (!solo && K <= 16) {
+                int c2 = c + 1;
+                if (c2 == i) c2++;
+                if (c2 <= c_hi) {
+                    const int32_t last2 = SMALL_TOK(c2);
+                    l1_pre = on ? small_ld(syn0 + (int64_t)last2 * stride) : 0.f;
+                    const uint64_t sl2 = s * mA + cA;
+                    t_pre = -1;
+                    if (lane < K) {
+                        t_pre = neg_table_row(p.ctab, dge_fast_mod(sl2 >> 16, (uint64_t)p.T, p.T_magic));
+                        if (t_pre == 0 && p.V > 1) t_pre = (int32_t)(sl2 % (uint64_t)(p.V - 1)) + 1;
+                        if (t_pre == word) t_pre = -1;
+                    }
+                    s_pre = shfl32_u64(sl2, K - 1);
+                    pre_ok = true;
+                }
+            }
             for (int base = 0; base < kc; base += SMALL_NEG_BATCH) {
                 int32_t tg[SMALL_NEG_BATCH];
                 float rr[SMALL_NEG_BATCH];
@@ -1913,15 +1951,28 @@ k_sgns_train_small(TrainParams p) {
 #pragma unroll
                     for (int q = 0; q < SMALL_NEG_BATCH; q++) rr[q] = (on && tg[q] >= 0) ? small_ld(syn1neg + (int64_t)tg[q] * stride) : 0.f;
                 }
+                if (!solo) {                              // the batch's dot products side by side (independent chains), then the updates
+                    float f[SMALL_NEG_BATCH];
 #pragma unroll
-                for (int q = 0; q < SMALL_NEG_BATCH; q++)
-                    if (tg[q] >= 0) {
-                        if (solo) { SMALL_SOLO_WAIT(); rr[q] = on ? small_ld(syn1neg + (int64_t)tg[q] * stride) : 0.f; }
-                        const float f = group32_sum(l1 * rr[q]);
-                        const float g = sgns_g(f, 0.0f, alpha, s_exp);
-                        neu = fmaf(g, rr[q], neu);
-                        if (on) atomicAdd(syn1neg + (int64_t)tg[q] * stride, g * l1);
-                    }
+                    for (int q = 0; q < SMALL_NEG_BATCH; q++) f[q] = group32_sum(l1 * rr[q]);
+#pragma unroll
+                    for (int q = 0; q < SMALL_NEG_BATCH; q++)
+                        if (tg[q] >= 0) {
+                            const float g = sgns_g(f[q], 0.0f, alpha, s_exp);
+                            neu = fmaf(g, rr[q], neu);
+                            if (on) atomicAdd(syn1neg + (int64_t)tg[q] * stride, g * l1);
+                        }
+                } else {
+#pragma unroll 1
+                    for (int q = 0; q < SMALL_NEG_BATCH; q++)
+                        if (tg[q] >= 0) {
+                            SMALL_SOLO_WAIT();
+                            const float r1 = on ? small_ld(syn1neg + (int64_t)tg[q] * stride) : 0.f;
+                            const float g = sgns_g(group32_sum(l1 * r1), 0.0f, alpha, s_exp);
+                            neu = fmaf(g, r1, neu);
+                            if (on) atomicAdd(syn1neg + (int64_t)tg[q] * stride, g * l1);
+                        }
+                }
             }
         }
         if (on) atomicAdd(syn0 + (int64_t)last * stride, neu);

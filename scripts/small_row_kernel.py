@@ -37,7 +37,7 @@ for D in (20, 32, 17):
     t = time.time(); om = O.train_sgns(walks, NV, D, L, arith=0, **kw); ts = time.time() - t
     print("D = %d  oracle sequential           : %.2e edges/s  AUC %.4f loss %.4f" % ((D, om.pairs / ts) + score(om.syn0, om.syn1neg, om.vocab_ids)), flush=True)
     for small in (0, 1):
-        for workers in (0, 6408, 9612, 16384):
+        for workers in (0, 3204, 4806, 6408, 9612, 16384):
             res = []
             for rep in range(2):
                 knobs = {"small_rows": small}

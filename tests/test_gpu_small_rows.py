@@ -62,7 +62,7 @@ def test_auto_takes_the_small_row_kernel_only_where_it_applies(dge):
 
 def test_tract_sized_graph_learns_what_the_sequential_oracle_learns(dge, oracle):
     """The reference's tract configuration (801 regions x 8 slices = 6 408 rows, D = 20, K = 5, L = W = 8) on a graph with structure (communities of 9 regions, 80 % of
-    a vertex's flow inside), the device-filling launch auto picks (9 612 workers of k_sgns_train_small): held-out link AUC within 0.005 and loss within 1 % of the
+    a vertex's flow inside), the device-filling launch auto picks (6 408 workers of k_sgns_train_small: one a row): held-out link AUC within 0.005 and loss within 1 % of the
     sequential oracle's, and the pair count exact."""
     R, T, L, D, K = 801, 8, 8, 20, 5
     NV = R * T
