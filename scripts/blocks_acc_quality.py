@@ -49,8 +49,11 @@ for b in range(10):
     one.train(corpus, b * nb, nb, walk_index_base=b * nb, words_before=wb, total_walks=epoch); wb += words_of(b * nb, nb)
 report("one GPU, 10 batches", one, vid, str(one.schedule()))
 one.close()
-for name, knob in (("8 ranks, banks off", {"acc_rows": 0}), ("8 ranks, 16 rows, 4 a flush", {"acc_rows": 16, "acc_drain": 4}), ("8 ranks, 16 rows, 8 a flush", {"acc_rows": 16, "acc_drain": 8}),
-                   ("8 ranks, 16 rows, 16 a flush", {"acc_rows": 16, "acc_drain": 16}), ("8 ranks, 16 rows, 64 a flush", {"acc_rows": 16, "acc_drain": 64})):
+sets = (("8 ranks, banks off", {"acc_rows": 0}), ("8 ranks, 16 rows, 4 a flush", {"acc_rows": 16, "acc_drain": 4}), ("8 ranks, 16 rows, 8 a flush", {"acc_rows": 16, "acc_drain": 8}),
+        ("8 ranks, 16 rows, 16 a flush", {"acc_rows": 16, "acc_drain": 16}), ("8 ranks, 16 rows, 64 a flush", {"acc_rows": 16, "acc_drain": 64}))
+if "workers" in sys.argv[2:]:      # the library's banks, fewer workers a block: a block's rows take n times their one-GPU share of the pairs in flight
+    sets = tuple(("8 ranks, default banks, %d workers" % w, {"workers": w}) for w in (6144, 4096, 3072, 2048))
+for name, knob in sets:
     with E.tuning(**knob):
         ms = [E.SgnsModel.create(cfg, counts, 0) for _ in range(N)]
         wb = 0; t0 = time.time()
