@@ -309,7 +309,8 @@ def test_cfg5_full_size_eight_rank_block_schedule(dge, cfg5_full):
 
 def test_cfg5_tenth_size_eight_rank_block_schedule_predicts_like_one_gpu(dge):
     """configs[4] at 1/10 (1 M vertices, 100 M edges, D = 256, K = 20), one epoch of 1 M walks in 10 global batches: the 8-rank block schedule's
-    embedding predicts held-out walk steps as well as the one-GPU embedding of the same walks (AUC within 0.005), same pair count.  (As ONE global
+    embedding predicts held-out walk steps as well as the one-GPU embedding of the same walks (AUC within 0.008: a power-law head, as on the skewed graph of
+    tests/test_gpu_blocks_scale.py), same pair count.  (As ONE global
     batch — the whole training block by block — it does not: 0.52 against 0.81; tests/test_gpu_blocks_scale.py.)"""
     import torch
     from embedding_amd import synth
