@@ -859,11 +859,15 @@ static int timing_end(dge_model* m, EventPair& ev, int rc_so_far) {
 // expected failures per try-lock are W * 5 * n^2 * sum_{partition}(q_i^2 + p_i^2) ~ W * 5 * n * sum_{all}(q_i^2 + p_i^2): the rule of
 // dge_model_create with the bound divided by n.  And a context row whose own pairs — serialised by its lock — are more than half of what one worker
 // trains in the launch (W * n * p_i > 0.5) goes to the atomics side as well.  Rows [0, head) take atomics, the rest stay under the commit locks.
+// Round 5, with the hottest rows' chains gone (the accumulator banks), the head size was swept again per graph (profiles/r05_skewed_knobs_*.txt, r05_blocks_head_quality_*.txt):
+// a block's speed has a flat optimum — cfg3_zipf 20 000 .. 160 000 rows within 2 %, cfg5 15 000 .. 60 000 (best 30 000: 8.47e7 against 8.31e7 at the 60 320 of the
+// 0.1 bound), the cfg3-sized community graph with a Zipf fifth 20 000 .. 40 000 (10 % faster than the 183 340 of the 0.1 bound) — and the embedding does not depend on it
+// (AUC / loss equal to the fourth digit from 10 000 to 183 340 rows).  A bound of 0.2 puts all three inside their optimum (44 222 / ~30 000 / 60 380 rows).
 static int64_t block_head(dge_model* m, int n, int64_t W) {
     if (m->block_head_n == n && m->block_head_workers == W) return m->block_head_rows;
     const double power = 0.75, twp = m->neg_norm, tw = (double)std::max<int64_t>(m->total_words, 1);
     double tail = 0.0; int64_t H = m->V;
-    const double bound = 0.1 / (5.0 * (double)W * (double)std::max(n, 1));
+    const double bound = 0.2 / (5.0 * (double)W * (double)std::max(n, 1));     // (round 5: 0.1 until the accumulator banks; see below)
     while (H > 0) {
         const double c = (double)m->h_counts[(size_t)(H - 1)];
         const double q = pow(c, power) / twp, pp = c / tw;
@@ -1100,9 +1104,16 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
             // in every workgroup — under 2 048, half of what the owner-computes schedule lets a row take from one stale value (dge_sorted_batch_items); measured on the
             // cfg3-sized Zipf graph at 8 ranks with 512 workgroups: 4 a flush AUC 0.826 / loss 1.280 (banks off 0.817 / 1.285), 8 a flush 0.825 / 1.296, 16 a flush
             // diverges (profiles/r05_blocks_acc_quality_zipf.txt).  (the kernel caps the rows at what its LDS holds: 16 a bank, 8 from 129 floats a row on)
-            const int64_t wgs = std::max<int64_t>((workers + 11) / 12, 1);
-            p.acc_rows = g_dge_tuning[DGE_TUNE_ACC_ROWS] >= 0 ? (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_ACC_ROWS], 64) : 16;
-            p.acc_drain = g_dge_tuning[DGE_TUNE_ACC_DRAIN] > 0 ? (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_ACC_DRAIN], 1 << 20) : (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, 2048 / wgs));
+            // (the flush period is set below, once the launch's workgroups are known)
+            // ... where that chain is long against the block: the partition's busiest row takes part_n x max(its share of the contexts, K x its share of the negative
+            // draws) of the block's pairs, ~78 ns each, against ~3 TB/s of row traffic for a pair.  Where it is short the banks buy nothing and cost a little: the
+            // community graph with a Zipf fifth (chain a quarter of the block) loses 0.0034 AUC / 2.3 % of the loss with them and gains 1 % (tests/test_gpu_blocks_scale.py).
+            const double top = (double)m->h_counts[0];
+            const double chain_share = (double)m->part_n * std::max(top / (double)std::max<int64_t>(m->total_words, 1), (double)m->cfg.negative * pow(top, 0.75) / m->neg_norm);
+            const double pair_s = 8.0 * (double)m->stride * (double)(m->cfg.negative + 2) / 3e12;
+            // (scripts/block_head_rule.py: that ratio is 1.08 on cfg3_zipf — banks: +50 % and a better AUC —, 0.55 on cfg5 — +10 % —, 0.32 on the community graph: on from 0.4)
+            const int32_t auto_rows = chain_share * 78e-9 > 0.4 * pair_s ? 16 : 0;
+            p.acc_rows = g_dge_tuning[DGE_TUNE_ACC_ROWS] >= 0 ? (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_ACC_ROWS], 64) : auto_rows;
         }
     }
     size_t shmem = 0;
@@ -1195,6 +1206,8 @@ static int train_rows(dge_model* m, const int32_t* d_rows, int64_t n_rows, int32
         // the mixed kernels keep every workgroup's fourth wave for the head rows' atomics (k_sgns_train_locked): 12 workers a workgroup
         if (m->cfg.workers == 0 && !(g_dge_tuning[DGE_TUNE_WORKERS] > 0)) { workers = std::max<int64_t>(workers / 16 * 12, 2); p.n_workers = workers; }
         blocks = (unsigned)((workers + 11) / 12);
+        if (pol == 27) p.acc_drain = g_dge_tuning[DGE_TUNE_ACC_DRAIN] > 0 ? (int32_t)std::min<int64_t>(g_dge_tuning[DGE_TUNE_ACC_DRAIN], 1 << 20)
+                                                                        : (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, 2048 / std::max(blocks, 1u)));
     }
 
     // per-segment descriptors (TableView) for tables of 4 GiB and more; DGE_TUNE_FORCE_SEGMENTS selects that code path on small

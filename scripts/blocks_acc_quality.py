@@ -53,6 +53,10 @@ sets = (("8 ranks, banks off", {"acc_rows": 0}), ("8 ranks, 16 rows, 4 a flush",
         ("8 ranks, 16 rows, 16 a flush", {"acc_rows": 16, "acc_drain": 16}), ("8 ranks, 16 rows, 64 a flush", {"acc_rows": 16, "acc_drain": 64}))
 if "workers" in sys.argv[2:]:      # the library's banks, fewer workers a block: a block's rows take n times their one-GPU share of the pairs in flight
     sets = tuple(("8 ranks, default banks, %d workers" % w, {"workers": w}) for w in (6144, 4096, 3072, 2048))
+if "head" in sys.argv[2:]:         # the block's head (rows that take atomics instead of commit locks): a block's speed does not depend on it (profiles/r05_skewed_knobs_*) — does the embedding?
+    sets = (("8 ranks, the library's head", {}),) + tuple(("8 ranks, head %d rows" % h, {"hot_rows": h}) for h in (160000, 80000, 40000, 20000, 10000))
+if "default" in sys.argv[2:]:      # what the library picks, nothing forced
+    sets = (("8 ranks, library defaults", {}),)
 for name, knob in sets:
     with E.tuning(**knob):
         ms = [E.SgnsModel.create(cfg, counts, 0) for _ in range(N)]
