@@ -712,6 +712,10 @@ int64_t dge_sorted_batch_items(const dge_model* m, int part_n) {
     // (wide rows: from half a million items on — round 4: a 50 000-row vocabulary with rank^-0.5 popularity lands at 0.9 M and ran 3.4e8 edges/s at D = 256 under this
     //  schedule against 2.1e8 under the atomics the rule used to leave it with: scripts/policy_sweep.py)
     //  — on rows of more than 128 floats: with D = 64 the same vocabulary runs 7.9e8 under atomics against 4.2e8 here; the sorts do not shrink with the row)
+    // One block of the multi-GPU schedule on a vocabulary large enough for the lock kernels (>= 32 768 rows a partition): those — the mixed kernel on a skewed
+    // vocabulary — are the alternative there, not atomics, and a mini-batch that the busiest row keeps small loses to them: cfg5 at 2 ranks landed at 0.7 M items and
+    // ran 4.6e7 edges/s per rank here against 8.6e7 under the mixed kernel at 4 ranks (round 5).  From 4 M items on (cfg3's blocks: 16 .. 18 M).
+    if (n >= 2 && m->V / n >= 32768) return items >= (4 << 20) ? items : 0;
     return items >= (m->stride > 128 ? (1 << 19) : (1 << 20)) ? items : 0;
 }
 
