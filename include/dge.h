@@ -363,8 +363,9 @@ enum {
     DGE_TUNE_STATIC_WALKS = 7,    /* > 0: the lock kernels' worker w trains walks w, w + workers, ... instead of taking them from a launch-wide counter */
     DGE_TUNE_HS_COLD = 8,         /* hierarchical softmax under atomics: inner nodes [0, value) take plain read-modify-write (default: those on < 2e-5 of the paths — derived from the COUNTS the model was created with: they must describe the corpus that is trained, or updates of nodes that are busier than their count says are lost; 0 = every node by atomics) */
     DGE_TUNE_HS_WAVE = 9,         /* hierarchical softmax under atomics: 0 = the workers issue their atomics themselves, 1 = through the workgroup's atomics wave (default: the wave from 65 536 rows on) */
-    DGE_TUNE_ACC_ROWS = 10,       /* update_policy 7: the hottest rows [0, value) add their syn1neg updates up in LDS (one set of atomics per DGE_TUNE_ACC_DRAIN updates; the kernel caps the value at what its LDS holds, 8 .. 16); default 0 = none: measured it buys 2-4 % and, from 16 updates a flush on, shifts the trained scores */
-    DGE_TUNE_ACC_DRAIN = 11,      /* updates of such a row between two flushes (default 16) */
+    DGE_TUNE_ACC_ROWS = 10,       /* update_policy 7: the hottest rows [0, value) add their syn1neg updates up in LDS (one set of atomics per DGE_TUNE_ACC_DRAIN updates; the kernel caps the value at what its LDS holds, 8 .. 16); one GPU: default 0 = none (measured: 2-4 %, and from 16 updates a flush on it shifts the trained scores).
+                                     One block of the multi-GPU schedule (v106): the partition's hottest `value` rows of BOTH tables (a bank each; slot = the row's rank inside the partition); default 16 where the busiest row's chain of atomics is long against the block, else 0; 0 = off, > 0 = on whatever the chain */
+    DGE_TUNE_ACC_DRAIN = 11,      /* updates of such a row between two flushes (one GPU: default 16; a block: default 2048 / workgroups of the launch = 4 — 16 diverges there, measured) */
     DGE_TUNE_TABLE_RUNS = 12,     /* the negative-sampling table's run form (dge_model_table_runs): 0 = not built / not used (the lock kernels read the table), N > 0 = built from at most N runs of the vocabulary's tail (tests: the head rows in front stay on the table); default: up to 2 046 runs */
     DGE_TUNE_BLOCK_SYN0_FREE = 13, /* block schedule, mixed lock kernel: 1 = the pair's syn0 row is never locked (agent-scope read, atomics), 0 = it is locked unless it is a head row; default: the library's rule */
     DGE_TUNE_HS_CENTRE = 14,      /* hierarchical softmax under atomics: 0 = pair by pair (k_sgns_train), 1 = a wave per centre wherever it applies (rows of up to 128 floats, walks of up to 64 tokens; k_sgns_train_hsw); 2 = that kernel with the pair's negatives and the centre's gathered syn1neg update under the rows' commit locks instead of atomics, 3 = the same in workgroups of seven training waves (one a compute unit) that share their LDS accumulators; default: a wave per centre from 65 536 vocabulary rows on — form 3 where update_policy 0 would pick the commit locks for the negative-sampling kernels, form 1 elsewhere */
