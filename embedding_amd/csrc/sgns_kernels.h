@@ -228,11 +228,15 @@ __device__ __forceinline__ void row_unlock(int* locks, int32_t row) {
     else __hip_atomic_store(&locks[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sum over the 16 lanes of a group, in every lane: four DPP steps inside the row of 16 — swap inside pairs, swap the pairs of a quad, mirror the half row, mirror the
+// row.  The same additions in the same tree as the xor butterfly (1, 2, 4, 8) it replaces (after a step every lane of a quad / half row holds the same bits: a + b ==
+// b + a), so results do not move; but __shfl_xor compiles to ds_bpermute — a trip through the LDS crossbar per step, six dot products a pair on the pair's latency chain.
+#define DGE_DPP_ADD(v, CTRL) ((v) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (CTRL), 0xF, 0xF, true)))
 __device__ __forceinline__ float group16_sum(float p) {
-    p += __shfl_xor(p, 1);
-    p += __shfl_xor(p, 2);
-    p += __shfl_xor(p, 4);
-    p += __shfl_xor(p, 8);
+    p = DGE_DPP_ADD(p, 0xB1);       // quad_perm [1, 0, 3, 2]
+    p = DGE_DPP_ADD(p, 0x4E);       // quad_perm [2, 3, 0, 1]
+    p = DGE_DPP_ADD(p, 0x141);      // row_half_mirror
+    p = DGE_DPP_ADD(p, 0x140);      // row_mirror
     return p;
 }
 
