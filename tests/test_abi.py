@@ -183,3 +183,14 @@ def test_java_surface_lists_every_member_of_the_scope_table():
         t = _java(f)
         t = re.sub(r'"(\\.|[^"\\])*"', '""', t); t = re.sub(r"'(\\.|[^'\\])'", "' '", t)
         assert t.count("{") == t.count("}") and t.count("(") == t.count(")") and t.count("[") == t.count("]"), f
+
+
+def test_tuning_knobs_of_the_ctypes_view_are_the_headers():
+    """dge_set_tuning's knob numbers: include/dge.h's enum (DGE_TUNE_<NAME> = n) and embedding_amd.engine.TUNING_KNOBS (name -> n, what tests and bench.py --tune use)
+    must be the same table — a knob added to one side only would set another knob."""
+    import embedding_amd as E
+    hdr = open(os.path.join(ROOT, "include", "dge.h")).read()
+    enum = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"\bDGE_TUNE_([A-Z0-9_]+)\s*=\s*(\d+)", hdr)}
+    count = enum.pop("count")
+    assert enum == E.engine.TUNING_KNOBS, (sorted(set(enum.items()) ^ set(E.engine.TUNING_KNOBS.items())))
+    assert sorted(enum.values()) == list(range(count))
