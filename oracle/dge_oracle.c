@@ -670,6 +670,144 @@ static int64_t train_walk(const orc_train_config* cfg, orc_model* m, const int32
     return pairs;
 }
 
+/* ---- train_walk once more with the same arithmetic and the processor's pipelines kept busy (what the test-suite and the CPU baseline run; the loop
+ * above stays the definition and orc_set_plain(1) runs it).
+ * Within one pair nothing a dot product reads is written before the pair's last line: l1 (a syn0 row) moves only in `l1[k] += neu1e[k]`, an inner node's row
+ * and a negative-sampling row only in their own term.  So where the rows of a pair's terms are pairwise distinct (a Huffman path's nodes always are; the
+ * positive target and the K draws unless a draw repeats) the terms' dot products are taken side by side — each one's additions in word2vec.c's order (arith 0)
+ * or the kernels' lane order (arith 1) — and the terms are then applied one after the other as above: the same floating-point operations on the same values,
+ * bit for bit the tables train_walk leaves.  A pair with a repeated row goes term by term.  The random draws do not depend on the arithmetic (K per pair).
+ * tests/test_oracle_kats.py compares both forms on random configurations, vocabularies of a handful of rows included. ---- */
+#define ILP_MAX 64
+static int g_orc_plain = 0;
+void orc_set_plain(int on) { g_orc_plain = on ? 1 : 0; }
+
+static void dots_seq(const float* a, float* const* rows, int n, int D, float* f) {          /* n x dot_seq, eight at a time */
+    for (int d = 0; d < n; d += 8) {
+        if (n - d == 1) { f[d] = dot_seq(a, rows[d], D); return; }
+        const float* b[8];
+        for (int j = 0; j < 8; j++) b[j] = d + j < n ? rows[d + j] : a;                      /* (a spare chain reads the vector itself; its sum is dropped) */
+        float f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0, f6 = 0, f7 = 0;
+        for (int c = 0; c < D; c++) {
+            const float x = a[c];
+            f0 += x * b[0][c]; f1 += x * b[1][c]; f2 += x * b[2][c]; f3 += x * b[3][c];
+            f4 += x * b[4][c]; f5 += x * b[5][c]; f6 += x * b[6][c]; f7 += x * b[7][c];
+        }
+        const float r[8] = {f0, f1, f2, f3, f4, f5, f6, f7};
+        for (int j = 0; j < 8 && d + j < n; j++) f[d + j] = r[j];
+    }
+}
+/* dot_lane16 with the sixteen lanes of a step next to each other (lane j still adds its elements 64c + 16e + j in increasing order, then the butterfly's lane 0) */
+static inline float dot_lane16_v(const float* a, const float* b, int D) {
+    float p[16];
+    for (int j = 0; j < 16; j++) p[j] = 0.0f;
+    int base = 0;
+    for (; base + 16 <= D; base += 16) {
+#pragma omp simd
+        for (int j = 0; j < 16; j++) p[j] = fmaf(a[base + j], b[base + j], p[j]);
+    }
+    for (int j = 0; base + j < D; j++) p[j] = fmaf(a[base + j], b[base + j], p[j]);
+    /* lane 0 of the butterfly: ((p0 + p1) + (p2 + p3)) + ... — the fifteen additions its value comes from, none of the other lanes' */
+    for (int s = 1; s < 16; s <<= 1)
+        for (int j = 0; j < 16; j += 2 * s) p[j] = p[j] + p[j + s];
+    return p[0];
+}
+static inline void apply_term(int arith, float g, const float* l1, float* l2, float* neu1e, int D) {
+    if (arith) {
+#pragma omp simd
+        for (int k = 0; k < D; k++) neu1e[k] = fmaf(g, l2[k], neu1e[k]);
+#pragma omp simd
+        for (int k = 0; k < D; k++) l2[k] = fmaf(g, l1[k], l2[k]);
+    } else {
+#pragma omp simd
+        for (int k = 0; k < D; k++) neu1e[k] += g * l2[k];
+#pragma omp simd
+        for (int k = 0; k < D; k++) l2[k] += g * l1[k];
+    }
+}
+static inline float ns_step(float f, float label, float alpha) {
+    if (f > MAX_EXP) return (label - 1) * alpha;
+    if (f < -MAX_EXP) return (label - 0) * alpha;
+    return (label - g_exp_table[(int)((f + MAX_EXP) * (EXP_TABLE_SIZE / MAX_EXP / 2))]) * alpha;
+}
+
+static int64_t train_walk_ilp(const orc_train_config* cfg, orc_model* m, const int32_t* sen, int len,
+                              int64_t gidx_base, float alpha, float* neu1e, int part_ctx, int part_tgt) {
+    const int D = cfg->dim, W = cfg->window, K = cfg->negative;
+    const int64_t V = m->V, T = m->table_size;
+    const int PN = cfg->part_n > 1 ? cfg->part_n : 1;
+    int64_t pairs = 0;
+    float* rows[ILP_MAX]; float lab[ILP_MAX], f[ILP_MAX]; int64_t tg[ILP_MAX];
+    for (int i = 0; i < len; i++) {
+        int32_t word = sen[i];
+        if (word < 0) continue;
+        const int is_tgt = PN <= 1 || word % PN == part_tgt;
+        if (!is_tgt && !cfg->use_hs) continue;
+        uint64_t s = orc_mix64(cfg->seed + (uint64_t)(gidx_base + i));
+        s = s * W2V_MULT + 11;
+        int b = (int)(s % (uint64_t)W);
+        const uint64_t s_centre = s;
+        for (int a = b; a < W * 2 + 1 - b; a++) {
+            if (a == W) continue;
+            int c = i - W + a;
+            if (c < 0 || c >= len) continue;
+            int32_t last = sen[c];
+            if (last < 0) continue;
+            if (PN > 1) {
+                if (last % PN != part_ctx) continue;
+                s = orc_mix64(s_centre + (uint64_t)c);
+            }
+            float* l1 = m->syn0 + (int64_t)last * D;
+            for (int k = 0; k < D; k++) neu1e[k] = 0;
+            if (cfg->use_hs) {                      /* the path's inner nodes: pairwise distinct rows of syn1 */
+                int n = 0;
+                for (int d = 0; d < m->codelen[word]; d++) {
+                    const int32_t node = m->points[(int64_t)word * MAX_CODE_LENGTH + d];
+                    if (PN > 1 && node % PN != part_tgt) continue;
+                    rows[n] = m->syn1 + (int64_t)node * D;
+                    lab[n] = (float)(1 - m->codes[(int64_t)word * MAX_CODE_LENGTH + d]);
+                    n++;
+                }
+                if (cfg->arith) for (int j = 0; j < n; j++) f[j] = dot_lane16_v(l1, rows[j], D);
+                else dots_seq(l1, rows, n, D, f);
+                for (int j = 0; j < n; j++) {
+                    float ff = f[j];
+                    if (ff <= -MAX_EXP) continue;
+                    else if (ff >= MAX_EXP) continue;
+                    ff = g_exp_table[(int)((ff + MAX_EXP) * (EXP_TABLE_SIZE / MAX_EXP / 2))];
+                    apply_term(cfg->arith, (lab[j] - ff) * alpha, l1, rows[j], neu1e, D);
+                }
+            }
+            if (is_tgt) {
+                int n = 0, distinct = 1;
+                tg[n] = word; lab[n] = 1; n++;
+                for (int d = 1; d < K + 1; d++) {
+                    s = s * W2V_MULT + 11;
+                    int64_t target = m->table[(s >> 16) % (uint64_t)T];
+                    if (target == 0 && V > 1) target = (int64_t)(s % (uint64_t)(V - 1)) + 1;
+                    if (PN > 1) { target = target / PN * PN + part_tgt; if (target >= V) target -= PN; }
+                    if (target == word) continue;
+                    for (int j = 1; j < n; j++) if (tg[j] == target) distinct = 0;
+                    tg[n] = target; lab[n] = 0; n++;
+                }
+                for (int j = 0; j < n; j++) rows[j] = m->syn1neg + tg[j] * D;
+                if (distinct) {
+                    if (cfg->arith) for (int j = 0; j < n; j++) f[j] = dot_lane16_v(l1, rows[j], D);
+                    else dots_seq(l1, rows, n, D, f);
+                    for (int j = 0; j < n; j++) apply_term(cfg->arith, ns_step(f[j], lab[j], alpha), l1, rows[j], neu1e, D);
+                } else
+                    for (int j = 0; j < n; j++) {       /* a draw repeats a row of this pair: its second term reads what the first wrote */
+                        const float ff = cfg->arith ? dot_lane16_v(l1, rows[j], D) : dot_seq(l1, rows[j], D);
+                        apply_term(cfg->arith, ns_step(ff, lab[j], alpha), l1, rows[j], neu1e, D);
+                    }
+            }
+            for (int k = 0; k < D; k++) l1[k] += neu1e[k];
+            pairs += is_tgt;
+        }
+    }
+    return pairs;
+}
+
 /* ---- update_policy 8: the owner-computes schedule (embedding_amd/csrc/sgns_sorted.hip), one block over walks [0, n_walks) ---- */
 typedef struct { int32_t key, other; float x; } so_item;      /* key = owning row, other = the row of the other table, x = signed alpha / g */
 
@@ -939,7 +1077,7 @@ int orc_train_sgns_from_hs(const int32_t* walks, int64_t n_walks, int32_t max_le
                 int64_t done = (int64_t)ep * m->total_words + cfg->words_before + wb[w];
                 float alpha = alpha_for(cfg, done, all_words);
                 int64_t gbase = (((int64_t)ep * total_walks) + cfg->walk_index_base + w) * (int64_t)max_len;
-                pairs += train_walk(cfg, m, buf, len, gbase, alpha, neu1e, part_ctx, part_tgt);
+                pairs += (g_orc_plain || cfg->negative + 1 > ILP_MAX ? train_walk : train_walk_ilp)(cfg, m, buf, len, gbase, alpha, neu1e, part_ctx, part_tgt);
             }
             free(neu1e);
         }

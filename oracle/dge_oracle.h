@@ -119,6 +119,9 @@ double  orc_model_seconds(const orc_model* m);          /* wall time of the trai
 void  orc_model_free(orc_model* m);
 float orc_exp_table(int i);                              /* sigmoid LUT entry (i in [0,1000)) */
 uint64_t orc_mix64(uint64_t x);
+/* 1: the trainer runs the plain word2vec.c-shaped loop (train_walk, the definition); 0 (default): the same floating-point operations with the dot products of
+ * a pair's distinct rows taken side by side (train_walk_ilp) — bit-identical tables, ~3x the speed; tests/test_oracle_kats.py compares the two */
+void  orc_set_plain(int on);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,7 @@ def lib():
     L.orc_model_free.argtypes = [vp]
     L.orc_exp_table.argtypes = [C.c_int]; L.orc_exp_table.restype = C.c_float
     L.orc_mix64.argtypes = [u64]; L.orc_mix64.restype = u64
+    L.orc_set_plain.argtypes = [C.c_int]
     _lib = L
     return L
 
@@ -264,6 +265,11 @@ def train_sgns(walks, n_vertices, dim, window, negative=5, min_count=2, epochs=1
     if rc != 0:
         raise RuntimeError("oracle train_sgns failed: rc=%d" % rc)
     return Model(h)
+
+
+def set_plain(on):
+    """True: train_sgns runs the plain word2vec.c-shaped loop (the definition); False (default): the same operations, a pair's dot products side by side."""
+    lib().orc_set_plain(int(bool(on)))
 
 
 def huffman(counts):

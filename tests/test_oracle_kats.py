@@ -338,6 +338,13 @@ def test_update_arithmetic_second_reading_in_numpy_float32(oracle):
     for use_hs in (False, True):
         m0 = oracle.train_sgns(walks, NV, D, W, negative=K, min_count=2, epochs=0, table_size=T, seed=seed, use_hs=use_hs)
         m1 = oracle.train_sgns(walks, NV, D, W, negative=K, min_count=2, epochs=1, table_size=T, seed=seed, use_hs=use_hs, arith=0)
+        # (m1: the form the suite runs — a pair's dot products side by side, train_walk_ilp; m1p: the plain word2vec.c-shaped loop, train_walk)
+        oracle.set_plain(True)
+        try:
+            m1p = oracle.train_sgns(walks, NV, D, W, negative=K, min_count=2, epochs=1, table_size=T, seed=seed, use_hs=use_hs, arith=0)
+        finally:
+            oracle.set_plain(False)
+        assert m1p.pairs == m1.pairs and np.array_equal(m1p.syn0.view(np.int32), m1.syn0.view(np.int32)) and np.array_equal(m1p.syn1neg.view(np.int32), m1.syn1neg.view(np.int32))
         V = m0.V
         remap = {int(v): r for r, v in enumerate(m0.vocab_ids)}
         table = m0.table(T)
@@ -411,6 +418,37 @@ def test_update_arithmetic_second_reading_in_numpy_float32(oracle):
         assert np.array_equal(syn1neg.view(np.int32), m1.syn1neg.view(np.int32)), use_hs
         if use_hs and V > 1:
             assert np.array_equal(syn1[:V - 1].view(np.int32), m1.syn1.view(np.int32))
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_side_by_side_dot_products_leave_the_plain_loops_tables(oracle, seed):
+    """oracle/dge_oracle.c has the pair loop twice: train_walk, shaped like word2vec.c's (the definition), and train_walk_ilp, which takes the dot products of
+    a pair's pairwise distinct rows side by side and then applies the terms in the same order (what the suite and bench.py's CPU baseline run: ~3x the
+    speed).  Same floating-point operations on the same values: the tables must be BIT-IDENTICAL — random widths (tails of both lane orders), 0 .. 30 negatives,
+    vocabularies from 3 rows (every pair repeats a row: the term-by-term branch) to thousands, ragged walks, the tree term, blocks of 2 / 3 ranks, both
+    arithmetic orders, two epochs."""
+    rng = np.random.default_rng(1000 + seed)
+    NV = int(rng.choice([3, 5, 12, 60, 400, 3000]))
+    L = int(rng.integers(2, 25)); n = int(rng.integers(20, 300))
+    D = int(rng.choice([1, 2, 7, 16, 20, 31, 64, 100, 128, 130, 200, 256]))
+    K = int(rng.choice([0, 1, 2, 5, 5, 7, 8, 9, 20, 30])); W = int(rng.integers(1, L + 1))
+    walks = rng.integers(0, NV, (n, L)).astype(np.int32)
+    if seed % 3 == 0:                                                     # a skewed vocabulary: the same rows drawn again and again
+        walks = np.minimum(walks, rng.integers(0, NV, (n, L))).astype(np.int32)
+    walks[rng.random(walks.shape) < 0.1] = -1
+    kw = dict(negative=K, min_count=int(rng.integers(1, 3)), epochs=int(rng.integers(1, 3)), table_size=int(rng.choice([53, 1009, 100_003])), seed=int(rng.integers(1, 1 << 30)),
+              arith=seed & 1, use_hs=bool((seed >> 1) & 1), part_n=int(rng.choice([0, 0, 2, 3])))
+    fast = oracle.train_sgns(walks, NV, D, W, **kw)
+    oracle.set_plain(True)
+    try:
+        plain = oracle.train_sgns(walks, NV, D, W, **kw)
+    finally:
+        oracle.set_plain(False)
+    assert fast.pairs == plain.pairs and np.array_equal(fast.vocab_ids, plain.vocab_ids), (seed, kw)
+    assert np.array_equal(fast.syn0.view(np.int32), plain.syn0.view(np.int32)), (seed, NV, D, K, kw)
+    assert np.array_equal(fast.syn1neg.view(np.int32), plain.syn1neg.view(np.int32)), (seed, NV, D, K, kw)
+    if kw["use_hs"] and fast.V > 1:
+        assert np.array_equal(fast.syn1.view(np.int32), plain.syn1.view(np.int32)), (seed, NV, D, K, kw)
 
 
 def test_oracle_continues_from_a_given_state(oracle):
