@@ -27,55 +27,72 @@ public class CrossTimeGraph extends LayeredGraph {
         return layer + "-" + region;
     }
 
-    public static CrossTimeGraph constructGraph_tract() {
-        Tracts trts = new Tracts();
-        trts.deserialzeTracts(DeepWalk.Year);
-        long t1 = System.currentTimeMillis();
-        System.out.println("Start generating cross-time graph...");
-        int timeStep = 24 / numLayer;
-        CrossTimeGraph g = new CrossTimeGraph();
-        for (int h = 0; h < numLayer; h++)
-            for (Tract a : trts.tracts.values())
-                for (Tract b : trts.tracts.values()) {
-                    int w = a.getFlowTo(b.id, h, h + timeStep - 1);
+    /** flow count of one slice between two regions: the one thing the two region levels differ in */
+    private interface SliceFlow {
+        int count(int slice, int fromRegion, int toRegion);
+    }
+
+    /**
+     * The edge rule once, for both region levels (J/CrossTimeGraph.java:36-47 and :79-89 apply it to Tracts and to CommunityAreas):
+     * every positive flow of slice h becomes one edge from layer h to layer (h+1) % numLayer; the sources are the layer-0 vertices an
+     * edge has created, in the order of `regions` (the region map's iteration order).  The edges go through addEdge because the
+     * reference exposes allEdges / allVertices as public state; the device receives them in ONE bulk call (LayeredGraph.upload).
+     */
+    private static CrossTimeGraph fromFlows(int[] regions, SliceFlow flow, String what) {
+        final long begun = System.currentTimeMillis();
+        System.out.println("Start generating " + what + "...");
+        final CrossTimeGraph g = new CrossTimeGraph();
+        for (int h = 0; h < numLayer; h++) {
+            final int next = (h + 1) % numLayer;
+            for (int from : regions)
+                for (int to : regions) {
+                    final int w = flow.count(h, from, to);
                     if (w > 0)
-                        g.addEdge(node(h, a.id), node((h + 1) % numLayer, b.id), w);
+                        g.addEdge(node(h, from), node(next, to), w);
                 }
-        for (Tract a : trts.tracts.values())
-            if (g.allVertices.containsKey(node(0, a.id)))
-                g.addSourceVertex(node(0, a.id));
-        System.out.format("Cross-time graph built successfully in %d milliseconds.\n", System.currentTimeMillis() - t1);
+        }
+        for (int r : regions)
+            if (g.allVertices.containsKey(node(0, r)))
+                g.addSourceVertex(node(0, r));
+        System.out.format("%s built successfully in %d milliseconds.\n", what, System.currentTimeMillis() - begun);
         return g;
     }
 
-    public static CrossTimeGraph constructGraph_CA() {
-        int timeStep = 24 / numLayer;                         // uniform time slots by default (:55-59)
-        int[] timeIntervals = new int[numLayer + 1];
-        for (int i = 0; i <= numLayer; i += timeStep)
-            timeIntervals[i] = (i * timeStep) % numLayer;
-        return constructGraph_CA(timeIntervals);
+    private static int[] idsOf(java.util.Collection<Integer> keys) {
+        int[] ids = new int[keys.size()];
+        int n = 0;
+        for (int k : keys)
+            ids[n++] = k;
+        return ids;
     }
 
-    /** timeIntervals[h] (inclusive) .. timeIntervals[h+1] (exclusive) is slice h (:68-95) */
+    /** J/CrossTimeGraph.java:25-52: tract level, numLayer slices of 24 / numLayer hours */
+    public static CrossTimeGraph constructGraph_tract() {
+        final Tracts trts = new Tracts();
+        trts.deserialzeTracts(DeepWalk.Year);
+        final int hours = 24 / numLayer;
+        return fromFlows(idsOf(trts.tracts.keySet()),
+                (h, a, b) -> trts.tracts.get(a).getFlowTo(b, h, h + hours - 1),
+                "cross-time graph");
+    }
+
+    /** J/CrossTimeGraph.java:54-66: community-area level with the default, uniform time slots */
+    public static CrossTimeGraph constructGraph_CA() {
+        final int hours = 24 / numLayer;
+        int[] bounds = new int[numLayer + 1];
+        for (int i = 0; i <= numLayer; i += hours)
+            bounds[i] = (i * hours) % numLayer;
+        return constructGraph_CA(bounds);
+    }
+
+    /** J/CrossTimeGraph.java:68-95: slice h covers timeIntervals[h] (inclusive) .. timeIntervals[h+1] (exclusive) */
     public static CrossTimeGraph constructGraph_CA(int[] timeIntervals) {
-        CommunityAreas cas = new CommunityAreas();
+        final CommunityAreas cas = new CommunityAreas();
         cas.deserialzeCAs(DeepWalk.Year);
         CrossTimeGraph.numLayer = timeIntervals.length - 1;
-        long t1 = System.currentTimeMillis();
-        System.out.println("Start generating crosstime graph for Communities ...");
-        CrossTimeGraph g = new CrossTimeGraph();
-        for (int h = 0; h < numLayer; h++)
-            for (CommunityArea a : cas.communities.values())
-                for (CommunityArea b : cas.communities.values()) {
-                    int w = a.getFlowTo(b.id, timeIntervals[h], timeIntervals[h + 1]);
-                    if (w > 0)
-                        g.addEdge(node(h, a.id), node((h + 1) % numLayer, b.id), w);
-                }
-        for (CommunityArea a : cas.communities.values())
-            if (g.allVertices.containsKey(node(0, a.id)))
-                g.addSourceVertex(node(0, a.id));
-        System.out.format("Crosstime graph for communities built successfully in %d milliseconds.\n", System.currentTimeMillis() - t1);
-        return g;
+        return fromFlows(idsOf(cas.communities.keySet()),
+                (h, a, b) -> cas.communities.get(a).getFlowTo(b, timeIntervals[h], timeIntervals[h + 1]),
+                "crosstime graph for communities");
     }
 
     /** J/CrossTimeGraph.java:103-112 */
