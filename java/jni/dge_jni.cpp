@@ -1,7 +1,8 @@
 // dge_jni.cpp — JNI shim between java/embedding/NativeEngine.java and libdge.so (include/dge.h).
 // Optional target: needs a JDK (jni.h); the build image has none, so this file is shipped as source only.
-//   g++ -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include dge_jni.cpp \
-//       -L../../embedding_amd -l:libdge.so -o libdge_jni.so
+//   g++ -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include dge_jni.cpp -L../../embedding_amd -l:libdge.so -o libdge_jni.so
+// Executed without a JVM by tests/native/jni_shim_test.cpp (a JNIEnv whose arrays are heap objects handed out as copies): marshalling, handles and the
+// status -> RuntimeException mapping run against the real library on the GPU box (tests/test_gpu_host_mirror.py).
 #include <jni.h>
 
 #include <algorithm>

@@ -142,6 +142,22 @@ def test_jni_shim_matches_native_engine_and_the_header():
                            "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "java", "jni", "dge_jni.cpp")])
 
 
+def test_jni_shim_turns_a_missing_device_into_the_runtime_exception(tmp_path):
+    """tests/native/jni_shim_test.cpp (the shim's own functions executed through a JNIEnv with a body instead of a JVM; the full run is a GPU test,
+    tests/test_gpu_host_mirror.py) builds and links against libdge.so here too; without a gfx950 device its first call, NativeEngine.graphCreate, must come back
+    with a null handle and a pending java.lang.RuntimeException carrying dge_last_error() — the product has no CPU path, and a Java caller is told so."""
+    import subprocess
+    exe = str(tmp_path / "jni_shim_test")
+    libdir = os.path.join(ROOT, "embedding_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "tests", "native", "jni_stub"), "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "jni_shim_test.cpp"), "-o", exe, "-L" + libdir, "-l:libdge.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    if out.returncode == 0:                                         # a box with a GPU: the whole scenario ran
+        assert "JNI SHIM OK" in out.stdout, out.stdout + out.stderr
+    else:
+        assert out.returncode == 3 and "graphCreate threw java/lang/RuntimeException" in out.stdout and "no CPU path" in out.stdout, out.stdout + out.stderr
+
+
 def test_java_surface_lists_every_member_of_the_scope_table():
     """the public Java member set a drop-in must keep (signatures from J/LayeredGraph.java, J/CrossTimeGraph.java,
     J/SpatialGraph.java, J/DeepWalk.java).  Text check only — javac is not in this image."""
