@@ -7,7 +7,9 @@
  *              under /root/reference; this restates the published word2vec.c skip-gram
  *              negative-sampling update with DL4J's pair enumeration.
  *
- * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma -fopenmp).
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mavx2 -mfma -fopenmp).
+ * The SGNS pair loop is here twice: train_walk (word2vec.c's shape: the definition) and train_walk_ilp (the same operations, a pair's dot products side by side:
+ * what runs by default; orc_set_plain(1) selects the former; tests/test_oracle_kats.py holds the two bit-identical).
  */
 #include "dge_oracle.h"
 #include <math.h>
